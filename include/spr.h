@@ -1,0 +1,219 @@
+/*
+ * spr.h -- C ABI of libspr_hip.so, the MI355X (gfx950) implementation of the
+ * Superpoints_Registration hot path.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - varlen batches are packed [sum N, C] row-major with cu_seqlens
+ *     int32[n_seg + 1] (cu[0] = 0) on the device; clouds are stacked
+ *     [src_0..src_{B-1}, tgt_0..tgt_{B-1}] as in qk_regtr_full.py:152;
+ *   - `stream` is a hipStream_t passed as void*; all work is stream ordered,
+ *     nothing synchronises, nothing allocates: scratch comes from the caller
+ *     (`ws`, size from the matching *_workspace_bytes query);
+ *   - return value 0 = success, anything else = failure; spr_last_error()
+ *     returns a thread-local message.  The Python binding raises RuntimeError,
+ *     which is what the reference's CPython modules raise
+ *     (cpp_neighbors/wrapper.cpp:201-205, cpp_subsampling/wrapper.cpp:266-270).
+ *
+ * Each function cites the reference interface it replaces (paths relative to
+ * /root/reference/src).
+ */
+#ifndef SPR_H_
+#define SPR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPR_VERSION 1
+
+/* activation codes for spr_linear / spr_instnorm */
+#define SPR_ACT_NONE 0
+#define SPR_ACT_RELU 1
+#define SPR_ACT_SIGMOID 2
+
+/* output ordering of spr_grid_subsample */
+#define SPR_ORDER_REFERENCE 0 /* libstdc++ unordered_map iteration order     */
+#define SPR_ORDER_CANONICAL 1 /* ascending (cloud, voxel key)                 */
+
+int spr_version(void);
+const char* spr_last_error(void);
+
+/* ---- a1: grid subsampling ------------------------------------------------
+ * Replaces grid_subsampling.subsample_batch(points, batches, sampleDl=, max_p=)
+ * (models/backbone_kpconv/cpp_wrappers/cpp_subsampling/wrapper.cpp:62-82 ->
+ *  grid_subsampling/grid_subsampling.cpp:109 batch_grid_subsampling), called
+ * from models/backbone_kpconv/kpconv.py:174-185 (and the GPU variant :217).
+ * Barycentres are bit-exact float32 (in-order sum * (float)(1.0/count)).
+ *   xyz      [n,3] f32        cu [nb+1] i32
+ *   out_xyz  [n,3] f32 (first *out_total rows valid)
+ *   out_lens [nb] i32         out_total [1] i32 (both device)
+ */
+size_t spr_grid_subsample_workspace_bytes(int n, int nb);
+int spr_grid_subsample(const float* xyz, const int* cu, int n, int nb, float dl,
+                       int max_p, int order_mode, float* out_xyz, int* out_lens,
+                       int* out_total, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- a2: batched fixed-radius neighbours ---------------------------------
+ * Replaces radius_neighbors.batch_query(queries, supports, q_batches,
+ * s_batches, radius=) (cpp_wrappers/cpp_neighbors/wrapper.cpp:58-75 ->
+ * neighbors/neighbors.cpp:211 batch_nanoflann_neighbors) plus the
+ * [:, :max_neighbors] slice of kpconv.py:258-262.
+ * Rows: supports of the same cloud with d2 < r*r (float32, exact reference
+ * arithmetic), ascending (d2, index), global indices, padded with ns.
+ *   out_idx [nq, limit] i32; max_count [1] i32 device = untruncated max row
+ *   count (the reference's row width); the caller may slice to
+ *   min(max_count, limit).
+ */
+size_t spr_radius_neighbors_workspace_bytes(int nq, int ns, int nb);
+int spr_radius_neighbors(const float* q_xyz, const int* q_cu, int nq,
+                         const float* s_xyz, const int* s_cu, int ns, int nb,
+                         float radius, int limit, int* out_idx, int* max_count,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ---- a4: KPConv forward ---------------------------------------------------
+ * Replaces KPConv.forward(q_pts, s_pts, neighb_inds, x)
+ * (models/backbone_kpconv/kpconv_blocks.py:269-414; rigid kernel, linear
+ * influence, 'sum' aggregation -- the only mode any shipped config selects).
+ *   nbr [nq, nbr_stride] i32, first `kmax` columns used, shadow index = ns
+ *   x [ns, cin]  weights [n_kp, cin, cout]  kernel_points [n_kp, 3]
+ *   out [nq, cout]
+ * rows_sorted != 0 promises that shadow entries only trail valid ones (true
+ * for spr_radius_neighbors output) and enables early exit.
+ * impl: 0 = default (MFMA tile kernel), 1 = simple reference kernel.
+ */
+size_t spr_kpconv_workspace_bytes(int nq, int ns, int cin, int cout);
+int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, int ns,
+                   const int* nbr, int nbr_stride, int kmax, int rows_sorted,
+                   const float* x, int cin, const float* weights, int cout,
+                   const float* kernel_points, int n_kp, float kp_extent,
+                   float* out, int impl, void* ws, size_t ws_bytes,
+                   void* stream);
+
+/* ---- a5: per-cloud InstanceNorm (+ residual add) (+ LeakyReLU) ------------
+ * Replaces BatchNormBlock.forward (kpconv_blocks.py:497-525: per-cloud
+ * nn.InstanceNorm1d, affine=False, eps, biased variance) fused with the
+ * LeakyReLU that follows it (kpconv_blocks.py:553-561, :645, :727) and with
+ * the residual add of ResnetBottleneckBlock (:741):
+ *   out = lrelu(IN(x) + add, slope)      slope = 1 -> no activation
+ * x,out [n,c] (may alias); add [n,c] or NULL; cu [nb+1].
+ * norm = 0 skips the normalisation (out = lrelu(x + add)).
+ */
+size_t spr_instnorm_workspace_bytes(int n, int nb, int c);
+int spr_instnorm(const float* x, const int* cu, int n, int nb, int c, float eps,
+                 int norm, const float* add, float slope, float* out, void* ws,
+                 size_t ws_bytes, void* stream);
+
+/* ---- a5: strided max pooling ----------------------------------------------
+ * Replaces max_pool(x, inds) (kpconv_blocks.py:127-143): max over the pooling
+ * neighbours, shadow index ns reads a zero row.  idx [nq, idx_stride], first
+ * k columns used.
+ */
+int spr_maxpool_gather(const float* x, int ns, int c, const int* idx, int nq,
+                       int idx_stride, int k, float* out, void* stream);
+
+/* ---- dense projection -------------------------------------------------------
+ * out[m,n] = act(x[m,k] @ w[n,k]^T + bias[n] + residual[m,n])
+ * Replaces the nn.Linear calls on the path: UnaryBlock.mlp
+ * (kpconv_blocks.py:549,:557), feat_proj / overlap_predictor
+ * (qk_regtr_full.py:47,:85,:176,:248), MultiheadAttention in/out projections
+ * and linear1/linear2 (transformer/transformers.py:96-104).  Exact-f32 MFMA.
+ * bias, residual may be NULL.  k must be a multiple of 32 unless n == 1.
+ */
+int spr_linear(const float* x, int m, int k, const float* w, int n,
+               const float* bias, const float* residual, int act, float* out,
+               void* stream);
+
+/* ---- LayerNorm (+ positional embedding add) --------------------------------
+ * Replaces norm1/2/3 + with_pos_embed (transformers.py:121,:196-197,:212-214,
+ * :234) and the final encoder norm (:46-48).
+ *   out_norm = LN(x) (may be NULL); out_pos = LN(x) + pos (NULL if pos NULL)
+ */
+int spr_layernorm(const float* x, int m, int c, const float* gamma,
+                  const float* beta, float eps, const float* pos,
+                  float* out_norm, float* out_pos, void* stream);
+
+/* ---- a7: sine positional embedding -----------------------------------------
+ * Replaces PositionEmbeddingCoordsSine.forward (transformer/
+ * position_embedding.py:29-50).  xyz [n,3] -> out [n,d_model].
+ */
+int spr_posemb_sine(const float* xyz, int n, int d_model, float scale,
+                    float temperature, float* out, void* stream);
+
+/* ---- a9: varlen multi-head attention core -----------------------------------
+ * Replaces the scaled-dot-product core of the four nn.MultiheadAttention
+ * calls per layer (transformers.py:198-227) on packed tokens: segment s
+ * attends from its own queries to the keys/values of segment kv_seg[s]
+ * (self: kv_seg[s] = s; cross: the partner cloud).  Key padding masks of the
+ * reference become segment bounds.
+ *   q,k,v: [T, *] f32 with row strides (in floats); head h uses columns
+ *   [h*head_dim, (h+1)*head_dim); head_dim must be 32.
+ *   cu [nseg+1]; kv_seg [nseg]; out [T, nhead*head_dim] (row stride o_stride)
+ *   max_len_host: upper bound of any segment length (sizes the grid).
+ */
+int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k,
+                        int k_stride, const float* v, int v_stride,
+                        const int* cu, const int* kv_seg, int nseg,
+                        int max_len_host, int nhead, int head_dim, float scale,
+                        float* out, int o_stride, void* stream);
+
+/* ---- a11: dual-softmax matching ---------------------------------------------
+ * Replaces the correlation / dual softmax / arg-max block of
+ * RegTR.softmax_correlation (qk_regtr_full.py:453-479, :565-588) for all pairs
+ * at once.  Pair b: src tokens = segment b, tgt tokens = segment b + npairs.
+ *   feat [T, d]; cu [2*npairs+1]
+ *   If N_b > M_b : one match per tgt token  (val,ind over src, len M_b)
+ *   else         : one match per src token  (val,ind over tgt, len N_b)
+ *   match_val / match_ind are written at the packed position of the token
+ *   that owns the match (tgt token when N>M, else src token); ind is LOCAL to
+ *   the partner cloud.  corr_ws: caller scratch for the correlation matrices,
+ *   size from spr_match_workspace_bytes (host needs the seg lengths).
+ */
+size_t spr_match_workspace_bytes(const int* cu_host, int npairs);
+int spr_match_dualsoftmax(const float* feat, int d, const int* cu,
+                          const int* cu_host, int npairs, float* match_val,
+                          int* match_ind, void* ws, size_t ws_bytes,
+                          void* stream);
+
+/* ---- a12: weighted Procrustes / Kabsch --------------------------------------
+ * Replaces compute_rigid_transform(a, b, weights) (utils/se3_torch.py:109-163)
+ * batched over pairs; 3x3 SVD by one-sided Jacobi in registers.
+ *   a,b [T,3] packed by pair_cu [npairs+1]; w [T]; out [npairs,3,4].
+ */
+int spr_weighted_procrustes(const float* a, const float* b, const float* w,
+                            const int* pair_cu, int npairs, float* out_pose,
+                            void* stream);
+
+/* ---- a13: Sinkhorn (slack) soft correspondences -----------------------------
+ * Replaces the Sinkhorn branch of softmax_correlation
+ * (qk_regtr_full.py:525-536 / :635-647) + sinkhorn() and the weighted target
+ * of compute_rigid_transform_with_sinkhorn (utils/se3_torch.py:166-239):
+ *   score = clamp(F_s F_t^T / sqrt(d), min 0)
+ *   affinity = -(score - softplus(alpha)) / (exp(beta) + 0.02)
+ *   n_iters x (row normalise incl. slack col; col normalise incl. slack row)
+ *   P = exp(.), w_i = sum_j P_ij, t_hat_i = sum_j P_ij tgt_j / (w_i + 1e-6)
+ * Outputs per src token: w [Tsrc], t_hat [Tsrc,3] (packed like the src
+ * segments).  Feed (src_xyz, t_hat, w) to spr_weighted_procrustes.
+ */
+size_t spr_sinkhorn_workspace_bytes(const int* cu_host, int npairs);
+int spr_sinkhorn_correspondences(const float* feat, int d, const float* xyz,
+                                 const int* cu, const int* cu_host, int npairs,
+                                 float alpha, float beta, int n_iters,
+                                 int slack, float* out_w, float* out_that,
+                                 void* ws, size_t ws_bytes, void* stream);
+
+/* ---- small helpers ----------------------------------------------------------*/
+/* out[i] = x[idx[i]] rows of width c (idx i32, rows >= n_src read zeros). */
+int spr_gather_rows(const float* x, int n_src, int c, const int* idx, int n,
+                    float* out, void* stream);
+
+/* MFMA / wave layout self test (writes 0 to *status_host on success). */
+int spr_selftest(int* status_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPR_H_ */

@@ -1,0 +1,163 @@
+// a9 -- varlen multi-head attention core (flash style, exact f32) on gfx950.
+//
+// Behaviour contract: the scaled-dot-product core of nn.MultiheadAttention as
+// called four times per layer in TransformerCrossEncoderLayer.forward_pre
+//   /root/reference/src/models/transformer/transformers.py:198-227
+// (softmax(Q K^T / sqrt(head_dim)) V per head, key padding mask = padded
+// positions excluded, dropout 0).  The reference pads every sequence to the
+// batch maximum and materialises (B*heads, Lq, Lk) weights; here tokens stay
+// packed, segment s reads the keys/values of segment kv_seg[s] (itself for
+// self attention, the partner cloud for cross attention) and nothing of size
+// Lq x Lk ever reaches memory.
+//
+// Kernel shape (head_dim = 32):
+//   workgroup = 4 waves = 128 queries of one (segment, head); each wave owns
+//   32 queries.  S^T = K Q^T is computed with v_mfma_f32_32x32x2_f32 so that
+//   a query is a LANE: the softmax row reductions are in-register (16
+//   accumulator registers + one cross-half shuffle), and the probabilities in
+//   the accumulator are already the B operand of O^T = V^T P^T with the key
+//   order permuted consistently on both operands -- no LDS round trip for P.
+//   K / V tiles of 32 keys are staged in LDS (row stride 33 / 32 words ->
+//   conflict-free fragment reads) and shared by the four waves.
+#include "spr_common.h"
+
+namespace spr {
+namespace {
+
+constexpr int HD = 32;        // head dim
+constexpr int KT = 32;        // keys per tile
+constexpr int QW = 32;        // queries per wave
+constexpr int QB = 128;       // queries per workgroup
+constexpr int KS = HD + 1;    // K tile row stride (words)
+
+__global__ __launch_bounds__(256) void k_attn(
+    const float* __restrict__ q, int q_stride, const float* __restrict__ k, int k_stride,
+    const float* __restrict__ v, int v_stride, const int* __restrict__ cu,
+    const int* __restrict__ kv_seg, int nhead, float scale, float* __restrict__ out,
+    int o_stride) {
+  __shared__ float Ks[KT * KS];
+  __shared__ float Vs[KT * HD];
+  const int seg = blockIdx.z, head = blockIdx.y;
+  const int qbeg = cu[seg], qlen = cu[seg + 1] - qbeg;
+  const int q0 = blockIdx.x * QB;
+  if (q0 >= qlen) return;  // uniform for the workgroup
+  const int ks = kv_seg[seg];
+  const int kbeg = cu[ks], klen = cu[ks + 1] - kbeg;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int qi = q0 + wave * QW + l31;  // this lane's query (local index)
+  const bool qok = qi < qlen;
+  const int hoff = head * HD;
+
+  // Q^T as B operand of S^T = K Q^T:  B[k = d][col = query]; step s covers
+  // d = 2s + lh.  Pre-scaled by 1/sqrt(head_dim).
+  float qreg[16];
+  {
+    const float* qp = q + (size_t)(qbeg + (qok ? qi : 0)) * q_stride + hoff;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) qreg[s] = qok ? qp[2 * s + lh] * scale : 0.f;
+  }
+
+  f32x16 o;  // O^T[d][query]: lane = query, d = (r&3) + 8*(r>>2) + 4*lh
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int kt = 0; kt < klen; kt += KT) {
+    __syncthreads();  // previous tile fully consumed
+    {
+      // 256 threads stage 32 keys x 32 dims of K and V (one float4 each)
+      const int r = tid >> 3, c4 = (tid & 7) * 4;
+      float4 kv4 = make_float4(0.f, 0.f, 0.f, 0.f), vv4 = kv4;
+      if (kt + r < klen) {
+        const size_t row = (size_t)(kbeg + kt + r);
+        kv4 = *reinterpret_cast<const float4*>(k + row * k_stride + hoff + c4);
+        vv4 = *reinterpret_cast<const float4*>(v + row * v_stride + hoff + c4);
+      }
+      float* kd = Ks + r * KS + c4;
+      kd[0] = kv4.x;
+      kd[1] = kv4.y;
+      kd[2] = kv4.z;
+      kd[3] = kv4.w;
+      *reinterpret_cast<float4*>(Vs + r * HD + c4) = vv4;
+    }
+    __syncthreads();
+
+    // S^T tile: rows = keys, cols = queries.  A[row = key l31][k = d = 2s+lh]
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    const float* kp = Ks + l31 * KS + lh;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s], qreg[s], st, 0, 0, 0);
+
+    // lane holds, for its query, the 16 keys  j(r) = (r&3) + 8*(r>>2) + 4*lh
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (j >= klen) st[r] = -INFINITY;  // tail of the key segment
+      mx = fmaxf(mx, st[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // other half-lane: other 16 keys
+    const float m_new = fmaxf(m_run, mx);    // finite: every tile has >= 1 key
+    const float corr = expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[r] = expf(st[r] - m_new);
+      psum += st[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= corr;
+
+    // O^T += V^T P^T.  Step r: lane half h contributes key j0(r) + 4h with
+    // j0(r) = (r&3) + 8*(r>>2); B operand = st[r] (already in place),
+    // A[row = d = l31][k = h] = V[j0(r) + 4h][d].
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[j * HD + l31], st[r], o, 0, 0, 0);
+    }
+  }
+
+  if (qok) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    float* op = out + (size_t)(qbeg + qi) * o_stride + hoff;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      // registers 4g..4g+3 -> d = 8g + 4*lh + (0..3): one float4
+      float4 w4 = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv,
+                              o[4 * g + 3] * inv);
+      *reinterpret_cast<float4*>(op + 8 * g + 4 * lh) = w4;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace spr
+
+using namespace spr;
+
+extern "C" int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k, int k_stride,
+                                   const float* v, int v_stride, const int* cu,
+                                   const int* kv_seg, int nseg, int max_len_host, int nhead,
+                                   int head_dim, float scale, float* out, int o_stride,
+                                   void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(head_dim == HD, "attention: head_dim must be %d (got %d)", HD, head_dim);
+  SPR_REQUIRE(nseg >= 1 && nhead >= 1 && max_len_host >= 1, "attention: bad sizes");
+  SPR_REQUIRE(q_stride % 4 == 0 && k_stride % 4 == 0 && v_stride % 4 == 0 && o_stride % 4 == 0,
+              "attention: row strides must be multiples of 4 floats");
+  SPR_REQUIRE(nseg <= 65535 && nhead <= 65535, "attention: grid too large");
+  dim3 grid(cdiv(max_len_host, QB), nhead, nseg);
+  hipLaunchKernelGGL(k_attn, grid, dim3(256), 0, stream, q, q_stride, k, k_stride, v, v_stride, cu,
+                     kv_seg, nhead, scale, out, o_stride);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}

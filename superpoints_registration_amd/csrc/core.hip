@@ -1,0 +1,93 @@
+// Error reporting, version and an on-device self test of the two f32 MFMA
+// fragment layouts every kernel in this library relies on.
+#include <cstring>
+#include <vector>
+
+#include "spr_common.h"
+
+namespace spr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+// D[16x16] = A[16x4] B[4x16] with A[l&15][l>>4], B[l>>4][l&15];
+// D: col = l&15, row = 4*(l>>4) + r
+__global__ void k_test_16x16x4(const float* A, const float* B, float* D) {
+  const int l = threadIdx.x;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[(l & 15) * 4 + (l >> 4)], B[(l >> 4) * 16 + (l & 15)],
+                                             acc, 0, 0, 0);
+  for (int r = 0; r < 4; ++r) D[(4 * (l >> 4) + r) * 16 + (l & 15)] = acc[r];
+}
+// D[32x32] = A[32x2] B[2x32] with A[l&31][l>>5], B[l>>5][l&31];
+// D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+__global__ void k_test_32x32x2(const float* A, const float* B, float* D) {
+  const int l = threadIdx.x;
+  f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(l & 31) * 2 + (l >> 5)], B[(l >> 5) * 32 + (l & 31)],
+                                             acc, 0, 0, 0);
+  for (int r = 0; r < 16; ++r)
+    D[((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + (l & 31)] = acc[r];
+}
+}  // namespace
+}  // namespace spr
+
+using namespace spr;
+
+extern "C" int spr_version(void) { return SPR_VERSION; }
+extern "C" const char* spr_last_error(void) { return g_err; }
+
+extern "C" int spr_selftest(int* status_host) {
+  *status_host = -1;
+  float *dA, *dB, *dD;
+  SPR_HIP_CHECK(hipMalloc(&dA, 4096));
+  SPR_HIP_CHECK(hipMalloc(&dB, 4096));
+  SPR_HIP_CHECK(hipMalloc(&dD, 8192));
+  int bad = 0;
+  {
+    std::vector<float> A(64), B(64), D(256), R(256, 0.f);
+    for (int i = 0; i < 16; ++i)
+      for (int k = 0; k < 4; ++k) A[i * 4 + k] = (float)(1 + i * 3 + k * 7);   // asymmetric
+    for (int k = 0; k < 4; ++k)
+      for (int j = 0; j < 16; ++j) B[k * 16 + j] = (float)(2 + k * 5 - j * 2);
+    for (int i = 0; i < 16; ++i)
+      for (int j = 0; j < 16; ++j)
+        for (int k = 0; k < 4; ++k) R[i * 16 + j] += A[i * 4 + k] * B[k * 16 + j];
+    SPR_HIP_CHECK(hipMemcpy(dA, A.data(), 256, hipMemcpyHostToDevice));
+    SPR_HIP_CHECK(hipMemcpy(dB, B.data(), 256, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_16x16x4, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+    SPR_HIP_CHECK(hipMemcpy(D.data(), dD, 1024, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 256; ++i)
+      if (D[i] != R[i]) bad |= 1;
+  }
+  {
+    std::vector<float> A(64), B(64), D(1024), R(1024, 0.f);
+    for (int i = 0; i < 32; ++i)
+      for (int k = 0; k < 2; ++k) A[i * 2 + k] = (float)(1 + i * 3 + k * 11);
+    for (int k = 0; k < 2; ++k)
+      for (int j = 0; j < 32; ++j) B[k * 32 + j] = (float)(2 + k * 5 - j * 2);
+    for (int i = 0; i < 32; ++i)
+      for (int j = 0; j < 32; ++j)
+        for (int k = 0; k < 2; ++k) R[i * 32 + j] += A[i * 2 + k] * B[k * 32 + j];
+    SPR_HIP_CHECK(hipMemcpy(dA, A.data(), 256, hipMemcpyHostToDevice));
+    SPR_HIP_CHECK(hipMemcpy(dB, B.data(), 256, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_test_32x32x2, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+    SPR_HIP_CHECK(hipMemcpy(D.data(), dD, 4096, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 1024; ++i)
+      if (D[i] != R[i]) bad |= 2;
+  }
+  (void)hipFree(dA);
+  (void)hipFree(dB);
+  (void)hipFree(dD);
+  *status_host = bad;
+  if (bad) set_error("MFMA layout self test failed (mask %d)", bad);
+  return bad ? 1 : 0;
+}

@@ -1,0 +1,256 @@
+// Dense projections, LayerNorm and the sine positional embedding on gfx950.
+//
+// Behaviour contract:
+//   nn.Linear call sites: UnaryBlock.mlp (kpconv_blocks.py:549,:557),
+//     feat_proj / overlap_predictor (qk_regtr_full.py:47,:85,:176,:248-249),
+//     MultiheadAttention in_proj / out_proj and linear1 / linear2
+//     (transformer/transformers.py:96-104, :198-238)
+//   nn.LayerNorm + with_pos_embed  transformers.py:121, :196-197, :212-214
+//   PositionEmbeddingCoordsSine.forward  transformer/position_embedding.py:29-50
+//
+// GEMM: out[M,N] = act(X[M,K] @ W[N,K]^T + bias + residual), both operands
+// K-contiguous ("NT").  Exact-f32 matrix cores (v_mfma_f32_32x32x2_f32: a
+// k-ordered fmaf chain, no reduced-precision path), one 32x32 accumulator per
+// wave, BMxBN workgroup tile staged through LDS with a row stride of 33 words
+// (conflict-free fragment reads); the next K-slab is prefetched into
+// registers while the current one feeds the MFMAs.
+#include "spr_common.h"
+
+namespace spr {
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDSK = BK + 1;
+
+// WM x WN waves, each a 32x32 tile.  256 threads when WM*WN == 4.
+template <int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt(
+    const float* __restrict__ X, int M, int K, const float* __restrict__ Wt, int N,
+    const float* __restrict__ bias, const float* __restrict__ residual, int act,
+    float* __restrict__ out) {
+  constexpr int BM = WM * 32, BN = WN * 32, NT = WM * WN * 64;
+  constexpr int A_F4 = BM * BK / 4, B_F4 = BN * BK / 4;  // float4 per slab
+  constexpr int A_PT = (A_F4 + NT - 1) / NT, B_PT = (B_F4 + NT - 1) / NT;
+  __shared__ float As[BM * LDSK];
+  __shared__ float Bs[BN * LDSK];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+  float4 ra[A_PT], rb[B_PT];
+  auto load_slab = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) {
+      const int f = tid + i * NT;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < A_F4) {
+        const int r = f / (BK / 4), c4 = f % (BK / 4);
+        if (m0 + r < M)
+          ra[i] = *reinterpret_cast<const float4*>(X + (size_t)(m0 + r) * K + k0 + c4 * 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) {
+      const int f = tid + i * NT;
+      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (f < B_F4) {
+        const int r = f / (BK / 4), c4 = f % (BK / 4);
+        if (n0 + r < N)
+          rb[i] = *reinterpret_cast<const float4*>(Wt + (size_t)(n0 + r) * K + k0 + c4 * 4);
+      }
+    }
+  };
+  auto store_slab = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) {
+      const int f = tid + i * NT;
+      if (f < A_F4) {
+        const int r = f / (BK / 4), c4 = f % (BK / 4);
+        float* d = As + r * LDSK + c4 * 4;
+        d[0] = ra[i].x;
+        d[1] = ra[i].y;
+        d[2] = ra[i].z;
+        d[3] = ra[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) {
+      const int f = tid + i * NT;
+      if (f < B_F4) {
+        const int r = f / (BK / 4), c4 = f % (BK / 4);
+        float* d = Bs + r * LDSK + c4 * 4;
+        d[0] = rb[i].x;
+        d[1] = rb[i].y;
+        d[2] = rb[i].z;
+        d[3] = rb[i].w;
+      }
+    }
+  };
+
+  load_slab(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    store_slab();
+    __syncthreads();
+    if (k0 + BK < K) load_slab(k0 + BK);
+    const float* ap = As + (wm * 32 + l31) * LDSK + lh;
+    const float* bp = Bs + (wn * 32 + l31) * LDSK + lh;
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+      // A[i = l&31][k = 2s + (l>>5)],  B[k][j = l&31]
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int col = n0 + wn * 32 + l31;
+  if (col < N) {
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < M) {
+        float v = acc[r] + bv;
+        if (residual) v += residual[(size_t)row * N + col];
+        if (act == SPR_ACT_RELU) v = fmaxf(v, 0.f);
+        if (act == SPR_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+        out[(size_t)row * N + col] = v;
+      }
+    }
+  }
+}
+
+// N small (overlap_predictor, N = 1): one wave per (row, n).
+__global__ void k_gemv_rows(const float* __restrict__ X, int M, int K, const float* __restrict__ Wt,
+                            int N, const float* __restrict__ bias,
+                            const float* __restrict__ residual, int act, float* __restrict__ out) {
+  const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wid >= (long)M * N) return;
+  const int row = (int)(wid / N), n = (int)(wid % N);
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += X[(size_t)row * K + k] * Wt[(size_t)n * K + k];
+  s = wave_sum(s);
+  if (lane == 0) {
+    float v = s + (bias ? bias[n] : 0.f);
+    if (residual) v += residual[(size_t)row * N + n];
+    if (act == SPR_ACT_RELU) v = fmaxf(v, 0.f);
+    if (act == SPR_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+    out[(size_t)row * N + n] = v;
+  }
+}
+
+// One wave per row; c % 64 == 0, c <= 1024.
+template <int MAXV>
+__global__ void k_layernorm(const float* __restrict__ x, int m, int c,
+                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                            float eps, const float* __restrict__ pos, float* __restrict__ out_norm,
+                            float* __restrict__ out_pos) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= m) return;
+  const int nv = c >> 6;
+  float v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    v[i] = (i < nv) ? x[(size_t)row * c + i * 64 + lane] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)c;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const float d = (i < nv) ? v[i] - mean : 0.f;
+    ss += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)c + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    if (i < nv) {
+      const int ch = i * 64 + lane;
+      const float y = (v[i] - mean) * rstd * gamma[ch] + beta[ch];
+      if (out_norm) out_norm[(size_t)row * c + ch] = y;
+      if (out_pos) out_pos[(size_t)row * c + ch] = y + pos[(size_t)row * c + ch];
+    }
+  }
+}
+
+// position_embedding.py:29-50
+__global__ void k_posemb(const float* __restrict__ xyz, int n, int d_model, int npf, float scale,
+                         float temperature, float* __restrict__ out) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)n * d_model) return;
+  const int row = (int)(gid / d_model), ch = (int)(gid % d_model);
+  float v = 0.f;
+  if (ch < 3 * npf) {
+    const int axis = ch / npf, i = ch % npf;
+    // dim_t[i] = temperature ** (2 * (i // 2) / npf)
+    const float e = (float)(2 * (i / 2)) / (float)npf;
+    const float dim_t = powf(temperature, e);
+    const float a = (xyz[3 * (size_t)row + axis] * scale) / dim_t;
+    v = (i & 1) ? cosf(a) : sinf(a);
+  }
+  out[gid] = v;
+}
+
+}  // namespace
+}  // namespace spr
+
+using namespace spr;
+
+extern "C" int spr_linear(const float* x, int m, int k, const float* w, int n, const float* bias,
+                          const float* residual, int act, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(m > 0 && k > 0 && n > 0, "linear: bad sizes m=%d k=%d n=%d", m, k, n);
+  if (n < 16 || k % BK != 0) {
+    SPR_REQUIRE(n <= 64 || k % BK == 0, "linear: k must be a multiple of %d for n > 64 (k=%d n=%d)", BK, k, n);
+    const long waves = (long)m * n;
+    hipLaunchKernelGGL(k_gemv_rows, dim3(cdiv(waves * 64, 256)), dim3(256), 0, stream, x, m, k, w, n,
+                       bias, residual, act, out);
+    SPR_LAUNCH_CHECK();
+    return 0;
+  }
+  if (n % 64 == 0) {
+    hipLaunchKernelGGL((k_gemm_nt<2, 2>), dim3(n / 64, cdiv(m, 64)), dim3(256), 0, stream, x, m, k,
+                       w, n, bias, residual, act, out);
+  } else {
+    hipLaunchKernelGGL((k_gemm_nt<4, 1>), dim3(cdiv(n, 32), cdiv(m, 128)), dim3(256), 0, stream, x,
+                       m, k, w, n, bias, residual, act, out);
+  }
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_layernorm(const float* x, int m, int c, const float* gamma, const float* beta,
+                             float eps, const float* pos, float* out_norm, float* out_pos,
+                             void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(m > 0 && c % 64 == 0 && c <= 1024, "layernorm: c must be a multiple of 64 and <= 1024 (c=%d)", c);
+  SPR_REQUIRE(out_pos == nullptr || pos != nullptr, "layernorm: out_pos needs pos");
+  const int grid = cdiv((long)m * 64, 256);
+  if (c <= 256)
+    hipLaunchKernelGGL(k_layernorm<4>, dim3(grid), dim3(256), 0, stream, x, m, c, gamma, beta, eps,
+                       pos, out_norm, out_pos);
+  else
+    hipLaunchKernelGGL(k_layernorm<16>, dim3(grid), dim3(256), 0, stream, x, m, c, gamma, beta, eps,
+                       pos, out_norm, out_pos);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_posemb_sine(const float* xyz, int n, int d_model, float scale, float temperature,
+                               float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(n > 0 && d_model >= 6, "posemb: bad sizes");
+  const int npf = d_model / 3 / 2 * 2;  // position_embedding.py:21
+  const long total = (long)n * d_model;
+  hipLaunchKernelGGL(k_posemb, dim3(cdiv(total, 256)), dim3(256), 0, stream, xyz, n, d_model, npf,
+                     scale, temperature, out);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}

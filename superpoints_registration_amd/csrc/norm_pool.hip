@@ -1,0 +1,211 @@
+// a5 -- per-cloud InstanceNorm (+ residual add + LeakyReLU), strided max
+// pooling and row gather on gfx950.
+//
+// Behaviour contract:
+//   BatchNormBlock.forward  kpconv_blocks.py:497-525 (nn.InstanceNorm1d per
+//     cloud: biased variance, eps inside the sqrt, no affine, no running stats)
+//   LeakyReLU(0.1) after it  kpconv_blocks.py:553-561, :645, :727, :741
+//   max_pool                kpconv_blocks.py:127-143
+//
+// The reference loops over clouds in Python (2B slices x ~30 norms per
+// forward).  Here every norm is three stream-ordered launches over the packed
+// [sum N, C] tensor, independent of the number of clouds:
+//   1. k_in_stats   grid (cloud, split): per-channel sum / sum of squares in
+//                   float64 over a row slice (deterministic: fixed slices,
+//                   fixed-order final reduction, no atomics)
+//   2. k_in_final   mean / rstd per (cloud, channel)
+//   3. k_in_apply   float4 streaming pass: normalise, + residual, LeakyReLU
+#include "spr_common.h"
+
+namespace spr {
+namespace {
+
+// block = 256 threads = (256/CW) row lanes x CW channel lanes, CW = min(c,64)
+__global__ __launch_bounds__(256) void k_in_stats(const float* __restrict__ x,
+                                                  const int* __restrict__ cu, int c, int nsplit,
+                                                  double* __restrict__ part /*[nb][nsplit][2][c]*/) {
+  const int cloud = blockIdx.x, split = blockIdx.y;
+  const int beg = cu[cloud], end = cu[cloud + 1];
+  const int len = end - beg;
+  const int per = (len + nsplit - 1) / nsplit;
+  const int r0 = beg + split * per;
+  const int r1 = min(r0 + per, end);
+  const int cw = c < 64 ? c : 64;
+  const int rl = 256 / cw;  // row lanes
+  const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
+  __shared__ double sh[2][256];
+  for (int cb = 0; cb < c; cb += cw) {
+    const int ch = cb + tc;
+    double s = 0.0, ss = 0.0;
+    if (tr < rl && ch < c) {
+      for (int r = r0 + tr; r < r1; r += rl) {
+        const double v = (double)x[(size_t)r * c + ch];
+        s += v;
+        ss += v * v;
+      }
+    }
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = ss;
+    __syncthreads();
+    if (tr == 0 && ch < c) {
+      for (int k = 1; k < rl; ++k) {
+        s += sh[0][k * cw + tc];
+        ss += sh[1][k * cw + tc];
+      }
+      double* p = part + (((size_t)cloud * nsplit + split) * 2) * c;
+      p[ch] = s;
+      p[c + ch] = ss;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void k_in_final(const double* __restrict__ part, const int* __restrict__ cu, int nb,
+                           int c, int nsplit, float eps, float* __restrict__ mean,
+                           float* __restrict__ rstd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb * c) return;
+  const int cloud = i / c, ch = i % c;
+  double s = 0.0, ss = 0.0;
+  for (int k = 0; k < nsplit; ++k) {
+    const double* p = part + (((size_t)cloud * nsplit + k) * 2) * c;
+    s += p[ch];
+    ss += p[c + ch];
+  }
+  const int len = cu[cloud + 1] - cu[cloud];
+  const double n = len > 0 ? (double)len : 1.0;
+  const double m = s / n;
+  double var = ss / n - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[i] = (float)m;
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// One thread per 4 channels of one row.
+__global__ void k_in_apply(const float* __restrict__ x, const int* __restrict__ cu, int n, int nb,
+                           int c, int norm, const float* __restrict__ mean,
+                           const float* __restrict__ rstd, const float* __restrict__ add,
+                           float slope, float* __restrict__ out) {
+  const int c4 = c >> 2;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)n * c4) return;
+  const int row = (int)(gid / c4), q = (int)(gid % c4);
+  float4 v = reinterpret_cast<const float4*>(x)[gid];
+  if (norm) {
+    const int cloud = find_segment(cu, nb, row);
+    const float4 m = reinterpret_cast<const float4*>(mean + (size_t)cloud * c)[q];
+    const float4 r = reinterpret_cast<const float4*>(rstd + (size_t)cloud * c)[q];
+    v.x = (v.x - m.x) * r.x;
+    v.y = (v.y - m.y) * r.y;
+    v.z = (v.z - m.z) * r.z;
+    v.w = (v.w - m.w) * r.w;
+  }
+  if (add) {
+    const float4 a = reinterpret_cast<const float4*>(add)[gid];
+    v.x += a.x;
+    v.y += a.y;
+    v.z += a.z;
+    v.w += a.w;
+  }
+  v.x = v.x >= 0.f ? v.x : v.x * slope;
+  v.y = v.y >= 0.f ? v.y : v.y * slope;
+  v.z = v.z >= 0.f ? v.z : v.z * slope;
+  v.w = v.w >= 0.f ? v.w : v.w * slope;
+  reinterpret_cast<float4*>(out)[gid] = v;
+}
+
+__global__ void k_maxpool(const float* __restrict__ x, int ns, int c, const int* __restrict__ idx,
+                          int nq, int idx_stride, int k, float* __restrict__ out) {
+  const int c4 = c >> 2;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)nq * c4) return;
+  const int row = (int)(gid / c4), q = (int)(gid % c4);
+  float4 m = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+  const int* ir = idx + (size_t)row * idx_stride;
+  for (int j = 0; j < k; ++j) {
+    const int id = ir[j];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);  // shadow row (kpconv_blocks.py:136)
+    if (id >= 0 && id < ns) v = reinterpret_cast<const float4*>(x + (size_t)id * c)[q];
+    m.x = fmaxf(m.x, v.x);
+    m.y = fmaxf(m.y, v.y);
+    m.z = fmaxf(m.z, v.z);
+    m.w = fmaxf(m.w, v.w);
+  }
+  reinterpret_cast<float4*>(out)[gid] = m;
+}
+
+__global__ void k_gather_rows(const float* __restrict__ x, int n_src, int c,
+                              const int* __restrict__ idx, int n, float* __restrict__ out) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)n * c) return;
+  const int row = (int)(gid / c), ch = (int)(gid % c);
+  const int id = idx[row];
+  out[gid] = (id >= 0 && id < n_src) ? x[(size_t)id * c + ch] : 0.f;
+}
+
+int in_nsplit(int n, int nb) {
+  int s = cdiv(n, (long)nb * 512);
+  if (s < 1) s = 1;
+  if (s > 64) s = 64;
+  return s;
+}
+
+}  // namespace
+}  // namespace spr
+
+using namespace spr;
+
+extern "C" size_t spr_instnorm_workspace_bytes(int n, int nb, int c) {
+  const size_t B = (size_t)(nb > 0 ? nb : 1), C = (size_t)(c > 0 ? c : 1);
+  const int ns = in_nsplit(n, nb > 0 ? nb : 1);
+  return align_up(B * ns * 2 * C * sizeof(double), 256) + 2 * align_up(B * C * sizeof(float), 256);
+}
+
+extern "C" int spr_instnorm(const float* x, const int* cu, int n, int nb, int c, float eps,
+                            int norm, const float* add, float slope, float* out, void* ws,
+                            size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(n > 0 && nb >= 1 && c >= 4 && c % 4 == 0, "instnorm: need n>0 and c %% 4 == 0 (c=%d)", c);
+  float* mean = nullptr;
+  float* rstd = nullptr;
+  if (norm) {
+    SPR_REQUIRE(ws_bytes >= spr_instnorm_workspace_bytes(n, nb, c), "instnorm: workspace too small");
+    Workspace w(ws, ws_bytes);
+    const int nsplit = in_nsplit(n, nb);
+    double* part = w.take<double>((size_t)nb * nsplit * 2 * c);
+    mean = w.take<float>((size_t)nb * c);
+    rstd = w.take<float>((size_t)nb * c);
+    SPR_REQUIRE(rstd != nullptr, "instnorm: workspace carve failed");
+    hipLaunchKernelGGL(k_in_stats, dim3(nb, nsplit), dim3(256), 0, stream, x, cu, c, nsplit, part);
+    hipLaunchKernelGGL(k_in_final, dim3(cdiv((long)nb * c, 256)), dim3(256), 0, stream, part, cu,
+                       nb, c, nsplit, eps, mean, rstd);
+    SPR_LAUNCH_CHECK();
+  }
+  const long total = (long)n * (c / 4);
+  hipLaunchKernelGGL(k_in_apply, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, cu, n, nb, c,
+                     norm, mean, rstd, add, slope, out);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_maxpool_gather(const float* x, int ns, int c, const int* idx, int nq,
+                                  int idx_stride, int k, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(nq > 0 && ns > 0 && c % 4 == 0 && k >= 1 && k <= idx_stride, "maxpool: bad arguments");
+  const long total = (long)nq * (c / 4);
+  hipLaunchKernelGGL(k_maxpool, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, ns, c, idx, nq,
+                     idx_stride, k, out);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_gather_rows(const float* x, int n_src, int c, const int* idx, int n, float* out,
+                               void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(n > 0 && c >= 1, "gather_rows: bad arguments");
+  const long total = (long)n * c;
+  hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, n_src, c, idx,
+                     n, out);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,100 @@
+// Shared host/device helpers for libspr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+
+#include "../../include/spr.h"
+
+namespace spr {
+
+constexpr int kWave = 64;
+
+void set_error(const char* fmt, ...);
+
+#define SPR_HIP_CHECK(expr)                                                   \
+  do {                                                                        \
+    hipError_t _e = (expr);                                                   \
+    if (_e != hipSuccess) {                                                   \
+      ::spr::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                       __FILE__, __LINE__);                                   \
+      return 1;                                                               \
+    }                                                                         \
+  } while (0)
+
+#define SPR_LAUNCH_CHECK()                                                  \
+  do {                                                                      \
+    hipError_t _e = hipGetLastError();                                      \
+    if (_e != hipSuccess) {                                                 \
+      ::spr::set_error("kernel launch failed: %s (%s:%d)",                  \
+                       hipGetErrorString(_e), __FILE__, __LINE__);          \
+      return 1;                                                             \
+    }                                                                       \
+  } while (0)
+
+#define SPR_REQUIRE(cond, ...)        \
+  do {                                \
+    if (!(cond)) {                    \
+      ::spr::set_error(__VA_ARGS__);  \
+      return 2;                       \
+    }                                 \
+  } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Bump allocator over a caller supplied workspace.
+struct Workspace {
+  char* base;
+  size_t size;
+  size_t off;
+  Workspace(void* p, size_t n) : base((char*)p), size(n), off(0) {}
+  template <typename T>
+  T* take(size_t count) {
+    size_t bytes = align_up(count * sizeof(T), 256);
+    if (off + bytes > size) return nullptr;
+    T* r = (T*)(base + off);
+    off += bytes;
+    return r;
+  }
+};
+
+// ---- device helpers --------------------------------------------------------
+#ifdef __HIPCC__
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Largest s in [0, nseg) with cu[s] <= i  (cu[0] = 0, cu non-decreasing).
+__device__ __forceinline__ int find_segment(const int* __restrict__ cu, int nseg,
+                                            int i) {
+  int lo = 0, hi = nseg;  // invariant: cu[lo] <= i < cu[hi]
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (cu[mid] <= i)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+#endif
+
+}  // namespace spr
