@@ -210,6 +210,15 @@ int spr_sinkhorn_correspondences(const float* feat, int d, const float* xyz,
 int spr_gather_rows(const float* x, int n_src, int c, const int* idx, int n,
                     float* out, void* stream);
 
+/* Per-launch timing of the fused KPConv kernel with HIP events recorded on the
+ * launch stream (used by bench.py for the roofline figure; off by default).
+ * spr_prof_enable(1) clears the log and starts recording, spr_prof_enable(0)
+ * clears and stops.  spr_prof_read synchronises on the recorded events and
+ * returns up to max_records entries (all arrays HOST memory):
+ *   codes[i] = cin * 100000 + cout, nqs[i] = query count, ms[i] = duration. */
+int spr_prof_enable(int on);
+int spr_prof_read(int max_records, int* codes_host, int* nqs_host, float* ms_host);
+
 /* MFMA / wave layout self test (writes 0 to *status_host on success). */
 int spr_selftest(int* status_host);
 

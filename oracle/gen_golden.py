@@ -1,0 +1,243 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by RUNNING THE
+REFERENCE (its Python from /root/reference/src and its C++ core via
+oracle/_ref) in the dev container.  Fixtures are data only: inputs, seeds and
+the reference's outputs.  Run from the repo root:
+
+    python -m oracle.gen_golden
+
+Weights are never stored: both sides fill their state dict with
+superpoints_registration_amd.synthetic.fill_parameters(model, seed), which is
+keyed on parameter names (identical in the reference and in this package).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from oracle import native, ref_harness  # noqa: E402
+from superpoints_registration_amd import synthetic  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def _idx16(a):
+    a = np.asarray(a)
+    assert a.max() < 65536 and a.min() >= 0
+    return a.astype(np.uint16)
+
+
+def gen_preprocess():
+    """Native-operator cases straight from the compiled reference core."""
+    rng = np.random.default_rng(7)
+    cases = {}
+
+    def add(name, pts, lens, dl, radius):
+        sub, sub_lens = native.ref_grid_subsample(pts, lens, dl)
+        nb = native.ref_radius_neighbors(pts, pts, lens, lens, radius)
+        pool = native.ref_radius_neighbors(sub, pts, sub_lens, lens, radius)
+        up = native.ref_radius_neighbors(pts, sub, lens, sub_lens, 2 * radius)
+        cases[name + '.pts'] = pts.astype(np.float32)
+        cases[name + '.lens'] = np.asarray(lens, np.int32)
+        cases[name + '.dl'] = np.float32(dl)
+        cases[name + '.radius'] = np.float32(radius)
+        cases[name + '.sub'] = sub
+        cases[name + '.sub_lens'] = sub_lens
+        cases[name + '.nb'] = _idx16(nb)
+        cases[name + '.pool'] = _idx16(pool)
+        cases[name + '.up'] = _idx16(up)
+
+    # ragged surface-like clouds
+    a = synthetic.box_faces(700, rng, 1.0) + rng.normal(0, 0.003, (700, 3))
+    b = synthetic.box_faces(653, rng, 1.0) + rng.normal(0, 0.003, (653, 3)) + 5.0
+    c = synthetic.box_faces(211, rng, 0.5) - 3.0
+    add('ragged', np.concatenate([a, b, c]).astype(np.float32), [700, 653, 211], 0.05, 0.125)
+    # exact lattice: many equal-distance ties, several points per voxel
+    g = np.stack(np.meshgrid(np.arange(9), np.arange(9), np.arange(4), indexing='ij'), -1)
+    lat = (g.reshape(-1, 3) * 0.02).astype(np.float32)
+    lat = lat[rng.permutation(len(lat))]
+    add('lattice', np.concatenate([lat, lat[:150] + np.float32(1.0)]), [len(lat), 150], 0.05, 0.0625)
+    # degenerate sizes: single point cloud, 3-point cloud, negative coordinates
+    tiny = np.array([[0.1, 0.2, 0.3], [-1.0, -1.01, -1.02], [-1.03, -1.0, -1.0], [-0.98, -1.0, -1.04]],
+                    np.float32)
+    add('tiny', tiny, [1, 3], 0.05, 0.125)
+    # dense blob: neighbour counts above every configured limit (K-nearest truncation)
+    blob = rng.normal(0, 0.03, (900, 3)).astype(np.float32)
+    add('dense', blob, [500, 400], 0.02, 0.05)
+    np.savez_compressed(os.path.join(OUT, 'preprocess.npz'), **cases)
+    print('preprocess.npz', {k: v.shape for k, v in cases.items() if k.endswith('.nb')})
+
+
+def ops_inputs():
+    """Seeded inputs shared by the generator and the tests (only the
+    reference's OUTPUTS are stored in ops.npz)."""
+    R = synthetic.rand
+    rng = np.random.default_rng(3)
+    pts = (synthetic.box_faces(600, rng, 1.0) + rng.normal(0, 0.004, (600, 3))).astype(np.float32)
+    lens = np.array([330, 270], np.int32)
+    d = {'kp.pts': pts, 'kp.lens': lens, 'kp.radius': 0.125, 'kp.extent': 0.1, 'kp.sub_dl': 0.1}
+    for tag, cin, cout, seed in (('c1', 1, 64, 101), ('c32', 32, 32, 102), ('c64', 64, 128, 103),
+                                 ('c128', 128, 128, 104), ('c48', 48, 24, 105)):
+        d[f'kp.{tag}.x'] = torch.ones((600, 1)) if cin == 1 else R((600, cin), seed, -0.4, 0.6)
+        d[f'kp.{tag}.w'] = R((15, cin, cout), seed + 50, -0.25, 0.25)
+    d['in.x'] = R((600, 64), 201, -5.0, 7.0)
+    d['pe.xyz'] = R((50, 3), 202, -4.0, 4.0)
+    d['tl.s_l'], d['tl.t_l'] = [37, 50], [45, 29]
+    d['tl.src'] = [R((n, 256), 210 + i, -1.5, 1.5) for i, n in enumerate(d['tl.s_l'])]
+    d['tl.tgt'] = [R((n, 256), 220 + i, -1.5, 1.5) for i, n in enumerate(d['tl.t_l'])]
+    d['tl.src_pe'] = [R((n, 256), 230 + i, -0.7, 0.7) for i, n in enumerate(d['tl.s_l'])]
+    d['tl.tgt_pe'] = [R((n, 256), 240 + i, -0.7, 0.7) for i, n in enumerate(d['tl.t_l'])]
+    a = R((3, 200, 3), 250, -1.0, 1.0)
+    Rz = torch.from_numpy(synthetic.rotation_z(0.7)).float()
+    b = a @ Rz.t() + torch.tensor([0.3, -0.2, 0.1]) + 0.01 * R((3, 200, 3), 251)
+    a[1, :, 2] *= 1e-3                                  # nearly planar set
+    b[1] = a[1] * torch.tensor([1.0, 1.0, -1.0]) + 0.001 * R((200, 3), 252)  # mirrored -> det fix
+    d['rt.a'], d['rt.b'], d['rt.w'] = a, b, R((3, 200), 253, 0.0, 1.0)
+    d['sk.fs'], d['sk.ft'] = R((60, 256), 260, -0.9, 0.9), R((47, 256), 261, -0.9, 0.9)
+    d['sk.xs'], d['sk.xt'] = R((60, 3), 262, -1.0, 1.0), R((47, 3), 263, -1.0, 1.0)
+    d['sk.alpha'], d['sk.beta'] = 0.9, 1.1
+    return d
+
+
+def gen_ops():
+    ns = ref_harness.load()
+    blocks, se3, posemb, tr, seq = ns['blocks'], ns['se3'], ns['posemb'], ns['transformers'], ns['seq']
+    d = ops_inputs()
+    out = {}
+    pts, lens = d['kp.pts'], d['kp.lens']
+    nb = native.ref_radius_neighbors(pts, pts, lens, lens, d['kp.radius'])[:, :40]
+    out['kp.nb'] = _idx16(nb)
+    for tag in ('c1', 'c32', 'c64', 'c128', 'c48'):
+        x, w = d[f'kp.{tag}.x'], d[f'kp.{tag}.w']
+        np.random.seed(5)
+        conv = blocks.KPConv(15, 3, w.shape[1], w.shape[2], d['kp.extent'], d['kp.radius'])
+        with torch.no_grad():
+            conv.weights.copy_(w)
+            y = conv(torch.from_numpy(pts), torch.from_numpy(pts), torch.from_numpy(nb.astype(np.int64)), x)
+        out[f'kp.{tag}.kpts'] = conv.kernel_points.detach().numpy()
+        out[f'kp.{tag}.y'] = y.numpy()
+    bn = blocks.BatchNormBlock(64, True, 0.02)
+    out['in.y'] = torch.nn.functional.leaky_relu(bn(d['in.x'], torch.from_numpy(lens)), 0.1).numpy()
+    sub, sub_lens = native.ref_grid_subsample(pts, lens, d['kp.sub_dl'])
+    pool = native.ref_radius_neighbors(sub, pts, sub_lens, lens, d['kp.radius'])[:, :40]
+    out['mp.idx'] = _idx16(pool)
+    out['mp.y'] = blocks.max_pool(d['in.x'], torch.from_numpy(pool.astype(np.int64))).numpy()
+    out['pe.y'] = posemb.PositionEmbeddingCoordsSine(3, 256, scale=1.0)(d['pe.xyz']).numpy()
+
+    layer = tr.TransformerCrossEncoderLayer(256, 8, 1024, 0.0, 'relu', True, True, True, 'dot_prod')
+    synthetic.fill_parameters(layer, seed=21)
+    layer.eval()
+    sp, sm, _ = seq.pad_sequence(d['tl.src'], require_padding_mask=True)
+    tp, tm, _ = seq.pad_sequence(d['tl.tgt'], require_padding_mask=True)
+    spp, _, _ = seq.pad_sequence(d['tl.src_pe'])
+    tpp, _, _ = seq.pad_sequence(d['tl.tgt_pe'])
+    with torch.no_grad():
+        so, to = layer(sp, tp, src_key_padding_mask=sm, tgt_key_padding_mask=tm, src_pos=spp, tgt_pos=tpp)
+    out['tl.src_out'] = torch.cat(seq.unpad_sequences(so, d['tl.s_l'])).numpy()
+    out['tl.tgt_out'] = torch.cat(seq.unpad_sequences(to, d['tl.t_l'])).numpy()
+
+    out['rt.T'] = se3.compute_rigid_transform(d['rt.a'], d['rt.b'], d['rt.w']).numpy()
+    out['rt.T_unw'] = se3.compute_rigid_transform(d['rt.a'], d['rt.b']).numpy()
+
+    fs, ft, xs, xt = d['sk.fs'], d['sk.ft'], d['sk.xs'], d['sk.xt']
+    score = torch.clamp(fs @ ft.t() / 16.0, min=0.0)
+    aff = -(score - torch.nn.functional.softplus(torch.tensor(d['sk.alpha']))) / (np.exp(d['sk.beta']) + 0.02)
+    perm = torch.exp(se3.sinkhorn(aff[None], n_iters=3, slack=True))[0]
+    out['sk.w'] = perm.sum(1).numpy()
+    out['sk.that'] = (perm @ xt / (perm.sum(1, keepdim=True) + 1e-6)).numpy()
+    out['sk.T'] = se3.compute_rigid_transform_with_sinkhorn(xs[None], xt[None], aff[None], True, 3).numpy()
+    # dual softmax arg-max (qk_regtr_full.py:453-468 / :565-576), both branches
+    corr = fs @ ft.t() / 16.0
+    attn = torch.softmax(corr, 0) * torch.softmax(corr, 1)
+    v, i = attn.max(0)          # N (60) > M (47): one match per tgt
+    out['ds.val_nm'], out['ds.ind_nm'] = v.numpy(), i.numpy().astype(np.int32)
+    v, i = attn.t().max(1)      # roles swapped: N (47) <= M (60): one match per src
+    out['ds.val_mn'], out['ds.ind_mn'] = v.numpy(), i.numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, 'ops.npz'), **out)
+    print('ops.npz', len(out), 'arrays', os.path.getsize(os.path.join(OUT, 'ops.npz')) // 1024, 'KB')
+
+
+def pairs_for(cfg_tag, B):
+    if cfg_tag == '3dmatch':
+        sizes = [(1024, 900), (800, 1100)][:B]
+        return [synthetic.make_pair(max(n, m), seed=40 + i, extent=0.45, jitter=0.002,
+                                    trans=(0.03, -0.02, 0.01))[:2] for i, (n, m) in enumerate(sizes)], sizes
+    if cfg_tag == 'kitti':
+        sizes = [(1500, 1300), (1200, 1500)][:B]
+        return [synthetic.make_pair(max(n, m), seed=50 + i, extent=6.0, jitter=0.02,
+                                    trans=(0.4, -0.2, 0.05))[:2] for i, (n, m) in enumerate(sizes)], sizes
+    sizes = [(717, 650), (600, 717)][:B]
+    return [synthetic.make_sphere_pair(1024, seed=60 + i, radius=0.2)[:2] for i in range(B)], sizes
+
+
+def gen_regtr(cfg_tag, B):
+    model, cfg = ref_harness.make_model(f'qk_regtr_full_{cfg_tag}.yaml', seed=0)
+    synthetic.fill_parameters(model, seed=0)
+    pairs, sizes = pairs_for(cfg_tag, B)
+    src = [p[0][:n] for p, (n, m) in zip(pairs, sizes)]
+    tgt = [p[1][:m] for p, (n, m) in zip(pairs, sizes)]
+    block_out = {}
+    hooks = []
+    for i, blk in enumerate(model.kpf_encoder.encoder_blocks):
+        hooks.append(blk.register_forward_hook(lambda m, a, o, i=i: block_out.__setitem__(i, o.detach())))
+    batch = {'src_xyz': [torch.from_numpy(s) for s in src], 'tgt_xyz': [torch.from_numpy(t) for t in tgt],
+             'pose': torch.eye(4)[None, :3].repeat(B, 1, 1)}
+    with torch.no_grad():
+        out = model(batch)
+    for h in hooks:
+        h.remove()
+    meta = batch['kpconv_meta']
+    fx = {'B': np.int32(B), 'seed': np.int32(0)}
+    fx['sizes'] = np.asarray(sizes, np.int32)   # inputs are regenerated from seeds (pairs_for)
+    L = len(meta['points'])
+    fx['levels'] = np.int32(L)
+    for l in range(L):
+        fx[f'points{l}'] = meta['points'][l].numpy()
+        fx[f'lens{l}'] = meta['stack_lengths'][l].numpy().astype(np.int32)
+        fx[f'neighbors{l}'] = _idx16(meta['neighbors'][l].numpy())
+        if meta['pools'][l].shape[0] > 0:
+            fx[f'pools{l}'] = _idx16(meta['pools'][l].numpy())
+            fx[f'upsamples{l}'] = _idx16(meta['upsamples'][l].numpy())
+    nblk = len(model.kpf_encoder.encoder_blocks)
+    for i in range(nblk):
+        o = block_out[i]
+        fx[f'block{i}_stats'] = np.array([o.mean(), o.abs().mean(), o.abs().max()], np.float64)
+        fx[f'block{i}_head'] = o[:8].numpy()
+    fx['feats_un'] = block_out[nblk - 1].numpy()
+    fx['pose'] = out['pose'].numpy()
+    for b in range(B):
+        fx[f'src_feat{b}'] = out['src_feat'][b][0].numpy()
+        fx[f'tgt_feat{b}'] = out['tgt_feat'][b][0].numpy()
+        fx[f'src_overlap{b}'] = out['src_overlap'][b][0, :, 0].numpy()
+        fx[f'tgt_overlap{b}'] = out['tgt_overlap'][b][0, :, 0].numpy()
+        fx[f'val{b}'] = out['overlap_prob_list'][b].numpy()
+        fx[f'ind{b}'] = out['ind_list'][b].numpy().astype(np.int32)
+    path = os.path.join(OUT, f'regtr_{cfg_tag}_b{B}.npz')
+    np.savez_compressed(path, **fx)
+    print(os.path.basename(path), os.path.getsize(path) // 1024, 'KB',
+          [tuple(meta['points'][l].shape) for l in range(L)], 'pose', out['pose'][0, :, 3].numpy())
+
+
+def main():
+    assert ref_harness.available(), "needs /root/reference (dev container only)"
+    os.makedirs(OUT, exist_ok=True)
+    cwd = os.getcwd()
+    try:
+        what = sys.argv[1:] or ['preprocess', 'ops', '3dmatch', 'kitti', 'modelnet']
+        if 'preprocess' in what:
+            gen_preprocess()
+        if 'ops' in what:
+            gen_ops()
+        for tag in ('3dmatch', 'kitti', 'modelnet'):
+            if tag in what:
+                gen_regtr(tag, 2)
+    finally:
+        os.chdir(cwd)
+
+
+if __name__ == '__main__':
+    main()

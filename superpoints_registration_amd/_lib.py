@@ -1,0 +1,81 @@
+"""ctypes binding of libspr_hip.so (the C ABI declared in include/spr.h).
+
+The library is the product: there is no CPU or PyTorch fallback behind these
+calls.  If the shared object is missing or a symbol is absent, importing /
+calling fails loudly.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspr_hip.so")
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/spr.h exactly
+SIGNATURES = {
+    "spr_version": (_i, []),
+    "spr_last_error": (ctypes.c_char_p, []),
+    "spr_grid_subsample_workspace_bytes": (_sz, [_i, _i]),
+    "spr_grid_subsample": (_i, [_vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "spr_radius_neighbors_workspace_bytes": (_sz, [_i, _i, _i]),
+    "spr_radius_neighbors": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _sz, _vp]),
+    "spr_kpconv_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "spr_kpconv_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp,
+                            _i, _vp, _sz, _vp]),
+    "spr_instnorm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "spr_instnorm": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _f, _vp, _vp, _sz, _vp]),
+    "spr_maxpool_gather": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "spr_linear": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "spr_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "spr_posemb_sine": (_i, [_vp, _i, _i, _f, _f, _vp, _vp]),
+    "spr_attn_varlen_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _vp]),
+    "spr_match_workspace_bytes": (_sz, [_vp, _i]),
+    "spr_match_dualsoftmax": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "spr_weighted_procrustes": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "spr_sinkhorn_workspace_bytes": (_sz, [_vp, _i]),
+    "spr_sinkhorn_correspondences": (_i, [_vp, _i, _vp, _vp, _vp, _i, _f, _f, _i, _i, _vp, _vp, _vp,
+                                          _sz, _vp]),
+    "spr_gather_rows": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
+    "spr_selftest": (_i, [_vp]),
+    "spr_prof_enable": (_i, [_i]),
+    "spr_prof_read": (_i, [_i, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "clean"])
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(_HERE, "csrc")])
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library with typed entry points.  Raises if it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no fallback path)")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().spr_last_error()
+        raise RuntimeError(f"{what}: {msg.decode() if msg else 'error'} (status {rc})")

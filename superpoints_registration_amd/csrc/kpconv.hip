@@ -27,6 +27,8 @@
 //   ~61 KB (2 workgroups per CU); phase-2 accumulators persist across chunks.
 // The neighbour-count normaliser needs sum_c x[i,c] > 0 per support point:
 // a 1-pass pre-kernel writes one flag byte per support point.
+#include <vector>
+
 #include "spr_common.h"
 
 namespace spr {
@@ -275,6 +277,36 @@ __global__ __launch_bounds__(256) void k_kpconv_mfma(
   }
 }
 
+// ---- optional per-launch HIP-event timing (bench.py roofline leg) ------------
+struct ProfRec {
+  hipEvent_t beg, end;
+  int code;  // cin * 100000 + cout
+  int nq;
+};
+static std::vector<ProfRec> g_prof;
+static bool g_prof_on = false;
+
+struct ProfScope {
+  hipStream_t stream;
+  bool on;
+  ProfRec rec;
+  ProfScope(hipStream_t s, int cin, int cout, int nq) : stream(s), on(g_prof_on) {
+    if (!on) return;
+    rec.code = cin * 100000 + cout;
+    rec.nq = nq;
+    if (hipEventCreate(&rec.beg) != hipSuccess || hipEventCreate(&rec.end) != hipSuccess) {
+      on = false;
+      return;
+    }
+    (void)hipEventRecord(rec.beg, stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(rec.end, stream);
+    g_prof.push_back(rec);
+  }
+};
+
 template <int CC, int TQ, int NTW>
 int launch_mfma(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
                 int nbr_stride, int kmax, int rows_sorted, const float* x, int cin,
@@ -283,6 +315,7 @@ int launch_mfma(const float* q_xyz, int nq, const float* s_xyz, int ns, const in
   constexpr int STRIDE = kKP * CC + 2;
   const size_t lds = sizeof(float) * (size_t)TQ * STRIDE + sizeof(int) * TQ;
   auto kern = k_kpconv_mfma<CC, TQ, NTW>;
+  ProfScope prof(stream, cin, cout, nq);
   if (lds > 64 * 1024) {
     SPR_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -364,4 +397,30 @@ extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, in
                      inv_extent, flag, out);
   SPR_LAUNCH_CHECK();
   return 0;
+}
+
+// ---- profiling control (see include/spr.h) -----------------------------------
+extern "C" int spr_prof_enable(int on) {
+  for (auto& r : g_prof) {
+    (void)hipEventDestroy(r.beg);
+    (void)hipEventDestroy(r.end);
+  }
+  g_prof.clear();
+  g_prof_on = on != 0;
+  return 0;
+}
+
+extern "C" int spr_prof_read(int max_records, int* codes, int* nqs, float* ms) {
+  int n = 0;
+  for (auto& r : g_prof) {
+    if (n >= max_records) break;
+    if (hipEventSynchronize(r.end) != hipSuccess) break;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.beg, r.end) != hipSuccess) break;
+    codes[n] = r.code;
+    nqs[n] = r.nq;
+    ms[n] = t;
+    ++n;
+  }
+  return n;
 }

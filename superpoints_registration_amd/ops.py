@@ -1,0 +1,308 @@
+"""Tensor-level wrappers over the C ABI (include/spr.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream;
+every computation below happens in libspr_hip.so.  Inputs must be CUDA(HIP)
+tensors -- a CPU tensor raises, there is no fallback.
+"""
+import ctypes
+import math
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+ORDER_REFERENCE, ORDER_CANONICAL = 0, 1
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _dev(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a tensor on the MI355X device (got "
+                           f"{t.device if isinstance(t, torch.Tensor) else type(t)}); "
+                           "the HIP path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per device+stream (stream-ordered reuse)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def lengths_to_cu(lengths, device) -> torch.Tensor:
+    """int32 [nb+1] exclusive prefix of the per-cloud lengths."""
+    if isinstance(lengths, torch.Tensor):
+        l = lengths.to(device=device, dtype=torch.int32)
+        cu = torch.zeros(l.numel() + 1, dtype=torch.int32, device=device)
+        cu[1:] = torch.cumsum(l, 0)
+        return cu
+    arr = np.zeros(len(lengths) + 1, dtype=np.int32)
+    arr[1:] = np.cumsum(np.asarray(lengths, dtype=np.int64))
+    return torch.from_numpy(arr).to(device)
+
+
+# --------------------------------------------------------------------------- #
+def selftest() -> None:
+    st = ctypes.c_int(-1)
+    _lib.check(_lib.lib().spr_selftest(ctypes.byref(st)), "spr_selftest")
+
+
+def grid_subsample(points: torch.Tensor, cu: torch.Tensor, dl: float, max_p: int = 0,
+                   order: int = ORDER_REFERENCE) -> Tuple[torch.Tensor, torch.Tensor]:
+    """a1.  Returns (sub_points [N',3] f32, lengths [nb] i32 on device).
+    One device->host read of the output size (the reference returns exact
+    shapes too)."""
+    points = _dev(points, "points", torch.float32)
+    cu = _dev(cu, "cu", torch.int32)
+    n, nb = points.shape[0], cu.numel() - 1
+    L = _lib.lib()
+    ws = _workspace(L.spr_grid_subsample_workspace_bytes(n, nb), points.device)
+    out = torch.empty((max(n, 1), 3), dtype=torch.float32, device=points.device)
+    out_lens = torch.empty((nb,), dtype=torch.int32, device=points.device)
+    total = torch.empty((1,), dtype=torch.int32, device=points.device)
+    _lib.check(L.spr_grid_subsample(_ptr(points), _ptr(cu), n, nb, float(dl), int(max_p), int(order),
+                                    _ptr(out), _ptr(out_lens), _ptr(total), _ptr(ws), ws.numel(),
+                                    _stream(points)), "spr_grid_subsample")
+    m = int(total.item())
+    if m < 0:
+        raise RuntimeError("spr_grid_subsample: voxel grid too large for 40-bit keys")
+    return out[:m], out_lens
+
+
+def radius_neighbors(queries: torch.Tensor, supports: torch.Tensor, q_cu: torch.Tensor,
+                     s_cu: torch.Tensor, radius: float, limit: int,
+                     exact_width: bool = True) -> Tuple[torch.Tensor, int]:
+    """a2.  int32 [Nq, W] neighbour indices (shadow = Ns) and the untruncated
+    max count.  exact_width=True slices to W = min(max_count, limit) like the
+    reference (one device->host read); False keeps W = limit (no sync)."""
+    queries = _dev(queries, "queries", torch.float32)
+    supports = _dev(supports, "supports", torch.float32)
+    q_cu = _dev(q_cu, "q_cu", torch.int32)
+    s_cu = _dev(s_cu, "s_cu", torch.int32)
+    nq, ns, nb = queries.shape[0], supports.shape[0], q_cu.numel() - 1
+    L = _lib.lib()
+    ws = _workspace(L.spr_radius_neighbors_workspace_bytes(nq, ns, nb), queries.device)
+    out = torch.empty((nq, limit), dtype=torch.int32, device=queries.device)
+    mc = torch.empty((1,), dtype=torch.int32, device=queries.device)
+    _lib.check(L.spr_radius_neighbors(_ptr(queries), _ptr(q_cu), nq, _ptr(supports), _ptr(s_cu), ns,
+                                      nb, float(radius), int(limit), _ptr(out), _ptr(mc), _ptr(ws),
+                                      ws.numel(), _stream(queries)), "spr_radius_neighbors")
+    if not exact_width:
+        return out, -1
+    m = int(mc.item())
+    if m < 0:
+        raise RuntimeError("spr_radius_neighbors: cloud extent / radius exceeds 8191 cells per axis")
+    if m < 1:  # cpp_neighbors/wrapper.cpp:201-205
+        raise RuntimeError("Error")
+    return out[:, :min(m, limit)], m
+
+
+def kpconv(q_pts, s_pts, nbr, x, weights, kernel_points, kp_extent: float, rows_sorted: bool = False,
+           impl: int = 0) -> torch.Tensor:
+    """a4.  nbr may be int32 or int64 [Nq, K] (possibly a column slice)."""
+    q_pts = _dev(q_pts, "q_pts", torch.float32)
+    s_pts = _dev(s_pts, "s_pts", torch.float32)
+    x = _dev(x, "x", torch.float32)
+    weights = _dev(weights, "weights", torch.float32)
+    kernel_points = _dev(kernel_points, "kernel_points", torch.float32)
+    if not nbr.is_cuda:
+        raise RuntimeError("neighb_inds must be on the device")
+    if nbr.dtype != torch.int32:
+        nbr = nbr.to(torch.int32)
+    stride = nbr.stride(0) if nbr.stride(1) == 1 and nbr.shape[1] > 0 else None
+    if stride is None:
+        nbr = nbr.contiguous()
+        stride = nbr.shape[1]
+    nq, ns, kmax = q_pts.shape[0], s_pts.shape[0], nbr.shape[1]
+    n_kp, cin, cout = weights.shape
+    assert x.shape == (ns, cin), (x.shape, ns, cin)
+    L = _lib.lib()
+    ws = _workspace(L.spr_kpconv_workspace_bytes(nq, ns, cin, cout), x.device)
+    out = torch.empty((nq, cout), dtype=torch.float32, device=x.device)
+    _lib.check(L.spr_kpconv_fwd(_ptr(q_pts), nq, _ptr(s_pts), ns, _ptr(nbr), int(stride), kmax,
+                                int(bool(rows_sorted)), _ptr(x), cin, _ptr(weights), cout,
+                                _ptr(kernel_points), n_kp, float(kp_extent), _ptr(out), int(impl),
+                                _ptr(ws), ws.numel(), _stream(x)), "spr_kpconv_fwd")
+    return out
+
+
+def instnorm(x, cu, eps: float = 1e-5, norm: bool = True, add=None, slope: float = 1.0,
+             out=None) -> torch.Tensor:
+    """a5.  out = lrelu(InstanceNorm_per_cloud(x) + add, slope)."""
+    x = _dev(x, "x", torch.float32)
+    cu = _dev(cu, "cu", torch.int32)
+    n, c = x.shape
+    nb = cu.numel() - 1
+    if add is not None:
+        add = _dev(add, "add", torch.float32)
+        assert add.shape == x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    L = _lib.lib()
+    ws = _workspace(L.spr_instnorm_workspace_bytes(n, nb, c), x.device)
+    _lib.check(L.spr_instnorm(_ptr(x), _ptr(cu), n, nb, c, float(eps), int(bool(norm)), _ptr(add),
+                              float(slope), _ptr(out), _ptr(ws), ws.numel(), _stream(x)),
+               "spr_instnorm")
+    return out
+
+
+def maxpool(x, idx) -> torch.Tensor:
+    x = _dev(x, "x", torch.float32)
+    if idx.dtype != torch.int32:
+        idx = idx.to(torch.int32)
+    stride = idx.stride(0) if idx.stride(1) == 1 else None
+    if stride is None:
+        idx = idx.contiguous()
+        stride = idx.shape[1]
+    ns, c = x.shape
+    nq, k = idx.shape
+    out = torch.empty((nq, c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().spr_maxpool_gather(_ptr(x), ns, c, _ptr(idx), nq, int(stride), k, _ptr(out),
+                                             _stream(x)), "spr_maxpool_gather")
+    return out
+
+
+def linear(x, weight, bias=None, residual=None, act: int = ACT_NONE) -> torch.Tensor:
+    x = _dev(x, "x", torch.float32)
+    weight = _dev(weight, "weight", torch.float32)
+    m, k = x.shape
+    n = weight.shape[0]
+    assert weight.shape[1] == k
+    if bias is not None:
+        bias = _dev(bias, "bias", torch.float32)
+    if residual is not None:
+        residual = _dev(residual, "residual", torch.float32)
+        assert residual.shape == (m, n)
+    out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().spr_linear(_ptr(x), m, k, _ptr(weight), n, _ptr(bias), _ptr(residual),
+                                     int(act), _ptr(out), _stream(x)), "spr_linear")
+    return out
+
+
+def layernorm(x, gamma, beta, eps: float = 1e-5, pos=None, want_norm: bool = True):
+    """Returns (LN(x) or None, LN(x)+pos or None)."""
+    x = _dev(x, "x", torch.float32)
+    m, c = x.shape
+    out_norm = torch.empty_like(x) if want_norm else None
+    out_pos = None
+    if pos is not None:
+        pos = _dev(pos, "pos", torch.float32)
+        out_pos = torch.empty_like(x)
+    _lib.check(_lib.lib().spr_layernorm(_ptr(x), m, c, _ptr(_dev(gamma, "gamma", torch.float32)),
+                                        _ptr(_dev(beta, "beta", torch.float32)), float(eps), _ptr(pos),
+                                        _ptr(out_norm), _ptr(out_pos), _stream(x)), "spr_layernorm")
+    return out_norm, out_pos
+
+
+def posemb_sine(xyz, d_model: int, scale: float = 1.0, temperature: float = 10000.0) -> torch.Tensor:
+    xyz = _dev(xyz, "xyz", torch.float32)
+    n = xyz.shape[0]
+    out = torch.empty((n, d_model), dtype=torch.float32, device=xyz.device)
+    _lib.check(_lib.lib().spr_posemb_sine(_ptr(xyz), n, d_model, float(scale * 2 * math.pi),
+                                          float(temperature), _ptr(out), _stream(xyz)),
+               "spr_posemb_sine")
+    return out
+
+
+def attention(q, k, v, cu, kv_seg, max_len: int, nhead: int, out=None) -> torch.Tensor:
+    """a9.  q,k,v: [T, nhead*32] views (row stride may exceed the width, e.g.
+    slices of a fused [T, 3*d] projection)."""
+    for t, nm in ((q, "q"), (k, "k"), (v, "v")):
+        if not t.is_cuda or t.dtype != torch.float32 or t.stride(1) != 1:
+            raise RuntimeError(f"attention: {nm} must be a float32 device tensor with unit inner stride")
+    T, d = q.shape
+    hd = d // nhead
+    cu = _dev(cu, "cu", torch.int32)
+    kv_seg = _dev(kv_seg, "kv_seg", torch.int32)
+    nseg = cu.numel() - 1
+    if out is None:
+        out = torch.empty((T, d), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().spr_attn_varlen_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v),
+                                              v.stride(0), _ptr(cu), _ptr(kv_seg), nseg, int(max_len),
+                                              nhead, hd, 1.0 / math.sqrt(hd), _ptr(out), out.stride(0),
+                                              _stream(q)), "spr_attn_varlen_fwd")
+    return out
+
+
+def _cu_host_arr(cu_host: Sequence[int]):
+    arr = (ctypes.c_int * len(cu_host))(*[int(v) for v in cu_host])
+    return arr
+
+
+def match_dualsoftmax(feat, cu, cu_host: Sequence[int], npairs: int):
+    """a11.  Returns (val [T] f32, ind [T] i32) -- see include/spr.h."""
+    feat = _dev(feat, "feat", torch.float32)
+    cu = _dev(cu, "cu", torch.int32)
+    T, d = feat.shape
+    arr = _cu_host_arr(cu_host)
+    L = _lib.lib()
+    ws = _workspace(L.spr_match_workspace_bytes(arr, npairs), feat.device)
+    val = torch.zeros((T,), dtype=torch.float32, device=feat.device)
+    ind = torch.zeros((T,), dtype=torch.int32, device=feat.device)
+    _lib.check(L.spr_match_dualsoftmax(_ptr(feat), d, _ptr(cu), arr, npairs, _ptr(val), _ptr(ind),
+                                       _ptr(ws), ws.numel(), _stream(feat)), "spr_match_dualsoftmax")
+    return val, ind
+
+
+def sinkhorn_correspondences(feat, xyz, cu, cu_host: Sequence[int], npairs: int, alpha: float,
+                             beta: float, n_iters: int, slack: bool = True):
+    """a13.  Returns (w [Tsrc] f32, t_hat [Tsrc,3] f32) for the src tokens."""
+    feat = _dev(feat, "feat", torch.float32)
+    xyz = _dev(xyz, "xyz", torch.float32)
+    cu = _dev(cu, "cu", torch.int32)
+    T, d = feat.shape
+    tsrc = int(cu_host[npairs])
+    arr = _cu_host_arr(cu_host)
+    L = _lib.lib()
+    ws = _workspace(L.spr_sinkhorn_workspace_bytes(arr, npairs), feat.device)
+    w = torch.empty((tsrc,), dtype=torch.float32, device=feat.device)
+    that = torch.empty((tsrc, 3), dtype=torch.float32, device=feat.device)
+    _lib.check(L.spr_sinkhorn_correspondences(_ptr(feat), d, _ptr(xyz), _ptr(cu), arr, npairs,
+                                              float(alpha), float(beta), int(n_iters), int(bool(slack)),
+                                              _ptr(w), _ptr(that), _ptr(ws), ws.numel(), _stream(feat)),
+               "spr_sinkhorn_correspondences")
+    return w, that
+
+
+def weighted_procrustes(a, b, w, pair_cu) -> torch.Tensor:
+    """a12.  a,b [T,3], w [T] or None, pair_cu int32 [P+1] -> [P,3,4]."""
+    a = _dev(a, "a", torch.float32)
+    b = _dev(b, "b", torch.float32)
+    if w is not None:
+        w = _dev(w, "w", torch.float32)
+    pair_cu = _dev(pair_cu, "pair_cu", torch.int32)
+    p = pair_cu.numel() - 1
+    out = torch.empty((p, 3, 4), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().spr_weighted_procrustes(_ptr(a), _ptr(b), _ptr(w), _ptr(pair_cu), p,
+                                                  _ptr(out), _stream(a)), "spr_weighted_procrustes")
+    return out
+
+
+def gather_rows(x, idx) -> torch.Tensor:
+    x = _dev(x, "x", torch.float32)
+    idx = _dev(idx, "idx", torch.int32)
+    n_src, c = x.shape
+    n = idx.numel()
+    out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().spr_gather_rows(_ptr(x), n_src, c, _ptr(idx), n, _ptr(out), _stream(x)),
+               "spr_gather_rows")
+    return out

@@ -1,0 +1,188 @@
+"""RegTR on the HIP library -- drop-in for the forward pass of the reference's
+``src/models/qk_regtr_full.py`` (RegTR.forward :126-311, softmax_correlation
+:423-672): same constructor argument (a flat config), same batch dict in
+(`src_xyz`, `tgt_xyz` lists), same output dict keys, same state-dict names
+ so reference checkpoints load.
+
+Differences by design (documented in DESIGN.md):
+  * tokens stay packed from the encoder to the pose head; no (L,B,D) padding,
+    no per-pair Python loop in the matching head;
+  * `attn` (the dense N x M dual-softmax matrices) is not materialised; the
+    entry is a list of None unless `return_attn=True`;
+  * config-off refinements (LGR, RANSAC, ratio test, overlap weighting, top-k
+    pruning, attention/correlation affinity) raise NotImplementedError;
+  * forward only -- compute_loss / backward are the "next" rows.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .kpconv import KPFEncoder, Preprocessor
+from .transformers import (PositionEmbeddingCoordsSine, TransformerCrossEncoder,
+                           TransformerCrossEncoderLayer, make_segments)
+
+
+class _BilinearW(nn.Module):
+    """Parameter holder for the loss-only `feature_criterion(.un).W` tensors
+    (models/losses/feature_loss.py:246-260) so that state dicts round-trip."""
+
+    def __init__(self, d):
+        super().__init__()
+        self.W = nn.Parameter(torch.zeros(d, d), requires_grad=True)
+        nn.init.normal_(self.W, std=0.1)
+
+
+_UNSUPPORTED_FLAGS = ('use_lgr', 'use_ransac', 'use_ratio_test', 'threshold_corr',
+                      'remove_outliers_overlap', 'use_overlap_as_weights',
+                      'remove_points_from_val', 'use_attn_affinity', 'use_corr_affinity')
+
+
+class RegTR(nn.Module):
+    def __init__(self, cfg, *args, compute_upsamples=True, order=ops.ORDER_REFERENCE,
+                 return_attn=False, **kwargs):
+        super().__init__()
+        self.cfg = cfg
+        self.return_attn = return_attn
+        for flag in _UNSUPPORTED_FLAGS:
+            if cfg.get(flag, False):
+                raise NotImplementedError(f"cfg.{flag}=True is outside the hot-path scope "
+                                          "(off in all shipped configs)")
+        if cfg.get('pos_emb_type', 'sine') != 'sine':
+            raise NotImplementedError("only pos_emb_type='sine'")
+
+        self.preprocessor = Preprocessor(cfg, compute_upsamples=compute_upsamples, order=order)
+        self.kpf_encoder = KPFEncoder(cfg, cfg.d_embed)
+        self.feat_proj = nn.Linear(self.kpf_encoder.encoder_skip_dims[-1], cfg.d_embed, bias=True)
+        self.pos_embed = PositionEmbeddingCoordsSine(3, cfg.d_embed,
+                                                     scale=cfg.get('pos_emb_scaling', 1.0))
+        encoder_layer = TransformerCrossEncoderLayer(
+            cfg.d_embed, cfg.nhead, cfg.d_feedforward, cfg.dropout,
+            activation=cfg.transformer_act, normalize_before=cfg.pre_norm,
+            sa_val_has_pos_emb=cfg.sa_val_has_pos_emb, ca_val_has_pos_emb=cfg.ca_val_has_pos_emb,
+            attention_type=cfg.attention_type)
+        encoder_norm = nn.LayerNorm(cfg.d_embed) if cfg.pre_norm else None
+        self.transformer_encoder = TransformerCrossEncoder(encoder_layer, cfg.num_encoder_layers,
+                                                           encoder_norm, return_intermediate=False)
+        self.beta = nn.Parameter(torch.tensor(1.0))
+        self.alpha = nn.Parameter(torch.tensor(1.0))
+        self.overlap_predictor = nn.Linear(cfg.d_embed, 1)
+        if cfg.get('feature_loss_type', 'infonce') == 'infonce':
+            self.feature_criterion = _BilinearW(cfg.d_embed)
+            self.feature_criterion_un = _BilinearW(cfg.d_embed)
+
+    # ------------------------------------------------------------------ #
+    @torch.no_grad()
+    def forward(self, batch):
+        cfg = self.cfg
+        B = len(batch['src_xyz'])
+        meta = self.preprocessor(list(batch['src_xyz']) + list(batch['tgt_xyz']))
+        batch['kpconv_meta'] = meta                      # qk_regtr_full.py:153
+        lens_c = meta['_lens_host'][-1]
+        src_lens, tgt_lens = lens_c[:B], lens_c[B:]
+        xyz_c = meta['points'][-1]
+        device = xyz_c.device
+
+        # KPConv encoder on a column of ones (qk_regtr_full.py:157-166)
+        feats0 = torch.ones((meta['points'][0].shape[0], 1), dtype=torch.float32, device=device)
+        feats_un, _ = self.kpf_encoder(feats0, meta)
+        tokens = ops.linear(feats_un, self.feat_proj.weight.detach(), self.feat_proj.bias.detach())
+
+        # superpoint attention on packed tokens (qk_regtr_full.py:199-230)
+        pe = self.pos_embed(xyz_c) if cfg.transformer_encoder_has_pos_emb else None
+        cu, seg_self, seg_cross, max_len = make_segments(src_lens, tgt_lens, device)
+        cond = self.transformer_encoder.forward_packed(tokens, cu, seg_self, seg_cross, max_len, pos=pe)
+
+        # overlap head (qk_regtr_full.py:248-249)
+        overlap = ops.linear(cond, self.overlap_predictor.weight.detach(),
+                             self.overlap_predictor.bias.detach(), act=ops.ACT_SIGMOID)
+
+        # matching + pose (qk_regtr_full.py:423-672), all pairs at once
+        cu_host = [0]
+        for n in list(src_lens) + list(tgt_lens):
+            cu_host.append(cu_host[-1] + int(n))
+        val, ind = ops.match_dualsoftmax(cond, cu, cu_host, B)
+        n_src = cu_host[B]
+        src_xyz_all, tgt_xyz_all = xyz_c[:n_src], xyz_c[n_src:]
+        if cfg.use_sinkhorn:
+            w, t_hat = ops.sinkhorn_correspondences(cond, xyz_c, cu, cu_host, B,
+                                                    float(self.alpha), float(self.beta),
+                                                    int(cfg.sinkhorn_itr), bool(cfg.slack))
+            pose = ops.weighted_procrustes(src_xyz_all, t_hat, w, cu[:B + 1].contiguous())
+        else:
+            pose = self._pose_from_matches(xyz_c, val, ind, cu, cu_host, B)
+
+        # ---- reference-shaped outputs (lists over the batch) ----
+        def split(t, lens, off):
+            out, o = [], off
+            for n in lens:
+                out.append(t[o:o + n])
+                o += n
+            return out
+
+        src_feat = [f.unsqueeze(0) for f in split(cond, src_lens, 0)]
+        tgt_feat = [f.unsqueeze(0) for f in split(cond, tgt_lens, n_src)]
+        src_kp, tgt_kp = split(xyz_c, src_lens, 0), split(xyz_c, tgt_lens, n_src)
+        src_ov = [o.unsqueeze(0) for o in split(overlap, src_lens, 0)]
+        tgt_ov = [o.unsqueeze(0) for o in split(overlap, tgt_lens, n_src)]
+        vals, inds, src_corr, tgt_corr = [], [], [], []
+        for b in range(B):
+            N, M = src_lens[b], tgt_lens[b]
+            if N > M:   # one match per tgt point (qk_regtr_full.py:455-479)
+                sl = slice(cu_host[B + b], cu_host[B + b + 1])
+                v, i = val[sl], ind[sl].long()
+                s_pts = src_kp[b] if cfg.use_sinkhorn else src_kp[b][i]
+                t_pts = tgt_kp[b]
+            else:       # one match per src point (:563-588)
+                sl = slice(cu_host[b], cu_host[b + 1])
+                v, i = val[sl], ind[sl].long()
+                s_pts = src_kp[b]
+                t_pts = tgt_kp[b] if cfg.use_sinkhorn else tgt_kp[b][i]
+            vals.append(v)
+            inds.append(i)
+            src_corr.append(s_pts)
+            tgt_corr.append(t_pts)
+
+        attn = [None] * B
+        if self.return_attn:
+            attn = [self._dense_attn(src_feat[b][0], tgt_feat[b][0]) for b in range(B)]
+        return {
+            'pose': pose, 'attn': attn,
+            'src_feat': src_feat, 'tgt_feat': tgt_feat,
+            'src_kp': src_kp, 'tgt_kp': tgt_kp,
+            'src_corr': src_corr, 'tgt_corr': tgt_corr,
+            'src_overlap': src_ov, 'tgt_overlap': tgt_ov,
+            'overlap_prob_list': vals, 'ind_list': inds,
+        }
+
+    def _pose_from_matches(self, xyz_c, val, ind, cu, cu_host, B):
+        """arg-max correspondences -> weighted Procrustes for all pairs in one
+        launch.  For pair b the matched set lives on the tgt tokens when
+        N_b > M_b and on the src tokens otherwise; build packed (a, b, w) by
+        index arithmetic on the device."""
+        device = xyz_c.device
+        a_idx, b_idx, w_idx, set_cu = [], [], [], [0]
+        for b in range(B):
+            s0, s1 = cu_host[b], cu_host[b + 1]
+            t0, t1 = cu_host[B + b], cu_host[B + b + 1]
+            if (s1 - s0) > (t1 - t0):
+                own = torch.arange(t0, t1, device=device)
+                a_idx.append(ind[t0:t1].long() + s0)   # matched src point
+                b_idx.append(own)                      # tgt point itself
+            else:
+                own = torch.arange(s0, s1, device=device)
+                a_idx.append(own)
+                b_idx.append(ind[s0:s1].long() + t0)
+            w_idx.append(own)
+            set_cu.append(set_cu[-1] + own.numel())
+        a_idx, b_idx, w_idx = torch.cat(a_idx), torch.cat(b_idx), torch.cat(w_idx)
+        a = ops.gather_rows(xyz_c, a_idx.to(torch.int32))
+        bb = ops.gather_rows(xyz_c, b_idx.to(torch.int32))
+        w = val[w_idx]
+        return ops.weighted_procrustes(a, bb, w, torch.tensor(set_cu, dtype=torch.int32, device=device))
+
+    @staticmethod
+    def _dense_attn(fs, ft):
+        """Optional dense dual-softmax matrix for analysis (qk_regtr_full.py:453-459):
+        correlation GEMM on the library, the two softmaxes as tensor ops."""
+        corr = ops.linear(fs, ft) / (fs.shape[1] ** 0.5)
+        return (torch.softmax(corr, dim=0) * torch.softmax(corr, dim=1)).unsqueeze(0)

@@ -1,0 +1,212 @@
+"""Superpoint self/cross-attention encoder -- host-side mirror of the
+reference's ``src/models/transformer/transformers.py`` (TransformerCrossEncoder
+:18-82, TransformerCrossEncoderLayer :84-258) and
+``position_embedding.py`` (PositionEmbeddingCoordsSine :7-50) on the HIP
+library.
+
+Parameter containers are the same torch modules the reference uses
+(nn.MultiheadAttention, nn.Linear, nn.LayerNorm), so state-dict names and
+shapes are identical; their forward() is never called -- projections, the
+attention core and the norms run in libspr_hip.so on PACKED tokens
+(cu_seqlens), not on the reference's zero-padded (L, B, D) layout.
+
+Two entry points:
+  * forward(src, tgt, ..., src_key_padding_mask, ...)  the reference signature
+    (padded (L,B,D) in, (1,L,B,D) out) for drop-in use;
+  * forward_packed(x, cu, ...)  the native packed path RegTR uses.
+"""
+import copy
+import math
+from typing import Optional
+
+import torch
+from torch import nn, Tensor
+
+from . import ops
+
+
+class PositionEmbeddingCoordsSine(nn.Module):
+    """position_embedding.py:7-50."""
+
+    def __init__(self, n_dim: int = 1, d_model: int = 256, temperature=10000, scale=None):
+        super().__init__()
+        if n_dim != 3:
+            raise NotImplementedError("the hot path embeds 3-D coordinates")
+        self.n_dim = n_dim
+        self.num_pos_feats = d_model // n_dim // 2 * 2
+        self.temperature = temperature
+        self.padding = d_model - self.num_pos_feats * self.n_dim
+        self.d_model = d_model
+        if scale is None:
+            scale = 1.0
+        self.scale_arg = scale
+        self.scale = scale * 2 * math.pi
+
+    def forward(self, xyz: torch.Tensor) -> torch.Tensor:
+        assert xyz.shape[-1] == self.n_dim
+        lead = xyz.shape[:-1]
+        out = ops.posemb_sine(xyz.reshape(-1, 3), self.d_model, scale=self.scale_arg,
+                              temperature=float(self.temperature))
+        return out.view(*lead, self.d_model)
+
+
+def _pack(padded: Tensor, key_padding_mask: Optional[Tensor]):
+    """(L,B,D) + mask (B,L) [True = pad]  ->  packed [sum L_b, D], lengths."""
+    L, B, D = padded.shape
+    if key_padding_mask is None:
+        lens = [L] * B
+    else:
+        lens = (~key_padding_mask).sum(dim=1).tolist()
+    seqs = [padded[:lens[b], b, :] for b in range(B)]
+    return torch.cat(seqs, dim=0).contiguous(), lens
+
+
+def _unpack(packed: Tensor, lens, L: int):
+    B, D = len(lens), packed.shape[1]
+    out = packed.new_zeros((L, B, D))
+    off = 0
+    for b, n in enumerate(lens):
+        out[:n, b, :] = packed[off:off + n]
+        off += n
+    return out
+
+
+class TransformerCrossEncoderLayer(nn.Module):
+    """transformers.py:84-258."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu",
+                 normalize_before=False, sa_val_has_pos_emb=False, ca_val_has_pos_emb=False,
+                 attention_type='dot_prod', batch_first=False):
+        super().__init__()
+        if attention_type != 'dot_prod':
+            raise NotImplementedError
+        if activation != "relu":
+            raise NotImplementedError("only transformer_act='relu' (all shipped configs)")
+        if dropout != 0.0:
+            raise NotImplementedError("dropout must be 0.0 (all shipped configs; inference path)")
+        if (d_model // nhead) != 32:
+            raise NotImplementedError("head_dim must be 32 (d_embed 256 / nhead 8)")
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.dropout3 = nn.Dropout(dropout)
+        self.d_model = d_model
+        self.nhead = nhead
+        self.normalize_before = normalize_before
+        self.sa_val_has_pos_emb = sa_val_has_pos_emb
+        self.ca_val_has_pos_emb = ca_val_has_pos_emb
+        self.satt_weights, self.xatt_weights = None, None  # never materialised here
+
+    # -- one MHA over packed tokens: in_proj GEMM, attention core, out_proj GEMM (+ residual)
+    def _mha(self, mha: nn.MultiheadAttention, qk_in, v_in, cu, kv_seg, max_len, residual):
+        d = self.d_model
+        W, b = mha.in_proj_weight.detach(), mha.in_proj_bias.detach()
+        if v_in is qk_in:
+            qkv = ops.linear(qk_in, W, b)                      # [T, 3d]
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        else:
+            qk = ops.linear(qk_in, W[:2 * d], b[:2 * d])       # [T, 2d]
+            q, k = qk[:, :d], qk[:, d:]
+            v = ops.linear(v_in, W[2 * d:], b[2 * d:])
+        o = ops.attention(q, k, v, cu, kv_seg, max_len, self.nhead)
+        return ops.linear(o, mha.out_proj.weight.detach(), mha.out_proj.bias.detach(),
+                          residual=residual)
+
+    def _ln(self, norm: nn.LayerNorm, x, pos, need_plain):
+        plain, with_pos = ops.layernorm(x, norm.weight.detach(), norm.bias.detach(), norm.eps,
+                                        pos=pos, want_norm=need_plain or pos is None)
+        return plain, (with_pos if pos is not None else plain)
+
+    def forward_packed(self, x, cu, seg_self, seg_cross, max_len, pos=None):
+        """x: [T, d] packed tokens of all 2B clouds; returns the updated tokens.
+        Pre-norm (transformers.py:184-245) or post-norm (:124-182)."""
+        if self.normalize_before:
+            # self attention (same weights for src and tgt clouds)
+            x2, x2p = self._ln(self.norm1, x, pos, need_plain=not self.sa_val_has_pos_emb)
+            x = self._mha(self.self_attn, x2p, x2p if self.sa_val_has_pos_emb else x2, cu, seg_self,
+                          max_len, residual=x)
+            # cross attention (keys/values from the partner cloud)
+            x2, x2p = self._ln(self.norm2, x, pos, need_plain=not self.ca_val_has_pos_emb)
+            x = self._mha(self.multihead_attn, x2p, x2p if self.ca_val_has_pos_emb else x2, cu,
+                          seg_cross, max_len, residual=x)
+            # feed forward
+            x2, _ = self._ln(self.norm3, x, None, need_plain=True)
+            h = ops.linear(x2, self.linear1.weight.detach(), self.linear1.bias.detach(), act=ops.ACT_RELU)
+            x = ops.linear(h, self.linear2.weight.detach(), self.linear2.bias.detach(), residual=x)
+            return x
+        # post-norm
+        xp = x + pos if pos is not None else x
+        y = self._mha(self.self_attn, xp, xp if self.sa_val_has_pos_emb else x, cu, seg_self, max_len,
+                      residual=x)
+        x, _ = self._ln(self.norm1, y, None, True)
+        xp = x + pos if pos is not None else x
+        y = self._mha(self.multihead_attn, xp, xp if self.ca_val_has_pos_emb else x, cu, seg_cross,
+                      max_len, residual=x)
+        x, _ = self._ln(self.norm2, y, None, True)
+        h = ops.linear(x, self.linear1.weight.detach(), self.linear1.bias.detach(), act=ops.ACT_RELU)
+        y = ops.linear(h, self.linear2.weight.detach(), self.linear2.bias.detach(), residual=x)
+        x, _ = self._ln(self.norm3, y, None, True)
+        return x
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+def make_segments(src_lens, tgt_lens, device):
+    """cu_seqlens + self / cross kv segment maps for clouds stacked
+    [src_0..src_{B-1}, tgt_0..tgt_{B-1}]."""
+    B = len(src_lens)
+    lens = list(src_lens) + list(tgt_lens)
+    cu = ops.lengths_to_cu(lens, device)
+    seg_self = torch.arange(2 * B, dtype=torch.int32, device=device)
+    seg_cross = torch.cat([torch.arange(B, 2 * B, dtype=torch.int32, device=device),
+                           torch.arange(0, B, dtype=torch.int32, device=device)])
+    return cu, seg_self, seg_cross, max(lens)
+
+
+class TransformerCrossEncoder(nn.Module):
+    """transformers.py:18-82."""
+
+    def __init__(self, cross_encoder_layer, num_layers, norm=None, return_intermediate=False):
+        super().__init__()
+        if return_intermediate:
+            raise NotImplementedError("return_intermediate=False in RegTR (qk_regtr_full.py:72-74)")
+        self.layers = _get_clones(cross_encoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+        self.return_intermediate = return_intermediate
+
+    def forward_packed(self, x, cu, seg_self, seg_cross, max_len, pos=None):
+        for layer in self.layers:
+            x = layer.forward_packed(x, cu, seg_self, seg_cross, max_len, pos=pos)
+        if self.norm is not None:
+            x, _ = ops.layernorm(x, self.norm.weight.detach(), self.norm.bias.detach(), self.norm.eps)
+        return x
+
+    def forward(self, src, tgt, src_mask: Optional[Tensor] = None, tgt_mask: Optional[Tensor] = None,
+                src_key_padding_mask: Optional[Tensor] = None,
+                tgt_key_padding_mask: Optional[Tensor] = None,
+                src_pos: Optional[Tensor] = None, tgt_pos: Optional[Tensor] = None):
+        """Reference signature: padded (L,B,D) in, (1,L,B,D) x 2 out."""
+        assert src_mask is None and tgt_mask is None, 'Masking not implemented'
+        Ls, Lt = src.shape[0], tgt.shape[0]
+        sp, slens = _pack(src, src_key_padding_mask)
+        tp, tlens = _pack(tgt, tgt_key_padding_mask)
+        x = torch.cat([sp, tp], dim=0)
+        pos = None
+        if src_pos is not None:
+            spp, _ = _pack(src_pos, src_key_padding_mask)
+            tpp, _ = _pack(tgt_pos, tgt_key_padding_mask)
+            pos = torch.cat([spp, tpp], dim=0)
+        cu, seg_self, seg_cross, max_len = make_segments(slens, tlens, x.device)
+        y = self.forward_packed(x, cu, seg_self, seg_cross, max_len, pos=pos)
+        ns = sum(slens)
+        return _unpack(y[:ns], slens, Ls).unsqueeze(0), _unpack(y[ns:], tlens, Lt).unsqueeze(0)

@@ -1,0 +1,206 @@
+"""GPU: every floating-point operator of the C ABI against the reference's
+golden vectors (tests/golden/ops.npz) and the CPU oracle on the same seeded
+inputs.  Tolerances are written next to each check."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import torch_oracle as O
+from oracle.gen_golden import ops_inputs
+from superpoints_registration_amd import ops, synthetic
+from superpoints_registration_amd.se3 import compute_rigid_transform
+from superpoints_registration_amd.transformers import (PositionEmbeddingCoordsSine,
+                                                       TransformerCrossEncoder,
+                                                       TransformerCrossEncoderLayer, make_segments)
+from superpoints_registration_amd.seq_manipulation import pad_sequence, unpad_sequences
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return load_golden("ops.npz")
+
+
+@pytest.fixture(scope="module")
+def inp():
+    return ops_inputs()
+
+
+def _close(got, ref, rel, what=""):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    err = np.abs(got - ref).max()
+    scale = max(np.abs(ref).max(), 1e-30)
+    assert err <= rel * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.3e} > {rel})"
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("tag", ["c1", "c32", "c64", "c128", "c48"])
+def test_kpconv_vs_reference(gold, inp, device, tag, impl):
+    pts = T(inp["kp.pts"]).to(device)
+    nb = T(gold["kp.nb"].astype(np.int32)).to(device)
+    y = ops.kpconv(pts, pts, nb, inp[f"kp.{tag}.x"].to(device), inp[f"kp.{tag}.w"].to(device),
+                   T(gold[f"kp.{tag}.kpts"]).to(device), inp["kp.extent"], rows_sorted=True, impl=impl)
+    _close(y.cpu().numpy(), gold[f"kp.{tag}.y"], 1e-5, f"kpconv {tag} impl {impl}")   # features <= 1e-5 rel
+
+
+def test_kpconv_unsorted_rows_and_int64_indices(gold, inp, device):
+    # shadow entries in the middle of a row (rows_sorted=False) and an int64 strided view
+    pts = T(inp["kp.pts"]).to(device)
+    nb = gold["kp.nb"].astype(np.int64).copy()
+    rng = np.random.default_rng(0)
+    perm = np.argsort(rng.random(nb.shape), axis=1)
+    nb = np.take_along_axis(nb, perm, 1)
+    big = np.full((nb.shape[0], nb.shape[1] + 8), 600, np.int64)
+    big[:, :nb.shape[1]] = nb
+    x, w = inp["kp.c32.x"], inp["kp.c32.w"]
+    kp = T(gold["kp.c32.kpts"])
+    y = ops.kpconv(pts, pts, T(big).to(device)[:, :nb.shape[1]], x.to(device), w.to(device), kp.to(device),
+                   inp["kp.extent"], rows_sorted=False)
+    ref = O.kpconv(T(inp["kp.pts"]), T(inp["kp.pts"]), T(nb), x, w, kp, inp["kp.extent"])
+    _close(y.cpu().numpy(), ref.numpy(), 1e-5, "kpconv unsorted")
+
+
+def test_instnorm_lrelu_maxpool_residual(gold, inp, device):
+    cu = ops.lengths_to_cu(inp["kp.lens"].tolist(), device)
+    x = inp["in.x"].to(device)
+    y = ops.instnorm(x, cu, slope=0.1)
+    _close(y.cpu().numpy(), gold["in.y"], 2e-6, "instnorm+lrelu")
+    add = synthetic.rand((600, 64), 77)
+    y2 = ops.instnorm(x, cu, add=add.to(device), slope=0.1)
+    ref2 = O.lrelu(O.instance_norm(inp["in.x"], inp["kp.lens"]) + add)
+    _close(y2.cpu().numpy(), ref2.numpy(), 2e-6, "instnorm+add+lrelu")
+    mp = ops.maxpool(x, T(gold["mp.idx"].astype(np.int32)).to(device))
+    assert np.array_equal(mp.cpu().numpy(), gold["mp.y"])            # selection: bit exact
+
+
+def test_posemb(gold, inp, device):
+    pe = PositionEmbeddingCoordsSine(3, 256, scale=1.0)(inp["pe.xyz"].to(device))
+    assert np.abs(pe.cpu().numpy() - gold["pe.y"]).max() < 2e-6       # sin/cos of O(10) arguments
+
+
+@pytest.mark.parametrize("m,k,n", [(600, 64, 32), (1000, 128, 512), (333, 512, 128), (77, 256, 768),
+                                   (2500, 1024, 256), (130, 256, 1), (64, 32, 96)])
+def test_linear_exact_f32(device, m, k, n):
+    x, w = synthetic.rand((m, k), 1), synthetic.rand((n, k), 2, -0.2, 0.2)
+    b, r = synthetic.rand((n,), 3), synthetic.rand((m, n), 4)
+    ref = (x.double() @ w.double().t() + b.double() + r.double())
+    for act, f in ((ops.ACT_NONE, lambda t: t), (ops.ACT_RELU, torch.relu), (ops.ACT_SIGMOID, torch.sigmoid)):
+        y = ops.linear(x.to(device), w.to(device), b.to(device), r.to(device), act)
+        _close(y.cpu().numpy(), f(ref).numpy(), 2e-6, f"linear {m}x{k}x{n} act {act}")
+    y = ops.linear(x.to(device), w.to(device))
+    _close(y.cpu().numpy(), (x.double() @ w.double().t()).numpy(), 2e-6, "linear plain")
+
+
+def test_layernorm(device):
+    x, g, b, p = synthetic.rand((321, 256), 5, -3, 5), synthetic.rand((256,), 6, 0.5, 1.5), \
+        synthetic.rand((256,), 7), synthetic.rand((321, 256), 8)
+    n, npos = ops.layernorm(x.to(device), g.to(device), b.to(device), 1e-5, pos=p.to(device))
+    ref = torch.nn.functional.layer_norm(x.double(), (256,), g.double(), b.double(), 1e-5)
+    _close(n.cpu().numpy(), ref.numpy(), 2e-6, "layernorm")
+    _close(npos.cpu().numpy(), (ref + p.double()).numpy(), 2e-6, "layernorm+pos")
+
+
+def test_attention_core_vs_fp64(device):
+    lens = [70, 33, 129, 1]
+    tot = sum(lens)
+    qkv = synthetic.rand((tot, 768), 9, -2, 2)
+    cu = ops.lengths_to_cu(lens, device)
+    d_qkv = qkv.to(device)
+    for kv_seg in ([0, 1, 2, 3], [2, 3, 0, 1]):
+        seg = torch.tensor(kv_seg, dtype=torch.int32, device=device)
+        o = ops.attention(d_qkv[:, :256], d_qkv[:, 256:512], d_qkv[:, 512:], cu, seg, max(lens), 8)
+        offs = np.concatenate([[0], np.cumsum(lens)])
+        ref = torch.zeros((tot, 256), dtype=torch.float64)
+        for s in range(4):
+            q = qkv[offs[s]:offs[s + 1], :256].double().view(-1, 8, 32).transpose(0, 1)
+            ks = kv_seg[s]
+            k = qkv[offs[ks]:offs[ks + 1], 256:512].double().view(-1, 8, 32).transpose(0, 1)
+            v = qkv[offs[ks]:offs[ks + 1], 512:].double().view(-1, 8, 32).transpose(0, 1)
+            a = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(32), -1)
+            ref[offs[s]:offs[s + 1]] = (a @ v).transpose(0, 1).reshape(-1, 256)
+        _close(o.cpu().numpy(), ref.numpy(), 3e-6, f"attention kv_seg={kv_seg}")
+
+
+def _layer(device, seed=21):
+    layer = TransformerCrossEncoderLayer(256, 8, 1024, 0.0, 'relu', True, True, True, 'dot_prod')
+    synthetic.fill_parameters(layer, seed=seed)
+    return layer.to(device)
+
+
+def test_transformer_layer_packed_vs_reference(gold, inp, device):
+    layer = _layer(device)
+    x = torch.cat(inp["tl.src"] + inp["tl.tgt"]).to(device)
+    pe = torch.cat(inp["tl.src_pe"] + inp["tl.tgt_pe"]).to(device)
+    cu, s_self, s_cross, mx = make_segments(inp["tl.s_l"], inp["tl.t_l"], device)
+    y = layer.forward_packed(x, cu, s_self, s_cross, mx, pos=pe).cpu().numpy()
+    ns = sum(inp["tl.s_l"])
+    _close(y[:ns], gold["tl.src_out"], 2e-5, "layer src")     # conditioned features <= 2e-5 rel
+    _close(y[ns:], gold["tl.tgt_out"], 2e-5, "layer tgt")
+
+
+def test_transformer_reference_signature_padded(gold, inp, device):
+    enc = TransformerCrossEncoder(_layer(device), 1, None).to(device)
+    synthetic.fill_parameters(enc.layers[0], seed=21)
+    sp, sm, _ = pad_sequence([t.to(device) for t in inp["tl.src"]], require_padding_mask=True)
+    tp, tm, _ = pad_sequence([t.to(device) for t in inp["tl.tgt"]], require_padding_mask=True)
+    spp, _, _ = pad_sequence([t.to(device) for t in inp["tl.src_pe"]])
+    tpp, _, _ = pad_sequence([t.to(device) for t in inp["tl.tgt_pe"]])
+    so, to = enc(sp, tp, src_key_padding_mask=sm, tgt_key_padding_mask=tm, src_pos=spp, tgt_pos=tpp)
+    assert so.shape == (1, 50, 2, 256) and to.shape == (1, 45, 2, 256)
+    _close(torch.cat(unpad_sequences(so, inp["tl.s_l"]), dim=1)[0].cpu().numpy(), gold["tl.src_out"], 2e-5, "padded src")
+    _close(torch.cat(unpad_sequences(to, inp["tl.t_l"]), dim=1)[0].cpu().numpy(), gold["tl.tgt_out"], 2e-5, "padded tgt")
+
+
+def test_rigid_transform_vs_reference(gold, inp, device):
+    a, b, w = inp["rt.a"].to(device), inp["rt.b"].to(device), inp["rt.w"].to(device)
+    Tw = compute_rigid_transform(a, b, w).cpu().numpy()
+    Tu = compute_rigid_transform(a, b).cpu().numpy()
+    for k in range(3):
+        assert np.linalg.norm(Tw[k] - gold["rt.T"][k]) < 1e-4       # Frobenius (north_star)
+        assert np.linalg.norm(Tu[k] - gold["rt.T_unw"][k]) < 1e-4
+        assert abs(np.linalg.det(Tw[k][:, :3].astype(np.float64)) - 1) < 1e-5
+    with pytest.raises(AssertionError):
+        compute_rigid_transform(a, b, w + 2.0)                        # weights outside [0,1]
+    with pytest.raises(AssertionError):
+        compute_rigid_transform(a, b[:, :10], None)
+
+
+def test_procrustes_recovers_planted_transform(device):
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn((5, 1000, 3), generator=g)
+    poses = []
+    bs = []
+    for k in range(5):
+        q, _ = torch.linalg.qr(torch.randn((3, 3), generator=g))
+        if torch.det(q) < 0:
+            q[:, 0] *= -1
+        t = torch.randn(3, generator=g)
+        poses.append(torch.cat([q, t[:, None]], 1))
+        bs.append(a[k] @ q.t() + t)
+    est = compute_rigid_transform(a.to(device), torch.stack(bs).to(device), torch.rand((5, 1000), generator=g).to(device))
+    assert torch.allclose(est.cpu(), torch.stack(poses), atol=2e-5)
+
+
+def test_sinkhorn_and_match_vs_reference(gold, inp, device):
+    feat = torch.cat([inp["sk.fs"], inp["sk.ft"]]).to(device)
+    xyz = torch.cat([inp["sk.xs"], inp["sk.xt"]]).to(device)
+    cu_host = [0, 60, 107]
+    cu = torch.tensor(cu_host, dtype=torch.int32, device=device)
+    w, that = ops.sinkhorn_correspondences(feat, xyz, cu, cu_host, 1, inp["sk.alpha"], inp["sk.beta"], 3)
+    _close(w.cpu().numpy(), gold["sk.w"], 1e-5, "sinkhorn w")
+    _close(that.cpu().numpy(), gold["sk.that"], 1e-5, "sinkhorn t_hat")
+    pose = ops.weighted_procrustes(xyz[:60], that, w, cu[:2].contiguous())
+    assert np.linalg.norm(pose.cpu().numpy()[0] - gold["sk.T"].reshape(3, 4)) < 1e-4
+    val, ind = ops.match_dualsoftmax(feat, cu, cu_host, 1)          # N=60 > M=47: lives on tgt tokens
+    assert np.array_equal(ind.cpu().numpy()[60:], gold["ds.ind_nm"])
+    _close(val.cpu().numpy()[60:], gold["ds.val_nm"], 1e-5, "dual softmax val")
+    feat2 = torch.cat([inp["sk.ft"], inp["sk.fs"]]).to(device)      # N=47 <= M=60: lives on src tokens
+    cu_host2 = [0, 47, 107]
+    val2, ind2 = ops.match_dualsoftmax(feat2, torch.tensor(cu_host2, dtype=torch.int32, device=device), cu_host2, 1)
+    assert np.array_equal(ind2.cpu().numpy()[:47], gold["ds.ind_mn"])
+    _close(val2.cpu().numpy()[:47], gold["ds.val_mn"], 1e-5, "dual softmax val (N<=M)")

@@ -1,0 +1,152 @@
+"""GPU: grid subsampling and radius neighbours through the C ABI against the
+reference's golden vectors and the CPU oracle (bit-exact bar for index work)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import canon_ties, load_golden
+from oracle import native
+from oracle.gen_golden import pairs_for
+from superpoints_registration_amd import get_config, ops, synthetic
+from superpoints_registration_amd.kpconv import Preprocessor
+
+pytestmark = pytest.mark.gpu
+CASES = ["ragged", "lattice", "tiny", "dense"]
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return load_golden("preprocess.npz")
+
+
+def test_mfma_layout_selftest(device):
+    ops.selftest()
+
+
+def _cu(lens, device):
+    return ops.lengths_to_cu([int(v) for v in lens], device)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_grid_subsample_reference_order_bit_exact(gold, device, case):
+    pts, lens, dl = gold[f"{case}.pts"], gold[f"{case}.lens"], float(gold[f"{case}.dl"])
+    sub, sub_lens = ops.grid_subsample(torch.from_numpy(pts).to(device), _cu(lens, device), dl,
+                                       order=ops.ORDER_REFERENCE)
+    assert np.array_equal(sub_lens.cpu().numpy(), gold[f"{case}.sub_lens"])
+    assert np.array_equal(sub.cpu().numpy().view(np.uint32), gold[f"{case}.sub"].view(np.uint32))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_grid_subsample_canonical_order(gold, device, case):
+    pts, lens, dl = gold[f"{case}.pts"], gold[f"{case}.lens"], float(gold[f"{case}.dl"])
+    sub, sub_lens = ops.grid_subsample(torch.from_numpy(pts).to(device), _cu(lens, device), dl,
+                                       order=ops.ORDER_CANONICAL)
+    ref, ref_lens = native.grid_subsample(pts, lens, dl, order="canonical")
+    assert np.array_equal(sub_lens.cpu().numpy(), ref_lens)
+    assert np.array_equal(sub.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("which", ["nb", "pool", "up"])
+def test_radius_neighbors_vs_reference_golden(gold, device, case, which):
+    pts, lens = gold[f"{case}.pts"], gold[f"{case}.lens"]
+    sub, sub_lens, r = gold[f"{case}.sub"], gold[f"{case}.sub_lens"], float(gold[f"{case}.radius"])
+    q, s, ql, sl, rad = {"nb": (pts, pts, lens, lens, r), "pool": (sub, pts, sub_lens, lens, r),
+                         "up": (pts, sub, lens, sub_lens, 2 * r)}[which]
+    ref = gold[f"{case}.{which}"].astype(np.int64)
+    limit = 128
+    got, mc = ops.radius_neighbors(torch.from_numpy(q).to(device), torch.from_numpy(s).to(device),
+                                   _cu(ql, device), _cu(sl, device), rad, limit)
+    got = got.cpu().numpy().astype(np.int64)
+    assert mc == ref.shape[1]                       # untruncated row width of the reference
+    w = min(mc, limit)
+    assert got.shape == (q.shape[0], w)
+    # the oracle is literally identical (same (d2, index) tie rule, same truncation)
+    orc, _ = native.radius_neighbors(q, s, ql, sl, rad, limit=limit)
+    assert np.array_equal(got, orc)
+    if w == ref.shape[1]:
+        s_ext = np.concatenate([s, np.full((1, 3), 1e6, np.float32)])
+        assert np.array_equal(canon_ties(ref, q, s_ext)[0], canon_ties(got, q, s_ext)[0])
+    if case in ("ragged", "tiny") and which == "nb":
+        assert np.array_equal(got, ref[:, :w])      # tie-free: bit-exact vs the reference itself
+
+
+def test_limit_below_max_count_keeps_k_nearest(gold, device):
+    pts, lens, r = gold["dense.pts"], gold["dense.lens"], float(gold["dense.radius"])
+    got, mc = ops.radius_neighbors(torch.from_numpy(pts).to(device), torch.from_numpy(pts).to(device),
+                                   _cu(lens, device), _cu(lens, device), r, 40)
+    orc, mc2 = native.radius_neighbors(pts, pts, lens, lens, r, limit=40)
+    assert mc == mc2 and np.array_equal(got.cpu().numpy(), orc)
+
+
+def test_errors_follow_the_reference(device):
+    # no neighbour anywhere -> RuntimeError("Error") (cpp_neighbors/wrapper.cpp:201-205)
+    q = torch.zeros((2, 3), device=device)
+    s = torch.full((2, 3), 100.0, device=device)
+    cu = _cu([2], device)
+    with pytest.raises(RuntimeError):
+        ops.radius_neighbors(q, s, cu, cu, 0.1, 8)
+    with pytest.raises(RuntimeError):
+        ops.grid_subsample(torch.zeros((0, 3), device=device), _cu([0], device), 0.1)
+
+
+def test_full_size_pair_16384(device):
+    """BASELINE config 2 sizes: 2 x 16 384 points, three pyramid levels, checked
+    against the CPU oracle (bit-exact) and by size-independent properties."""
+    src, tgt, _ = synthetic.make_pair(16384, seed=1)
+    pts = np.concatenate([src, tgt])
+    lens = [16384, 16384]
+    cu = _cu(lens, device)
+    d_pts = torch.from_numpy(pts).to(device)
+    sub, sub_lens = ops.grid_subsample(d_pts, cu, 0.05)
+    ref, ref_lens = native.grid_subsample(pts, lens, 0.05)
+    assert np.array_equal(sub_lens.cpu().numpy(), ref_lens)
+    assert np.array_equal(sub.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    nb, mc = ops.radius_neighbors(d_pts, d_pts, cu, cu, 0.0625, 40)
+    nbh = nb.cpu().numpy()
+    orc, mc2 = native.radius_neighbors(pts, pts, lens, lens, 0.0625, limit=40)
+    assert mc == mc2 and np.array_equal(nbh, orc)
+    # properties: self is the first neighbour; rows sorted by distance; same-cloud only
+    assert np.array_equal(nbh[:, 0], np.arange(len(pts)))
+    valid = nbh < len(pts)
+    cloud = (np.arange(len(pts)) >= 16384)
+    assert np.all(((nbh >= 16384) == cloud[:, None]) | ~valid)
+    ext = np.concatenate([pts, np.full((1, 3), 1e6, np.float32)])
+    d2 = ((pts[:, None, :] - ext[nbh]) ** 2).sum(-1)
+    d2 = np.where(valid, d2, np.inf)
+    assert np.all(np.diff(d2, axis=1) >= -1e-9)
+    assert np.all(d2[valid] < 0.0625 ** 2 * (1 + 1e-5))
+
+
+@pytest.mark.parametrize("tag", ["3dmatch", "kitti", "modelnet"])
+def test_preprocessor_pyramid_matches_reference(device, tag):
+    g = load_golden(f"regtr_{tag}_b2.npz")
+    B = int(g["B"])
+    pairs, sizes = pairs_for(tag, B)
+    src = [torch.from_numpy(p[0][:n]).to(device) for p, (n, m) in zip(pairs, sizes)]
+    tgt = [torch.from_numpy(p[1][:m]).to(device) for p, (n, m) in zip(pairs, sizes)]
+    meta = Preprocessor(get_config(tag))(src + tgt)
+    L = int(g["levels"])
+    assert len(meta["points"]) == L
+    for l in range(L):
+        p = meta["points"][l].cpu().numpy()
+        assert np.array_equal(p.view(np.uint32), g[f"points{l}"].view(np.uint32))       # order + bits
+        assert np.array_equal(meta["stack_lengths"][l].cpu().numpy(), g[f"lens{l}"])
+        ext = np.concatenate([p, np.full((1, 3), 1e6, np.float32)])
+        for key in ("neighbors", "pools", "upsamples"):
+            if f"{key}{l}" not in g:
+                assert meta[key][l].shape == (0, 1)
+                continue
+            ref = g[f"{key}{l}"].astype(np.int64)
+            got = meta[key][l].cpu().numpy()
+            assert got.dtype == np.int64 and got.shape == ref.shape
+            q = {"neighbors": p, "pools": g[f"points{l + 1}"] if key == "pools" else p,
+                 "upsamples": p}[key]
+            s = {"neighbors": p, "pools": p, "upsamples": g[f"points{l + 1}"] if key == "upsamples" else p}[key]
+            s_ext = np.concatenate([s, np.full((1, 3), 1e6, np.float32)])
+            if ref.shape[1] < 40 or key != "neighbors":
+                # untruncated rows: identical up to equal-distance ties
+                ok = np.array_equal(canon_ties(ref, q, s_ext)[0], canon_ties(got, q, s_ext)[0])
+                lim = get_config(tag).neighborhood_limits[l]
+                assert ok or ref.shape[1] == lim
+            assert (got == ref).all(1).mean() > 0.97

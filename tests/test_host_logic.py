@@ -1,0 +1,90 @@
+"""CPU: host-side logic of the package (no kernels)."""
+import numpy as np
+import torch
+
+from superpoints_registration_amd import get_config, synthetic
+from superpoints_registration_amd.kpconv import plan_pyramid
+from superpoints_registration_amd.regtr import RegTR
+from superpoints_registration_amd.seq_manipulation import pad_sequence, split_src_tgt, unpad_sequences
+from superpoints_registration_amd import se3
+
+
+def test_pyramid_plan_matches_reference_block_dims():
+    # SURVEY.md section 8b / Appendix B (printed from the reference's RegTR(cfg))
+    blocks, levels, final = plan_pyramid(get_config("3dmatch"))
+    kp = [(b.in_dim if "simple" in b.name else b.out_dim // 4, b.out_dim // 2 if "simple" in b.name else b.out_dim // 4)
+          for b in blocks]
+    assert kp == [(1, 64), (32, 32), (32, 32), (64, 64), (64, 64), (64, 64), (128, 128), (128, 128)]
+    assert [round(l.radius, 6) for l in levels] == [0.0625, 0.125, 0.25]
+    assert [l.down for l in levels] == [True, True, False] and final == 512
+    blocks, levels, final = plan_pyramid(get_config("kitti"))
+    assert len(blocks) == 11 and len(levels) == 4 and final == 1024
+    assert [l.limit for l in levels] == [39, 57, 68, 74]
+    blocks, levels, final = plan_pyramid(get_config("modelnet"))
+    assert len(levels) == 2 and final == 1024 and blocks[1].out_dim == 512
+
+
+def test_state_dict_names_and_parameter_counts():
+    # B4 of SURVEY.md: 151 tensors / 7 797 547 parameters for the 3DMatch config
+    m = RegTR(get_config("3dmatch"))
+    sd = m.state_dict()
+    assert len(sd) == 151
+    assert sum(v.numel() for v in sd.values()) == 7797547
+    for name, shape in {
+        "alpha": (), "beta": (),
+        "kpf_encoder.encoder_blocks.0.KPConv.weights": (15, 1, 64),
+        "kpf_encoder.encoder_blocks.0.KPConv.kernel_points": (15, 3),
+        "kpf_encoder.encoder_blocks.1.unary1.mlp.weight": (32, 64),
+        "kpf_encoder.encoder_blocks.1.unary_shortcut.mlp.weight": (128, 64),
+        "kpf_encoder.encoder_blocks.7.unary2.mlp.weight": (512, 128),
+        "feat_proj.weight": (256, 512),
+        "transformer_encoder.layers.5.multihead_attn.in_proj_weight": (768, 256),
+        "transformer_encoder.layers.0.self_attn.out_proj.bias": (256,),
+        "transformer_encoder.layers.3.linear1.weight": (1024, 256),
+        "transformer_encoder.norm.weight": (256,),
+        "overlap_predictor.weight": (1, 256),
+        "feature_criterion.W": (256, 256), "feature_criterion_un.W": (256, 256),
+    }.items():
+        assert tuple(sd[name].shape) == shape, name
+    assert sum(v.numel() for v in RegTR(get_config("kitti")).state_dict().values()) == 11713458
+    assert sum(v.numel() for v in RegTR(get_config("modelnet")).state_dict().values()) == 11355665
+
+
+def test_fill_parameters_is_deterministic_and_name_keyed():
+    a, b = RegTR(get_config("3dmatch")), RegTR(get_config("3dmatch"))
+    synthetic.fill_parameters(a, 3)
+    synthetic.fill_parameters(b, 3)
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    synthetic.fill_parameters(b, 4)
+    assert not torch.equal(a.state_dict()["feat_proj.weight"], b.state_dict()["feat_proj.weight"])
+
+
+def test_padding_helpers_round_trip():
+    seqs = [torch.randn(5, 4), torch.randn(2, 4), torch.randn(7, 4)]
+    padded, mask, lens = pad_sequence(seqs, require_padding_mask=True, require_lens=True)
+    assert padded.shape == (7, 3, 4) and lens == [5, 2, 7]
+    assert mask.tolist()[1] == [False, False, True, True, True, True, True]
+    back = unpad_sequences(padded.unsqueeze(0), lens)
+    for s, r in zip(seqs, back):
+        assert torch.equal(s, r[0])
+    src, tgt = split_src_tgt(torch.arange(10).unsqueeze(1), [1, 2, 3, 4])
+    assert [len(t) for t in src] == [1, 2] and [len(t) for t in tgt] == [3, 4]
+
+
+def test_se3_algebra():
+    R = torch.tensor(synthetic.rotation_z(0.3), dtype=torch.float32)
+    T = se3.se3_init(R, torch.tensor([[0.1], [0.2], [0.3]]))
+    I = se3.se3_cat(T, se3.se3_inv(T))
+    assert torch.allclose(I, se3.se3_init(torch.eye(3), torch.zeros(3, 1)), atol=1e-6)
+    x = torch.randn(5, 3)
+    assert torch.allclose(se3.se3_transform(T, x), x @ R.t() + torch.tensor([0.1, 0.2, 0.3]), atol=1e-6)
+    err = se3.se3_compare(T, se3.se3_init(torch.eye(3), torch.zeros(3, 1)))
+    assert abs(float(err["rot_deg"]) - np.degrees(0.3)) < 1e-3
+
+
+def test_synthetic_pairs_are_reproducible():
+    a = synthetic.make_pair(256, seed=9)
+    b = synthetic.make_pair(256, seed=9)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert a[0].dtype == np.float32 and a[0].shape == (256, 3)
