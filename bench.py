@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Headline benchmark: point-cloud pairs/s (16 384 pts/cloud) through the full
+hot path -- KPConv pyramid preprocessing, KPConv encoder, superpoint
+self/cross attention, matching and the weighted-SVD pose -- on N MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one forward of `--pairs-per-step` synthetic pairs per rank, inputs
+already resident in HBM.  Pairs are independent, so ranks shard the pair
+stream with no data-path collective (weak scaling); the only collectives are
+the timing barrier and the max-over-ranks of the elapsed time.
+
+Rank 0 prints ONE JSON line (contract in the task statement) including
+  roofline      HBM roofline of the dominant kernel (fused KPConv gather):
+                algorithmic bytes / HIP-event duration measured inside the
+                timed region on the launch stream
+  cpu_baseline  the CPU oracle (port of the reference path) timed on this
+                host's cores on a bounded sample (one pair), N == 1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs-per-step", type=int, default=4)
+    ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--config", default="3dmatch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--canonical-order", action="store_true",
+                    help="ascending-voxel-key point order instead of the reference's hash-map order")
+    ap.add_argument("--skip-upsamples", action="store_true",
+                    help="skip the up-sampling neighbour search the encoder never reads")
+    return ap.parse_args()
+
+
+def kpconv_alg_bytes(meta, model):
+    """ALGORITHMIC bytes of every MFMA-path KPConv launch of one forward, in
+    launch order:
+       Kv*(4 + 12 + 4*Cin) + Nq*(12 + 4*Cout) + 60*Cin*Cout
+    Kv = valid (non-shadow) neighbour entries."""
+    out = []
+    for blk in model.kpf_encoder.encoder_blocks:
+        conv = blk.KPConv
+        li = blk.layer_ind
+        strided = 'strided' in blk.block_name
+        idx = meta['_i32'][('pools' if strided else 'neighbors', li)]
+        ns = meta['points'][li].shape[0]
+        nq = idx.shape[0]
+        kv = int((idx < ns).sum().item())
+        cin, cout = conv.in_channels, conv.out_channels
+        b = kv * (4 + 12 + 4 * cin) + nq * (12 + 4 * cout) + 60 * cin * cout
+        out.append(dict(code=cin * 100000 + cout, nq=nq, kv=kv, cin=cin, cout=cout, bytes=b))
+    return out
+
+
+def cpu_baseline(cfg, model_sd, n_points):
+    """The reference path restated on the CPU (oracle/), timed on ONE pair.
+    Native preprocessing: the reference's own C++ (oracle/_ref, kd-tree) when
+    its built library travelled with the repo, else our brute-force C port."""
+    from oracle import native, torch_oracle
+    from superpoints_registration_amd import synthetic
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    src, tgt, _ = synthetic.make_pair(n_points, seed=0)
+    use_ref = native.ref_available()
+    if use_ref:
+        orig_sub, orig_nb = native.grid_subsample, native.radius_neighbors
+
+        def nb(q, s, ql, sl, r, limit=0):
+            full = native.ref_radius_neighbors(q, s, ql, sl, r)
+            mc = full.shape[1]
+            return (full[:, :limit] if limit and limit < mc else full), mc
+
+        native.grid_subsample = lambda p, l, dl, max_p=0, order="reference", return_keys=False: \
+            native.ref_grid_subsample(p, l, dl, max_p)
+        native.radius_neighbors = nb
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        torch_oracle.regtr_forward(cfg, model_sd, [src], [tgt])
+    dt = time.perf_counter() - t0
+    if use_ref:
+        native.grid_subsample, native.radius_neighbors = orig_sub, orig_nb
+    return dict(value=1.0 / dt, unit="pairs/s", cores=threads, kind="port",
+                sample=f"1 pair x {n_points} pts/cloud, full forward in {dt:.1f} s; torch part on {threads} "
+                       f"threads, native preprocessing single-threaded "
+                       f"({'reference C++ via oracle/_ref' if use_ref else 'brute-force C port'})")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+
+    from superpoints_registration_amd import _lib, get_config, ops, synthetic
+    from superpoints_registration_amd.regtr import RegTR
+
+    cfg = get_config(args.config)
+    model = RegTR(cfg, compute_upsamples=not args.skip_upsamples,
+                  order=ops.ORDER_CANONICAL if args.canonical_order else ops.ORDER_REFERENCE)
+    synthetic.fill_parameters(model, seed=0)
+    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).eval()
+
+    B = args.pairs_per_step
+    pairs = [synthetic.make_pair(args.points, seed=1000 * rank + i) for i in range(B)]
+    batch = {"src_xyz": [torch.from_numpy(p[0]).to(dev) for p in pairs],
+             "tgt_xyz": [torch.from_numpy(p[1]).to(dev) for p in pairs]}
+
+    def step():
+        return model(batch)   # RegTR.forward leaves the pyramid in batch['kpconv_meta']
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    L = _lib.lib()
+
+    # ---- timed region --------------------------------------------------------
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    L.spr_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (rank 0) -----------------------------
+    roofline = None
+    if rank == 0:
+        cap = 64 * max(args.steps, 1)
+        codes = (ctypes.c_int * cap)()
+        nqs = (ctypes.c_int * cap)()
+        ms = (ctypes.c_float * cap)()
+        n = L.spr_prof_read(cap, codes, nqs, ms)
+        per_fwd = [r for r in kpconv_alg_bytes(batch['kpconv_meta'], model)
+                   if r['cin'] % 16 == 0]          # cin == 1 runs the small dedicated kernel
+        # aggregate per kernel instantiation (cin, cout) == one rocprof kernel name
+        agg = {}
+        for i in range(n):
+            a = agg.setdefault(codes[i], dict(ms=0.0, count=0))
+            a['ms'] += ms[i]
+            a['count'] += 1
+        fwd_bytes, fwd_launches = {}, {}
+        for r in per_fwd:
+            fwd_bytes[r['code']] = fwd_bytes.get(r['code'], 0) + r['bytes']
+            fwd_launches[r['code']] = fwd_launches.get(r['code'], 0) + 1
+        best = None
+        for code, a in agg.items():
+            if code not in fwd_bytes or a['count'] % fwd_launches[code] != 0:
+                continue
+            n_fwd = a['count'] // fwd_launches[code]
+            cand = dict(code=code, total_ms=a['ms'], count=a['count'],
+                        total_bytes=fwd_bytes[code] * n_fwd)
+            if best is None or cand['total_ms'] > best['total_ms']:
+                best = cand
+        if best is not None:
+            avg_ms = best['total_ms'] / best['count']
+            bytes_per_launch = best['total_bytes'] / best['count']
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(REPO, "profiles", "kpconv_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            cin, cout = best['code'] // 100000, best['code'] % 100000
+            roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                            kernel=f"k_kpconv_mfma (fused KPConv gather) cin={cin} cout={cout}",
+                            avg_launch_ms=round(avg_ms, 5), launches=best['count'],
+                            alg_bytes_per_launch=int(bytes_per_launch),
+                            all_kpconv_variants={f"{c // 100000}->{c % 100000}": dict(
+                                launches=a['count'], avg_ms=round(a['ms'] / a['count'], 5),
+                                gbs=round(fwd_bytes[c] / fwd_launches[c] / (a['ms'] / a['count'] * 1e-3) / 1e9, 1))
+                                for c, a in agg.items() if c in fwd_bytes})
+    L.spr_prof_enable(0)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    total_pairs = B * args.steps * world
+    result = {
+        "metric": "point-cloud pairs/sec (16 384 pts/cloud)",
+        "value": round(total_pairs / elapsed, 3),
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"synthetic {args.points}-pt pairs, full KPConv backbone + superpoint attn "
+                               f"+ {'Sinkhorn-' if cfg.use_sinkhorn else ''}SVD pose ({args.config} config, "
+                               f"BASELINE configs[1])",
+                   "pairs_per_step_per_gpu": B, "points_per_cloud": args.points,
+                   "point_order": "canonical" if args.canonical_order else "reference",
+                   "upsample_indices": not args.skip_upsamples,
+                   "parallelism": f"pairs sharded over {world} rank(s), no data-path collective"},
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, args.points)
+    else:
+        result["cpu_baseline"] = None
+    print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

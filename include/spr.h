@@ -99,13 +99,15 @@ int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, int ns,
  * LeakyReLU that follows it (kpconv_blocks.py:553-561, :645, :727) and with
  * the residual add of ResnetBottleneckBlock (:741):
  *   out = lrelu(IN(x) + add, slope)      slope = 1 -> no activation
- * x,out [n,c] (may alias); add [n,c] or NULL; cu [nb+1].
+ * x,out [n,c] (may alias); add [n,c] or NULL; cu [nb+1]; max_len_host = an
+ * upper bound of the longest cloud (sizes the statistics grid: fixed 1024-row
+ * slices relative to each cloud, so results are batch-invariant bit for bit).
  * norm = 0 skips the normalisation (out = lrelu(x + add)).
  */
-size_t spr_instnorm_workspace_bytes(int n, int nb, int c);
-int spr_instnorm(const float* x, const int* cu, int n, int nb, int c, float eps,
-                 int norm, const float* add, float slope, float* out, void* ws,
-                 size_t ws_bytes, void* stream);
+size_t spr_instnorm_workspace_bytes(int max_len_host, int nb, int c);
+int spr_instnorm(const float* x, const int* cu, int n, int nb, int max_len_host,
+                 int c, float eps, int norm, const float* add, float slope,
+                 float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a5: strided max pooling ----------------------------------------------
  * Replaces max_pool(x, inds) (kpconv_blocks.py:127-143): max over the pooling

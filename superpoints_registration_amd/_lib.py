@@ -28,7 +28,7 @@ SIGNATURES = {
     "spr_kpconv_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp,
                             _i, _vp, _sz, _vp]),
     "spr_instnorm_workspace_bytes": (_sz, [_i, _i, _i]),
-    "spr_instnorm": (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _f, _vp, _vp, _sz, _vp]),
+    "spr_instnorm": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _f, _vp, _vp, _sz, _vp]),
     "spr_maxpool_gather": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "spr_linear": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "spr_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),

@@ -20,16 +20,23 @@
 namespace spr {
 namespace {
 
+// Row slices are relative to each cloud's own start and have a fixed length,
+// so a cloud's statistics do not depend on what else is in the batch
+// (bitwise batch invariance).
+constexpr int kSliceRows = 1024;
+int in_nsplit(int max_len) {
+  int s = cdiv(max_len > 0 ? max_len : 1, kSliceRows);
+  return s < 1 ? 1 : s;
+}
+
 // block = 256 threads = (256/CW) row lanes x CW channel lanes, CW = min(c,64)
 __global__ __launch_bounds__(256) void k_in_stats(const float* __restrict__ x,
                                                   const int* __restrict__ cu, int c, int nsplit,
                                                   double* __restrict__ part /*[nb][nsplit][2][c]*/) {
   const int cloud = blockIdx.x, split = blockIdx.y;
   const int beg = cu[cloud], end = cu[cloud + 1];
-  const int len = end - beg;
-  const int per = (len + nsplit - 1) / nsplit;
-  const int r0 = beg + split * per;
-  const int r1 = min(r0 + per, end);
+  const int r0 = beg + split * kSliceRows;
+  const int r1 = min(r0 + kSliceRows, end);
   const int cw = c < 64 ? c : 64;
   const int rl = 256 / cw;  // row lanes
   const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
@@ -143,35 +150,29 @@ __global__ void k_gather_rows(const float* __restrict__ x, int n_src, int c,
   out[gid] = (id >= 0 && id < n_src) ? x[(size_t)id * c + ch] : 0.f;
 }
 
-int in_nsplit(int n, int nb) {
-  int s = cdiv(n, (long)nb * 512);
-  if (s < 1) s = 1;
-  if (s > 64) s = 64;
-  return s;
-}
-
 }  // namespace
 }  // namespace spr
 
 using namespace spr;
 
-extern "C" size_t spr_instnorm_workspace_bytes(int n, int nb, int c) {
+extern "C" size_t spr_instnorm_workspace_bytes(int max_len, int nb, int c) {
   const size_t B = (size_t)(nb > 0 ? nb : 1), C = (size_t)(c > 0 ? c : 1);
-  const int ns = in_nsplit(n, nb > 0 ? nb : 1);
+  const int ns = in_nsplit(max_len);
   return align_up(B * ns * 2 * C * sizeof(double), 256) + 2 * align_up(B * C * sizeof(float), 256);
 }
 
-extern "C" int spr_instnorm(const float* x, const int* cu, int n, int nb, int c, float eps,
-                            int norm, const float* add, float slope, float* out, void* ws,
-                            size_t ws_bytes, void* stream_) {
+extern "C" int spr_instnorm(const float* x, const int* cu, int n, int nb, int max_len_host, int c,
+                            float eps, int norm, const float* add, float slope, float* out,
+                            void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(n > 0 && nb >= 1 && c >= 4 && c % 4 == 0, "instnorm: need n>0 and c %% 4 == 0 (c=%d)", c);
   float* mean = nullptr;
   float* rstd = nullptr;
   if (norm) {
-    SPR_REQUIRE(ws_bytes >= spr_instnorm_workspace_bytes(n, nb, c), "instnorm: workspace too small");
+    SPR_REQUIRE(max_len_host >= 1 && max_len_host <= n, "instnorm: bad max_len_host=%d", max_len_host);
+    SPR_REQUIRE(ws_bytes >= spr_instnorm_workspace_bytes(max_len_host, nb, c), "instnorm: workspace too small");
     Workspace w(ws, ws_bytes);
-    const int nsplit = in_nsplit(n, nb);
+    const int nsplit = in_nsplit(max_len_host);
     double* part = w.take<double>((size_t)nb * nsplit * 2 * c);
     mean = w.take<float>((size_t)nb * c);
     rstd = w.take<float>((size_t)nb * c);

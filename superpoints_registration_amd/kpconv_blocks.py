@@ -30,6 +30,13 @@ def _cu_of(batch, layer_ind):
     return cu
 
 
+def _maxlen_of(batch, layer_ind):
+    """Host-side longest cloud of a level (None when the meta dict did not come
+    from our Preprocessor: the op then falls back to a safe upper bound)."""
+    lens = batch.get('_lens_host')
+    return max(lens[layer_ind]) if lens is not None else None
+
+
 def _idx_of(batch, key, layer_ind):
     """int32 view of an index matrix of the meta dict (the public entries are
     int64 like the reference's; the kernels read int32)."""
@@ -133,15 +140,15 @@ class BatchNormBlock(nn.Module):
         if not self.use_bn:
             self.bias = Parameter(torch.zeros(in_dim, dtype=torch.float32), requires_grad=True)
 
-    def forward(self, x, stack_lengths, cu=None, add=None, slope=1.0):
-        """`cu`, `add`, `slope` are extensions used by the fused blocks below:
-        out = lrelu(norm(x) + add, slope)."""
+    def forward(self, x, stack_lengths, cu=None, add=None, slope=1.0, max_len=None):
+        """`cu`, `add`, `slope`, `max_len` are extensions used by the fused
+        blocks below: out = lrelu(norm(x) + add, slope)."""
         if cu is None:
             cu = ops.lengths_to_cu(stack_lengths, x.device)
         if self.use_bn:
-            return ops.instnorm(x, cu, eps=self.eps, norm=True, add=add, slope=slope)
+            return ops.instnorm(x, cu, eps=self.eps, norm=True, add=add, slope=slope, max_len=max_len)
         y = x + self.bias.detach()
-        return ops.instnorm(y, cu, norm=False, add=add, slope=slope)
+        return ops.instnorm(y, cu, norm=False, add=add, slope=slope, max_len=max_len)
 
     def __repr__(self):
         return 'BatchNormBlock(in_feat: {:d}, momentum: {:.3f}, only_bias: {:s})'.format(
@@ -163,14 +170,14 @@ class UnaryBlock(nn.Module):
         if not no_relu:
             self.leaky_relu = nn.LeakyReLU(0.1)
 
-    def forward(self, x, stack_lengths=None, cu=None, add=None, final_slope=None):
+    def forward(self, x, stack_lengths=None, cu=None, add=None, final_slope=None, max_len=None):
         """out = act(norm(x W^T) [+ add]); `add` / `final_slope` let the
         bottleneck block fuse its residual add + LeakyReLU into this pass."""
         y = ops.linear(x, self.mlp.weight.detach())
         slope = 1.0 if self.no_relu else 0.1
         if final_slope is not None:
             slope = final_slope
-        return self.batch_norm(y, stack_lengths, cu=cu, add=add, slope=slope)
+        return self.batch_norm(y, stack_lengths, cu=cu, add=add, slope=slope, max_len=max_len)
 
     def __repr__(self):
         return 'UnaryBlock(in_feat: {:d}, out_feat: {:d}, BN: {:s}, ReLU: {:s})'.format(
@@ -203,14 +210,14 @@ class SimpleBlock(nn.Module):
         if 'strided' in self.block_name:
             q_pts, s_pts = batch['points'][li + 1], batch['points'][li]
             neighb_inds = _idx_of(batch, 'pools', li)
-            stack_lengths, cu = batch['stack_lengths'][li + 1], _cu_of(batch, li + 1)
+            stack_lengths, cu, ml = batch['stack_lengths'][li + 1], _cu_of(batch, li + 1), _maxlen_of(batch, li + 1)
         else:
             q_pts = s_pts = batch['points'][li]
             neighb_inds = _idx_of(batch, 'neighbors', li)
-            stack_lengths, cu = batch['stack_lengths'][li], _cu_of(batch, li)
+            stack_lengths, cu, ml = batch['stack_lengths'][li], _cu_of(batch, li), _maxlen_of(batch, li)
         self.KPConv.rows_sorted = bool(batch.get('_rows_sorted', False))
         x = self.KPConv(q_pts, s_pts, neighb_inds, x)
-        return self.batch_norm(x, stack_lengths, cu=cu, slope=0.1)
+        return self.batch_norm(x, stack_lengths, cu=cu, slope=0.1, max_len=ml)
 
 
 class ResnetBottleneckBlock(nn.Module):
@@ -246,27 +253,29 @@ class ResnetBottleneckBlock(nn.Module):
 
     def forward(self, features, batch):
         li = self.layer_ind
-        stack_lengths_pre, cu_pre = batch['stack_lengths'][li], _cu_of(batch, li)
+        stack_lengths_pre, cu_pre, ml_pre = batch['stack_lengths'][li], _cu_of(batch, li), _maxlen_of(batch, li)
         if 'strided' in self.block_name:
             q_pts, s_pts = batch['points'][li + 1], batch['points'][li]
             neighb_inds = _idx_of(batch, 'pools', li)
-            stack_lengths_post, cu_post = batch['stack_lengths'][li + 1], _cu_of(batch, li + 1)
+            stack_lengths_post, cu_post, ml_post = (batch['stack_lengths'][li + 1], _cu_of(batch, li + 1),
+                                                    _maxlen_of(batch, li + 1))
         else:
             q_pts = s_pts = batch['points'][li]
             neighb_inds = _idx_of(batch, 'neighbors', li)
-            stack_lengths_post, cu_post = batch['stack_lengths'][li], _cu_of(batch, li)
+            stack_lengths_post, cu_post, ml_post = batch['stack_lengths'][li], _cu_of(batch, li), ml_pre
 
-        x = self.unary1(features, stack_lengths_pre, cu=cu_pre) \
+        x = self.unary1(features, stack_lengths_pre, cu=cu_pre, max_len=ml_pre) \
             if isinstance(self.unary1, UnaryBlock) else features
         self.KPConv.rows_sorted = bool(batch.get('_rows_sorted', False))
         x = self.KPConv(q_pts, s_pts, neighb_inds, x)
-        x = self.batch_norm_conv(x, stack_lengths_post, cu=cu_post, slope=0.1)
+        x = self.batch_norm_conv(x, stack_lengths_post, cu=cu_post, slope=0.1, max_len=ml_post)
 
         if 'strided' in self.block_name:
             shortcut = max_pool(features, neighb_inds)
         else:
             shortcut = features
         if isinstance(self.unary_shortcut, UnaryBlock):
-            shortcut = self.unary_shortcut(shortcut, stack_lengths_post, cu=cu_post)
+            shortcut = self.unary_shortcut(shortcut, stack_lengths_post, cu=cu_post, max_len=ml_post)
         # unary2 (no relu) + shortcut, then LeakyReLU: fused into unary2's norm pass
-        return self.unary2(x, stack_lengths_post, cu=cu_post, add=shortcut, final_slope=0.1)
+        return self.unary2(x, stack_lengths_post, cu=cu_post, add=shortcut, final_slope=0.1,
+                           max_len=ml_post)

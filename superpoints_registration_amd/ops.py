@@ -146,8 +146,10 @@ def kpconv(q_pts, s_pts, nbr, x, weights, kernel_points, kp_extent: float, rows_
 
 
 def instnorm(x, cu, eps: float = 1e-5, norm: bool = True, add=None, slope: float = 1.0,
-             out=None) -> torch.Tensor:
-    """a5.  out = lrelu(InstanceNorm_per_cloud(x) + add, slope)."""
+             out=None, max_len: Optional[int] = None) -> torch.Tensor:
+    """a5.  out = lrelu(InstanceNorm_per_cloud(x) + add, slope).  max_len: host
+    upper bound of the longest cloud (defaults to n: correct, just a larger
+    statistics grid)."""
     x = _dev(x, "x", torch.float32)
     cu = _dev(cu, "cu", torch.int32)
     n, c = x.shape
@@ -158,8 +160,9 @@ def instnorm(x, cu, eps: float = 1e-5, norm: bool = True, add=None, slope: float
     if out is None:
         out = torch.empty_like(x)
     L = _lib.lib()
-    ws = _workspace(L.spr_instnorm_workspace_bytes(n, nb, c), x.device)
-    _lib.check(L.spr_instnorm(_ptr(x), _ptr(cu), n, nb, c, float(eps), int(bool(norm)), _ptr(add),
+    max_len = n if max_len is None else max(1, min(int(max_len), n))
+    ws = _workspace(L.spr_instnorm_workspace_bytes(max_len, nb, c), x.device)
+    _lib.check(L.spr_instnorm(_ptr(x), _ptr(cu), n, nb, max_len, c, float(eps), int(bool(norm)), _ptr(add),
                               float(slope), _ptr(out), _ptr(ws), ws.numel(), _stream(x)),
                "spr_instnorm")
     return out

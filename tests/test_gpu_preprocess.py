@@ -113,7 +113,7 @@ def test_full_size_pair_16384(device):
     assert np.all(((nbh >= 16384) == cloud[:, None]) | ~valid)
     ext = np.concatenate([pts, np.full((1, 3), 1e6, np.float32)])
     d2 = ((pts[:, None, :] - ext[nbh]) ** 2).sum(-1)
-    d2 = np.where(valid, d2, np.inf)
+    d2 = np.where(valid, d2, 1e30)
     assert np.all(np.diff(d2, axis=1) >= -1e-9)
     assert np.all(d2[valid] < 0.0625 ** 2 * (1 + 1e-5))
 
@@ -149,4 +149,6 @@ def test_preprocessor_pyramid_matches_reference(device, tag):
                 ok = np.array_equal(canon_ties(ref, q, s_ext)[0], canon_ties(got, q, s_ext)[0])
                 lim = get_config(tag).neighborhood_limits[l]
                 assert ok or ref.shape[1] == lim
-            assert (got == ref).all(1).mean() > 0.97
+            # raw identity: conv rows tie rarely; pool / upsample queries are barycentres and
+            # tie structurally (a 2-point voxel's barycentre is equidistant from both points)
+            assert (got == ref).all(1).mean() > (0.97 if key == 'neighbors' else 0.85)
