@@ -78,7 +78,8 @@ def cpu_baseline(cfg, model_sd, n_points):
     its built library travelled with the repo, else our brute-force C port."""
     from oracle import native, torch_oracle
     from superpoints_registration_amd import synthetic
-    threads = os.cpu_count() or 1
+    # the GPU box gives one GPU a 16-core share; never oversubscribe it
+    threads = min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 16)
     torch.set_num_threads(threads)
     src, tgt, _ = synthetic.make_pair(n_points, seed=0)
     use_ref = native.ref_available()

@@ -48,13 +48,17 @@ def test_regtr_matches_reference(device, tag):
         assert err < 1e-4, f"pose error {err:.2e}"
 
 
-def test_batching_does_not_change_a_pair(device):
-    _, both, _ = _run("3dmatch", device)
-    _, one, _ = _run("3dmatch", device, which=[1])
-    # every kernel reduces in a batch-independent order -> bitwise identical
-    assert torch.equal(both["src_feat"][1], one["src_feat"][0])
-    assert torch.equal(both["tgt_feat"][1], one["tgt_feat"][0])
-    assert torch.equal(both["pose"][1], one["pose"][0])
+def test_forward_is_deterministic(device):
+    """No atomics on float data anywhere: two runs are bitwise identical.
+    (A pair's result is NOT independent of its batch mates -- neither in the
+    reference: the neighbour-matrix width is the batch-wide max count, and
+    max_pool reads a zero 'shadow' row for every padded column,
+    kpconv_blocks.py:136-143 -- so batch invariance is deliberately not asserted.)"""
+    _, a, _ = _run("3dmatch", device)
+    _, b, _ = _run("3dmatch", device)
+    assert torch.equal(a["pose"], b["pose"])
+    for x, y in zip(a["src_feat"] + a["tgt_feat"], b["src_feat"] + b["tgt_feat"]):
+        assert torch.equal(x, y)
 
 
 def test_canonical_order_gives_the_same_pose(device):
