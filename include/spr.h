@@ -67,12 +67,16 @@ int spr_grid_subsample(const float* xyz, const int* cu, int n, int nb, float dl,
  *   out_idx [nq, limit] i32; max_count [1] i32 device = untruncated max row
  *   count (the reference's row width); the caller may slice to
  *   min(max_count, limit).
+ * algo 0: dense per-cloud cell table (fast; *max_count = -2 if the clouds'
+ *   bounding boxes need more cells than the table holds -> retry with algo 1);
+ * algo 1: sorted cell keys + binary search (no geometry limit besides 8191
+ *   cells per axis, *max_count = -1).  Results are identical.
  */
 size_t spr_radius_neighbors_workspace_bytes(int nq, int ns, int nb);
 int spr_radius_neighbors(const float* q_xyz, const int* q_cu, int nq,
                          const float* s_xyz, const int* s_cu, int ns, int nb,
-                         float radius, int limit, int* out_idx, int* max_count,
-                         void* ws, size_t ws_bytes, void* stream);
+                         float radius, int limit, int algo, int* out_idx,
+                         int* max_count, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a4: KPConv forward ---------------------------------------------------
  * Replaces KPConv.forward(q_pts, s_pts, neighb_inds, x)
@@ -100,7 +104,7 @@ int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, int ns,
  * the residual add of ResnetBottleneckBlock (:741):
  *   out = lrelu(IN(x) + add, slope)      slope = 1 -> no activation
  * x,out [n,c] (may alias); add [n,c] or NULL; cu [nb+1]; max_len_host = an
- * upper bound of the longest cloud (sizes the statistics grid: fixed 1024-row
+ * upper bound of the longest cloud (sizes the statistics grid: fixed 512-row
  * slices relative to each cloud, so results are batch-invariant bit for bit).
  * norm = 0 skips the normalisation (out = lrelu(x + add)).
  */

@@ -23,7 +23,7 @@ SIGNATURES = {
     "spr_grid_subsample_workspace_bytes": (_sz, [_i, _i]),
     "spr_grid_subsample": (_i, [_vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "spr_radius_neighbors_workspace_bytes": (_sz, [_i, _i, _i]),
-    "spr_radius_neighbors": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _sz, _vp]),
+    "spr_radius_neighbors": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "spr_kpconv_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "spr_kpconv_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp,
                             _i, _vp, _sz, _vp]),

@@ -156,7 +156,7 @@ __global__ void k_bary(const float* __restrict__ xyz,
                        const unsigned long long* __restrict__ keys,
                        const int* __restrict__ vals, const int* __restrict__ vstart,
                        const int* __restrict__ nvox_p, int n, float* bary,
-                       unsigned long long* vkey, int* vfirst, int* cloud_cnt) {
+                       unsigned long long* vkey, int* vfirst) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   const int nvox = *nvox_p;
   if (v >= nvox) return;
@@ -177,24 +177,38 @@ __global__ void k_bary(const float* __restrict__ xyz,
   const unsigned long long k = keys[beg];
   vkey[v] = k;
   vfirst[v] = vals[beg];
-  atomicAdd(&cloud_cnt[(int)(k >> kKeyBits)], 1);
+}
+
+// vcu[c] = first voxel of cloud c (voxels are sorted by (cloud, key)); one
+// thread per cloud boundary, binary search instead of contended atomics.
+__global__ void k_cloud_lb(const unsigned long long* __restrict__ vkey,
+                           const int* __restrict__ nvox_p, int nb, int* vcu) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > nb) return;
+  const int nvox = *nvox_p;
+  int lo = 0, hi = nvox;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)(vkey[mid] >> kKeyBits) < c)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  vcu[c] = lo;
 }
 
 // Single workgroup: per-cloud voxel offsets (vcu), output lens / offsets.
-__global__ void k_cloud_offsets(const int* __restrict__ cloud_cnt, int nb, int max_p,
-                                int* vcu, int* out_cu, int* out_lens, int* out_total) {
+__global__ void k_cloud_offsets(const int* __restrict__ vcu, int nb, int max_p, int* out_cu,
+                                int* out_lens, int* out_total) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  int a = 0, b = 0;
+  int b = 0;
   for (int c = 0; c < nb; ++c) {
-    vcu[c] = a;
     out_cu[c] = b;
-    const int m = cloud_cnt[c];
+    const int m = vcu[c + 1] - vcu[c];
     const int keep = (max_p > 0 && m > max_p) ? max_p : m;
     out_lens[c] = keep;
-    a += m;
     b += keep;
   }
-  vcu[nb] = a;
   out_cu[nb] = b;
   *out_total = b;
 }
@@ -456,9 +470,10 @@ extern "C" int spr_grid_subsample(const float* xyz, const int* cu, int n, int nb
   hipLaunchKernelGGL(k_segstart, dim3(cdiv(n, TB)), dim3(TB), 0, stream, flags, vid, n,
                      vstart, nvox);
   hipLaunchKernelGGL(k_bary, dim3(cdiv(n, TB)), dim3(TB), 0, stream, xyz, keys2, vals2,
-                     vstart, nvox, n, bary, vkey, vfirst, cloud_cnt);
-  hipLaunchKernelGGL(k_cloud_offsets, dim3(1), dim3(64), 0, stream, cloud_cnt, nb, max_p,
-                     vcu, out_cu, out_lens, out_total);
+                     vstart, nvox, n, bary, vkey, vfirst);
+  hipLaunchKernelGGL(k_cloud_lb, dim3(cdiv(nb + 1, 256)), dim3(256), 0, stream, vkey, nvox, nb, vcu);
+  hipLaunchKernelGGL(k_cloud_offsets, dim3(1), dim3(64), 0, stream, vcu, nb, max_p, out_cu,
+                     out_lens, out_total);
   SPR_LAUNCH_CHECK();
   if (order_mode == SPR_ORDER_CANONICAL) {
     hipLaunchKernelGGL(k_emit_canonical, dim3(cdiv(n, TB)), dim3(TB), 0, stream, bary,

@@ -141,6 +141,21 @@ __global__ __launch_bounds__(256) void k_kpconv_cin1(
 // 256 threads = 4 waves.  Wave w: phase 1 -> queries [w*TQ/4, (w+1)*TQ/4);
 // phase 2 -> m-tile (w % MT), n-tiles [(w / MT) * NTW, +NTW).
 // Requires cout == 16 * NTW * (4 / MT).
+//
+// Phase 1 is software pipelined over "items" = (query, block of 16
+// neighbours): while item i feeds the MFMAs, the gathers of item i+1 are in
+// flight and the neighbour indices of item i+2 are being fetched, so a wave
+// always has ~2 dependent round trips outstanding instead of stalling on each.
+template <int NTC>
+struct KpItem {
+  int idx[4];
+  float sp[4][3];   // neighbour xyz, one dwordx3 per k-step
+  float b[4][NTC];
+  float qx, qy, qz;
+  int fl[4];
+  bool any;
+};
+
 template <int CC, int TQ, int NTW>
 __global__ __launch_bounds__(256) void k_kpconv_mfma(
     const float* __restrict__ q_xyz, int nq, const float* __restrict__ s_xyz, int ns,
@@ -151,16 +166,30 @@ __global__ __launch_bounds__(256) void k_kpconv_mfma(
   constexpr int NTC = CC / 16;
   constexpr int MT = TQ / 16;
   constexpr int KW = kKP * CC;       // phase-2 K per chunk
-  constexpr int STRIDE = KW + 2;     // KW % 32 == 0 -> stride = 2 mod 32 words
+  constexpr int STRIDE = KW + 2;     // conflict-free A-fragment reads (see header)
   constexpr int QPW = TQ / 4;        // queries per wave in phase 1
   extern __shared__ __align__(16) float lds[];
   float* wf = lds;                   // [TQ][STRIDE]
   int* lcnt = (int*)(lds + TQ * STRIDE);  // [TQ]
+  int* lidx = lcnt + TQ;             // [TQ][KP] neighbour indices of the tile
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int p16 = lane & 15, j4 = lane >> 4;
   const int q0 = blockIdx.x * TQ;
+  const int nblk = (kmax + 15) >> 4;      // neighbour blocks per query
+  const int KP = nblk * 16;
+  const int n_items = QPW * nblk;
+
+  // Stage the tile's neighbour rows in LDS once (coalesced), padded with the
+  // shadow index: the gather pipeline below then depends on LDS reads only, so
+  // index fetches never drain the vector-memory queue.
+  for (int e = tid; e < TQ * KP; e += 256) {
+    const int q = e / KP, k = e - q * KP;
+    const int n = q0 + q;
+    lidx[e] = (n < nq && k < kmax) ? nbr[(size_t)n * nbr_stride + k] : ns;
+  }
+  __syncthreads();
 
   // kernel point of this lane (lane 15 of each 16 is padding)
   float kx = 0.f, ky = 0.f, kz = 0.f;
@@ -178,88 +207,177 @@ __global__ __launch_bounds__(256) void k_kpconv_mfma(
 
   for (int c0 = 0; c0 < cin; c0 += CC) {
     // ------------------------------ phase 1 --------------------------------
-    for (int qi = 0; qi < QPW; ++qi) {
-      const int ql = wave * QPW + qi;
-      const int n = q0 + ql;
-      f32x4 acc1[NTC];
+    f32x4 acc1[NTC];
 #pragma unroll
-      for (int t = 0; t < NTC; ++t) acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      int cnt = 0;
-      if (n < nq) {  // wave-uniform
-        const float qx = q_xyz[3 * (size_t)n], qy = q_xyz[3 * (size_t)n + 1],
-                    qz = q_xyz[3 * (size_t)n + 2];
-        const int* row = nbr + (size_t)n * nbr_stride;
-        // blocks of 4 k-steps = 16 neighbours: issue all loads, then compute
-        for (int kb = 0; kb < kmax; kb += 16) {
-          int idx[4];
-          bool ok[4];
-          float sx[4], sy[4], sz[4];
-          float b[4][NTC];
+    for (int t = 0; t < NTC; ++t) acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int cnt = 0;
+
+    // neighbour indices of item `it` for this lane's 4 k-steps
+    auto load_idx = [&](int it, int (&idx)[4]) {
+      const bool live = it < n_items;                   // wave-uniform
+      const int itc = live ? it : 0;
+      const int qi = itc / nblk, b = itc - qi * nblk;
+      const int* row = lidx + (wave * QPW + qi) * KP + b * 16 + j4;
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int k = kb + 4 * s + j4;
-            idx[s] = (k < kmax) ? row[k] : ns;
-            ok[s] = idx[s] >= 0 && idx[s] < ns;
-          }
-          if (rows_sorted) {
-            const bool any = ok[0];  // first neighbour of the block, lanes j4==0
-            if (__ballot(any) == 0ull) break;
-          }
+      for (int s = 0; s < 4; ++s) {
+        const int v = row[4 * s];
+        idx[s] = live ? v : ns;
+      }
+    };
+    // issue the gathers of item `it` (indices already in registers)
+    auto issue = [&](int it, const int (&idx)[4], KpItem<NTC>& I) {
+      const int qi = it / nblk;
+      const int n = min(q0 + wave * QPW + qi, nq - 1);
+      bool mine = false;
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const size_t id = ok[s] ? (size_t)idx[s] : 0;
-            sx[s] = s_xyz[3 * id];
-            sy[s] = s_xyz[3 * id + 1];
-            sz[s] = s_xyz[3 * id + 2];
+      for (int s = 0; s < 4; ++s) {
+        I.idx[s] = idx[s];
+        mine |= (idx[s] >= 0 && idx[s] < ns);
+      }
+      I.any = __ballot(mine) != 0ull;   // wave-uniform; loads stay unconditional so that the
+      I.qx = q_xyz[3 * (size_t)n];
+      I.qy = q_xyz[3 * (size_t)n + 1];
+      I.qz = q_xyz[3 * (size_t)n + 2];
 #pragma unroll
-            for (int t = 0; t < NTC; ++t) b[s][t] = x[id * cin + c0 + t * 16 + p16];
-            if (c0 == 0 && p16 == 0 && ok[s]) cnt += flag[id];
-          }
+      for (int s = 0; s < 4; ++s) {
+        const bool ok = idx[s] >= 0 && idx[s] < ns;
+        const size_t id = ok ? (size_t)idx[s] : 0;
+        I.sp[s][0] = s_xyz[3 * id];      // destination registers are the struct itself
+        I.sp[s][1] = s_xyz[3 * id + 1];
+        I.sp[s][2] = s_xyz[3 * id + 2];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const float dx = (sx[s] - qx) - kx, dy = (sy[s] - qy) - ky, dz = (sz[s] - qz) - kz;
-            float w = fmaxf(0.f, 1.f - sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
-            if (!ok[s] || p16 >= kKP) w = 0.f;
+        for (int t = 0; t < NTC; ++t) I.b[s][t] = x[id * cin + c0 + t * 16 + p16];
+        I.fl[s] = (int)flag[id];
+      }
+    };
+    // consume item `it`; flush the query's accumulators after its last block
+    auto compute = [&](int it, const KpItem<NTC>& I) {
+      if (it >= n_items) return;
+      if (I.any) {
 #pragma unroll
-            for (int t = 0; t < NTC; ++t) {
-              const float bv = ok[s] ? b[s][t] : 0.f;
-              acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, bv, acc1[t], 0, 0, 0);
-            }
+        for (int s = 0; s < 4; ++s) {
+          const bool ok = I.idx[s] >= 0 && I.idx[s] < ns;
+          const float dx = (I.sp[s][0] - I.qx) - kx, dy = (I.sp[s][1] - I.qy) - ky,
+                      dz = (I.sp[s][2] - I.qz) - kz;
+          float w = fmaxf(0.f, 1.f - sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
+          if (!ok || p16 >= kKP) w = 0.f;
+          cnt += (ok && c0 == 0 && p16 == 0) ? I.fl[s] : 0;
+#pragma unroll
+          for (int t = 0; t < NTC; ++t) {
+            const float bv = ok ? I.b[s][t] : 0.f;
+            acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, bv, acc1[t], 0, 0, 0);
           }
         }
       }
-      // C/D layout: row (kernel point) = 4*j4 + r, col (channel) = p16
+      const int qi = it / nblk;
+      if (it - qi * nblk == nblk - 1) {
+        const int ql = wave * QPW + qi;
+        // C/D layout: row (kernel point) = 4*j4 + r, col (channel) = p16
 #pragma unroll
-      for (int t = 0; t < NTC; ++t)
+        for (int t = 0; t < NTC; ++t) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int p = 4 * j4 + r;
-          if (p < kKP) wf[ql * STRIDE + p * CC + t * 16 + p16] = acc1[t][r];
+          for (int r = 0; r < 4; ++r) {
+            const int p = 4 * j4 + r;
+            if (p < kKP) wf[ql * STRIDE + p * CC + t * 16 + p16] = acc1[t][r];
+          }
+          acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-      if (c0 == 0) {
-        // lanes with p16 == 0 hold partial counts (one per j4)
-        int c = cnt;
-        c += __shfl_xor(c, 16, 64);
-        c += __shfl_xor(c, 32, 64);
-        if (lane == 0) lcnt[ql] = c;
+        if (c0 == 0) {
+          int c = cnt;  // lanes with p16 == 0 hold the partial counts (one per j4)
+          c += __shfl_xor(c, 16, 64);
+          c += __shfl_xor(c, 32, 64);
+          if (lane == 0) lcnt[ql] = c;
+        }
+        cnt = 0;
+      }
+    };
+
+    {
+      KpItem<NTC> A, B;
+      int ia[4], ib[4];
+      load_idx(0, ia);
+      issue(0, ia, A);
+      load_idx(1, ib);
+      for (int it = 0; it < n_items; it += 2) {
+        issue(it + 1, ib, B);
+        load_idx(it + 2, ia);
+        compute(it, A);
+        issue(it + 2, ia, A);
+        load_idx(it + 3, ib);
+        compute(it + 1, B);
       }
     }
     __syncthreads();
     // ------------------------------ phase 2 --------------------------------
+    // W streams from L2 straight into registers through a ring of D batches of
+    // U k-steps: the loads of batch i+D are issued right after batch i's MFMAs,
+    // so D-1 batches (~1k cycles of MFMA work) cover the L2 latency.
     {
       const float* arow = wf + (mt * 16 + p16) * STRIDE + j4;
-      // W row for phase-2 k index kk (within chunk): p = kk / CC, c = kk % CC
-      for (int k0 = 0; k0 < KW; k0 += 4) {
-        const float a = arow[k0];
-        const int kk = k0 + j4;
-        const int p = kk / CC, c = kk % CC;
-        const float* wrow = W + ((size_t)p * cin + c0 + c) * cout + (ng * NTW) * 16 + p16;
+      const float* wbase = W + (size_t)c0 * cout + (ng * NTW) * 16 + p16;
+      constexpr int NSTEP = KW / 4;                   // 240 / 120 / 60
+      constexpr int U = (CC == 16 && NTW == 1) ? 4 : 8 / NTW;   // k-steps per batch (<= 8 loads)
+      static_assert(NTW <= 8, "at most 8 n-tiles per wave");
+      constexpr int D = 5;                            // batches in flight
+      constexpr int NBATCH = NSTEP / U;
+      static_assert(NSTEP % U == 0 && NBATCH % D == 0 && NBATCH >= 2 * D, "ring shape");
+      // hipcc sinks ordinary loads down to their first use (one exposed L2 round
+      // trip per k-step), so the ring is issued with inline-asm loads and
+      // retired with hand-counted s_waitcnt vmcnt(N): no other vector memory
+      // operation is in flight in this phase (phase 1 is fully drained by the
+      // barrier above; LDS traffic counts on lgkmcnt).
+      constexpr int LPB = U * NTW;                    // loads per batch
+      float bv[D][U][NTW];
+      auto load_batch = [&](int bi, float (&dst)[U][NTW]) {
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-          const float bv = wrow[t * 16];
-          acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc2[t], 0, 0, 0);
+        for (int u = 0; u < U; ++u) {
+          const int kk = 4 * (bi * U + u) + j4;       // k index within the chunk
+          const int p = kk / CC, c = kk % CC;
+          const float* wrow = wbase + ((size_t)p * cin + c) * cout;
+#pragma unroll
+          for (int t = 0; t < NTW; ++t)
+            asm volatile("global_load_dword %0, %1, off" : "=v"(dst[u][t]) : "v"(wrow + t * 16));
+        }
+      };
+      auto mma_batch = [&](int bi, const float (&src)[U][NTW]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float a = arow[4 * (bi * U + u)];
+#pragma unroll
+          for (int t = 0; t < NTW; ++t)
+            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, src[u][t], acc2[t], 0, 0, 0);
+        }
+      };
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int d = 0; d < D; ++d) load_batch(d, bv[d]);
+      for (int b0 = 0; b0 < NBATCH - D; b0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPB) : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          mma_batch(b0 + d, bv[d]);
+          __builtin_amdgcn_sched_barrier(0);
+          load_batch(b0 + d + D, bv[d]);
         }
       }
+      // drain: batch NBATCH-D+d has (D-1-d) younger batches behind it
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPB) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      mma_batch(NBATCH - D + 0, bv[0]);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPB) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      mma_batch(NBATCH - D + 1, bv[1]);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPB) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      mma_batch(NBATCH - D + 2, bv[2]);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * LPB) : "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      mma_batch(NBATCH - D + 3, bv[3]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      mma_batch(NBATCH - D + 4, bv[4]);
+      static_assert(D == 5, "drain sequence is written for D == 5");
     }
     __syncthreads();
   }
@@ -313,12 +431,18 @@ int launch_mfma(const float* q_xyz, int nq, const float* s_xyz, int ns, const in
                 const float* W, int cout, const float* kpts, float inv_extent,
                 const unsigned char* flag, float* out, hipStream_t stream) {
   constexpr int STRIDE = kKP * CC + 2;
-  const size_t lds = sizeof(float) * (size_t)TQ * STRIDE + sizeof(int) * TQ;
+  const int kp = ((kmax + 15) / 16) * 16;
+  const size_t lds = sizeof(float) * (size_t)TQ * STRIDE + sizeof(int) * TQ + sizeof(int) * (size_t)TQ * kp;
   auto kern = k_kpconv_mfma<CC, TQ, NTW>;
   ProfScope prof(stream, cin, cout, nq);
+  SPR_REQUIRE(lds <= 80 * 1024, "kpconv: neighbour rows too wide for the LDS tile (kmax=%d)", kmax);
   if (lds > 64 * 1024) {
-    SPR_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static bool raised = false;  // per instantiation
+    if (!raised) {
+      SPR_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+      raised = true;
+    }
   }
   hipLaunchKernelGGL(kern, dim3(cdiv(nq, TQ)), dim3(256), lds, stream, q_xyz, nq, s_xyz, ns,
                      nbr, nbr_stride, kmax, rows_sorted, x, cin, W, cout, kpts, inv_extent,

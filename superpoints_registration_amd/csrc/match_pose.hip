@@ -60,18 +60,19 @@ __global__ void k_row_lse(const float* __restrict__ mat, const PairDesc* __restr
   if (lane == 0) row_out[p.src_beg + row] = mx + logf(s);
 }
 
-// block = 256 threads: 64 columns x 4 row lanes
-__global__ __launch_bounds__(256) void k_col_lse(const float* __restrict__ mat,
+// block = 1024 threads: 64 columns x 16 row lanes
+constexpr int kColLanes = 16;
+__global__ __launch_bounds__(1024) void k_col_lse(const float* __restrict__ mat,
                                                  const PairDesc* __restrict__ pd,
                                                  float* __restrict__ col_out,
                                                  const float* __restrict__ row_sub, int slack) {
   const PairDesc p = pd[blockIdx.y];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
-  __shared__ float smx[4][64], ssum[4][64];
+  __shared__ float smx[kColLanes][64], ssum[kColLanes][64];
   float mx = -INFINITY, s = 0.f;
   if (col < p.m) {
-    for (int i = rl; i < p.n; i += 4) {
+    for (int i = rl; i < p.n; i += kColLanes) {
       const float v = mat[p.off + (size_t)i * p.m + col] - (row_sub ? row_sub[p.src_beg + i] : 0.f);
       if (v > mx) {
         s = s * expf(mx - v) + 1.f;
@@ -86,9 +87,9 @@ __global__ __launch_bounds__(256) void k_col_lse(const float* __restrict__ mat,
   __syncthreads();
   if (rl == 0 && col < p.m) {
     float M = slack ? 0.f : -INFINITY;
-    for (int k = 0; k < 4; ++k) M = fmaxf(M, smx[k][cl]);
+    for (int k = 0; k < kColLanes; ++k) M = fmaxf(M, smx[k][cl]);
     float S = slack ? expf(0.f - M) : 0.f;
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < kColLanes; ++k)
       if (smx[k][cl] > -INFINITY) S += ssum[k][cl] * expf(smx[k][cl] - M);
     col_out[p.tgt_beg + col] = M + logf(S);
   }
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void k_col_lse(const float* __restrict__ mat,
 // ---- dual softmax arg-max ---------------------------------------------------
 // N > M : for every tgt j   arg max_i  exp(c - col_lse[j]) * exp(c - row_lse[i])
 // else  : for every src i   arg max_j  (same product)
-__global__ __launch_bounds__(256) void k_match_cols(const float* __restrict__ mat,
+__global__ __launch_bounds__(1024) void k_match_cols(const float* __restrict__ mat,
                                                     const PairDesc* __restrict__ pd,
                                                     const float* __restrict__ row_lse,
                                                     const float* __restrict__ col_lse,
@@ -106,13 +107,13 @@ __global__ __launch_bounds__(256) void k_match_cols(const float* __restrict__ ma
   if (!(p.n > p.m)) return;
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
-  __shared__ float sv[4][64];
-  __shared__ int si[4][64];
+  __shared__ float sv[kColLanes][64];
+  __shared__ int si[kColLanes][64];
   float best = -1.f;
   int bi = 0;
   if (col < p.m) {
     const float cl_j = col_lse[p.tgt_beg + col];
-    for (int i = rl; i < p.n; i += 4) {
+    for (int i = rl; i < p.n; i += kColLanes) {
       const float c = mat[p.off + (size_t)i * p.m + col];
       const float a = expf(c - cl_j) * expf(c - row_lse[p.src_beg + i]);
       if (a > best) {
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void k_match_cols(const float* __restrict__ ma
   si[rl][cl] = bi;
   __syncthreads();
   if (rl == 0 && col < p.m) {
-    for (int k = 1; k < 4; ++k) {
+    for (int k = 1; k < kColLanes; ++k) {
       const float b = sv[k][cl];
       const int i = si[k][cl];
       if (b > best || (b == best && i < bi)) {
@@ -491,9 +492,9 @@ extern "C" int spr_match_dualsoftmax(const float* feat, int d, const int* cu, co
   hipLaunchKernelGGL(k_scale, dim3(cdiv(total, 256)), dim3(256), 0, stream, mat, total, scale);
   hipLaunchKernelGGL(k_row_lse, dim3(cdiv((long)max_n * 64, 256), npairs), dim3(256), 0, stream, mat,
                      pd, row_lse, (const float*)nullptr, 0);
-  hipLaunchKernelGGL(k_col_lse, dim3(cdiv(max_m, 64), npairs), dim3(256), 0, stream, mat, pd, col_lse,
+  hipLaunchKernelGGL(k_col_lse, dim3(cdiv(max_m, 64), npairs), dim3(1024), 0, stream, mat, pd, col_lse,
                      (const float*)nullptr, 0);
-  hipLaunchKernelGGL(k_match_cols, dim3(cdiv(max_m, 64), npairs), dim3(256), 0, stream, mat, pd,
+  hipLaunchKernelGGL(k_match_cols, dim3(cdiv(max_m, 64), npairs), dim3(1024), 0, stream, mat, pd,
                      row_lse, col_lse, match_val, match_ind);
   hipLaunchKernelGGL(k_match_rows, dim3(cdiv((long)max_n * 64, 256), npairs), dim3(256), 0, stream,
                      mat, pd, row_lse, col_lse, match_val, match_ind);
@@ -531,7 +532,7 @@ extern "C" int spr_sinkhorn_correspondences(const float* feat, int d, const floa
   for (int it = 0; it < n_iters; ++it) {
     hipLaunchKernelGGL(k_row_lse, dim3(cdiv((long)max_n * 64, 256), npairs), dim3(256), 0, stream,
                        mat, pd, u, (const float*)v, 1);
-    hipLaunchKernelGGL(k_col_lse, dim3(cdiv(max_m, 64), npairs), dim3(256), 0, stream, mat, pd, v,
+    hipLaunchKernelGGL(k_col_lse, dim3(cdiv(max_m, 64), npairs), dim3(1024), 0, stream, mat, pd, v,
                        (const float*)u, 1);
   }
   hipLaunchKernelGGL(k_sinkhorn_final, dim3(cdiv((long)max_n * 64, 256), npairs), dim3(256), 0,

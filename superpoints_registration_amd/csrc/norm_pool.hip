@@ -23,47 +23,73 @@ namespace {
 // Row slices are relative to each cloud's own start and have a fixed length,
 // so a cloud's statistics do not depend on what else is in the batch
 // (bitwise batch invariance).
-constexpr int kSliceRows = 1024;
+constexpr int kSliceRows = 512;
 int in_nsplit(int max_len) {
   int s = cdiv(max_len > 0 ? max_len : 1, kSliceRows);
   return s < 1 ? 1 : s;
 }
 
-// block = 256 threads = (256/CW) row lanes x CW channel lanes, CW = min(c,64)
+// grid (cloud, split, channel block of <= 64 channels); block = 256 threads =
+// (256 / CW4) row lanes x CW4 float4 columns.  Every thread streams its rows
+// with 4 independent 16-byte loads in flight and accumulates in float64; row
+// lanes are combined through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void k_in_stats(const float* __restrict__ x,
                                                   const int* __restrict__ cu, int c, int nsplit,
                                                   double* __restrict__ part /*[nb][nsplit][2][c]*/) {
-  const int cloud = blockIdx.x, split = blockIdx.y;
+  const int cloud = blockIdx.x, split = blockIdx.y, cb = blockIdx.z * 64;
   const int beg = cu[cloud], end = cu[cloud + 1];
   const int r0 = beg + split * kSliceRows;
   const int r1 = min(r0 + kSliceRows, end);
-  const int cw = c < 64 ? c : 64;
-  const int rl = 256 / cw;  // row lanes
-  const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
-  __shared__ double sh[2][256];
-  for (int cb = 0; cb < c; cb += cw) {
-    const int ch = cb + tc;
-    double s = 0.0, ss = 0.0;
-    if (tr < rl && ch < c) {
-      for (int r = r0 + tr; r < r1; r += rl) {
-        const double v = (double)x[(size_t)r * c + ch];
-        s += v;
-        ss += v * v;
+  const int cw = min(c - cb, 64);
+  const int cw4 = cw >> 2;
+  const int rl = 256 / cw4;  // row lanes
+  const int tc = threadIdx.x % cw4, tr = threadIdx.x / cw4;
+  __shared__ double sh[8][256];
+  double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+  if (tr < rl) {
+    const float* base = x + cb + 4 * tc;
+    int r = r0 + tr;
+    for (; r + 3 * rl < r1; r += 4 * rl) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        v[u] = *reinterpret_cast<const float4*>(base + (size_t)(r + u * rl) * c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double a = v[u].x, b = v[u].y, cc = v[u].z, d = v[u].w;
+        s[0] += a; ss[0] += a * a;
+        s[1] += b; ss[1] += b * b;
+        s[2] += cc; ss[2] += cc * cc;
+        s[3] += d; ss[3] += d * d;
       }
     }
-    sh[0][threadIdx.x] = s;
-    sh[1][threadIdx.x] = ss;
-    __syncthreads();
-    if (tr == 0 && ch < c) {
-      for (int k = 1; k < rl; ++k) {
-        s += sh[0][k * cw + tc];
-        ss += sh[1][k * cw + tc];
-      }
-      double* p = part + (((size_t)cloud * nsplit + split) * 2) * c;
-      p[ch] = s;
-      p[c + ch] = ss;
+    for (; r < r1; r += rl) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (size_t)r * c);
+      const double a = v.x, b = v.y, cc = v.z, d = v.w;
+      s[0] += a; ss[0] += a * a;
+      s[1] += b; ss[1] += b * b;
+      s[2] += cc; ss[2] += cc * cc;
+      s[3] += d; ss[3] += d * d;
     }
-    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    sh[k][threadIdx.x] = s[k];
+    sh[4 + k][threadIdx.x] = ss[k];
+  }
+  __syncthreads();
+  if (tr == 0) {
+    double* p = part + (((size_t)cloud * nsplit + split) * 2) * c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double a = s[k], b = ss[k];
+      for (int q = 1; q < rl; ++q) {
+        a += sh[k][q * cw4 + tc];
+        b += sh[4 + k][q * cw4 + tc];
+      }
+      p[cb + 4 * tc + k] = a;
+      p[c + cb + 4 * tc + k] = b;
+    }
   }
 }
 
@@ -177,7 +203,7 @@ extern "C" int spr_instnorm(const float* x, const int* cu, int n, int nb, int ma
     mean = w.take<float>((size_t)nb * c);
     rstd = w.take<float>((size_t)nb * c);
     SPR_REQUIRE(rstd != nullptr, "instnorm: workspace carve failed");
-    hipLaunchKernelGGL(k_in_stats, dim3(nb, nsplit), dim3(256), 0, stream, x, cu, c, nsplit, part);
+    hipLaunchKernelGGL(k_in_stats, dim3(nb, nsplit, cdiv(c, 64)), dim3(256), 0, stream, x, cu, c, nsplit, part);
     hipLaunchKernelGGL(k_in_final, dim3(cdiv((long)nb * c, 256)), dim3(256), 0, stream, part, cu,
                        nb, c, nsplit, eps, mean, rstd);
     SPR_LAUNCH_CHECK();

@@ -189,6 +189,213 @@ __global__ __launch_bounds__(BLOCK) void k_query(
   if ((t & 63) == 0 && m > 0) atomicMax(max_count, m);
 }
 
+
+// ===========================================================================
+// Fast path (algo 0): dense per-cloud cell table.
+//   k_grid_dims   per cloud: bbox min/max -> grid dims (cells of r*(1+2^-8))
+//   k_grid_offsets  prefix of the per-cloud cell counts (overflow -> error)
+//   k_cell_count  one integer atomic per support point (spread over ~N cells)
+//   rocPRIM exclusive scan over the cell counts -> cell starts
+//   k_cell_scatter  counting-sort scatter of (xyz, index) records
+//   k_query_table one thread per query: the 9 (dz,dy) rows of the 3x3x3
+//                 neighbourhood are 9 contiguous record ranges whose bounds
+//                 are 18 independent loads; candidates stream as 16-byte
+//                 records, 4 in flight.
+// The order inside a cell depends on atomic arrival order, the OUTPUT does
+// not: rows are ordered by (d2, index) and the K-nearest cut uses the same
+// total order.
+struct GridCloud {
+  float mn[3];
+  int dim[3];
+  long long off;  // first cell of this cloud in the table
+};
+
+__global__ __launch_bounds__(256) void k_grid_dims(const float* __restrict__ xyz,
+                                                   const int* __restrict__ cu, float inv_cell,
+                                                   GridCloud* info, int* err) {
+  const int c = blockIdx.x;
+  const int beg = cu[c], end = cu[c + 1];
+  __shared__ float smn[3][256], smx[3][256];
+  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int i = beg + threadIdx.x; i < end; i += blockDim.x)
+    for (int d = 0; d < 3; ++d) {
+      const float v = xyz[3 * (size_t)i + d];
+      mn[d] = fminf(mn[d], v);
+      mx[d] = fmaxf(mx[d], v);
+    }
+  for (int d = 0; d < 3; ++d) {
+    smn[d][threadIdx.x] = mn[d];
+    smx[d][threadIdx.x] = mx[d];
+  }
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s)
+      for (int d = 0; d < 3; ++d) {
+        smn[d][threadIdx.x] = fminf(smn[d][threadIdx.x], smn[d][threadIdx.x + s]);
+        smx[d][threadIdx.x] = fmaxf(smx[d][threadIdx.x], smx[d][threadIdx.x + s]);
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    GridCloud g;
+    for (int d = 0; d < 3; ++d) {
+      g.mn[d] = (end > beg) ? smn[d][0] : 0.f;
+      int n = 1;
+      if (end > beg) {
+        n = cell_coord(smx[d][0], g.mn[d], inv_cell) + 1;
+        if (n < 1) n = 1;
+        if (n > kMaxCell + 1) {
+          atomicOr(err, 1);
+          n = 1;
+        }
+      }
+      g.dim[d] = n;
+    }
+    g.off = 0;
+    info[c] = g;
+  }
+}
+
+__global__ void k_grid_offsets(GridCloud* info, int nb, long long cap, int* err) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  long long off = 0;
+  for (int c = 0; c < nb; ++c) {
+    info[c].off = off;
+    off += (long long)info[c].dim[0] * info[c].dim[1] * info[c].dim[2];
+    if (off > cap) {  // table too small for this geometry: flag, keep offsets in range
+      atomicOr(err, 2);
+      off = 0;
+    }
+  }
+}
+
+__device__ __forceinline__ long long grid_cell(const GridCloud& g, int cx, int cy, int cz) {
+  return g.off + ((long long)cz * g.dim[1] + cy) * g.dim[0] + cx;
+}
+
+__global__ void k_cell_count(const float* __restrict__ xyz, const int* __restrict__ cu, int n, int nb,
+                             float inv_cell, const GridCloud* __restrict__ info,
+                             const int* __restrict__ err, int* count, int* cell_of) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || *err) return;
+  const int c = find_segment(cu, nb, i);
+  const GridCloud g = info[c];
+  int cx = cell_coord(xyz[3 * (size_t)i + 0], g.mn[0], inv_cell);
+  int cy = cell_coord(xyz[3 * (size_t)i + 1], g.mn[1], inv_cell);
+  int cz = cell_coord(xyz[3 * (size_t)i + 2], g.mn[2], inv_cell);
+  cx = min(max(cx, 0), g.dim[0] - 1);
+  cy = min(max(cy, 0), g.dim[1] - 1);
+  cz = min(max(cz, 0), g.dim[2] - 1);
+  const long long L = grid_cell(g, cx, cy, cz);
+  cell_of[i] = (int)L;
+  atomicAdd(&count[L], 1);
+}
+
+__global__ void k_cell_scatter(const float* __restrict__ xyz, int n, const int* __restrict__ err,
+                               const int* __restrict__ cell_of, const int* __restrict__ start,
+                               int* cursor, float4* rec) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || *err) return;
+  const int L = cell_of[i];
+  const int pos = start[L] + atomicAdd(&cursor[L], 1);
+  rec[pos] = make_float4(xyz[3 * (size_t)i + 0], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2],
+                         __int_as_float(i));
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_query_table(
+    const float* __restrict__ q_xyz, const int* __restrict__ q_cu, int nq, int ns, int nb,
+    const GridCloud* __restrict__ info, const int* __restrict__ start,
+    const float4* __restrict__ rec, const int* __restrict__ err, float r2, float inv_cell,
+    int limit, int* __restrict__ out, int* max_count) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* l_d2 = (float*)smem;
+  int* l_id = (int*)(smem + sizeof(float) * (size_t)limit * BLOCK);
+  const int t = threadIdx.x;
+  const int i = blockIdx.x * BLOCK + t;
+  if (*err) return;
+  int total = 0;
+  if (i < nq) {
+    const int c = find_segment(q_cu, nb, i);
+    const GridCloud g = info[c];
+    const float qx = q_xyz[3 * (size_t)i + 0], qy = q_xyz[3 * (size_t)i + 1],
+                qz = q_xyz[3 * (size_t)i + 2];
+    const int cx = cell_coord(qx, g.mn[0], inv_cell);
+    const int cy = cell_coord(qy, g.mn[1], inv_cell);
+    const int cz = cell_coord(qz, g.mn[2], inv_cell);
+    const int xlo = max(cx - 1, 0), xhi = min(cx + 1, g.dim[0] - 1);
+    int rb[9], re[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int z = cz + k / 3 - 1, y = cy + k % 3 - 1;
+      const bool in = xlo <= xhi && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
+      const long long L0 = in ? grid_cell(g, xlo, y, z) : 0;
+      const long long L1 = in ? grid_cell(g, xhi, y, z) + 1 : 0;
+      rb[k] = start[L0];
+      re[k] = in ? start[L1] : rb[k];
+    }
+    int kept = 0;
+    auto consider = [&](const float4 s) {
+      // nanoflann.hpp:432-440: diff = query - support; result += diff*diff
+      const float dx = __fsub_rn(qx, s.x), dy = __fsub_rn(qy, s.y), dz = __fsub_rn(qz, s.z);
+      float d2 = __fmul_rn(dx, dx);
+      d2 = __fadd_rn(d2, __fmul_rn(dy, dy));
+      d2 = __fadd_rn(d2, __fmul_rn(dz, dz));
+      if (!(d2 < r2)) return;  // strict, nanoflann.hpp:249
+      total++;
+      const int sid = __float_as_int(s.w);
+      int pos;
+      if (kept < limit) {
+        pos = kept++;
+      } else {
+        const int last = limit - 1;
+        if (!nbr_less(d2, sid, l_d2[last * BLOCK + t], l_id[last * BLOCK + t])) return;
+        pos = last;
+      }
+      while (pos > 0 &&
+             nbr_less(d2, sid, l_d2[(pos - 1) * BLOCK + t], l_id[(pos - 1) * BLOCK + t])) {
+        l_d2[pos * BLOCK + t] = l_d2[(pos - 1) * BLOCK + t];
+        l_id[pos * BLOCK + t] = l_id[(pos - 1) * BLOCK + t];
+        --pos;
+      }
+      l_d2[pos * BLOCK + t] = d2;
+      l_id[pos * BLOCK + t] = sid;
+    };
+#pragma unroll 1
+    for (int k = 0; k < 9; ++k) {
+      int j = rb[k];
+      const int e = re[k];
+      for (; j + 3 < e; j += 4) {
+        const float4 s0 = rec[j], s1 = rec[j + 1], s2 = rec[j + 2], s3 = rec[j + 3];
+        consider(s0);
+        consider(s1);
+        consider(s2);
+        consider(s3);
+      }
+      for (; j < e; ++j) consider(rec[j]);
+    }
+    int* row = out + (size_t)i * limit;
+    for (int k = 0; k < limit; ++k) row[k] = (k < kept) ? l_id[k * BLOCK + t] : ns;
+  }
+  int m = total;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+  if ((t & 63) == 0 && m > 0) atomicMax(max_count, m);
+}
+
+__global__ void k_nbr_err2(const int* err, int* max_count) {
+  if (*err & 1) *max_count = -1;       // extent / radius too large
+  else if (*err & 2) *max_count = -2;  // cell table overflow -> caller retries with algo 1
+}
+
+size_t table_cap_cells(int ns) { return (size_t)64 * (size_t)(ns > 0 ? ns : 1) + ((size_t)1 << 20); }
+
+size_t scan_temp_bytes(size_t n) {
+  size_t sb = 0;
+  (void)rocprim::exclusive_scan(nullptr, sb, (int*)nullptr, (int*)nullptr, 0, n, rocprim::plus<int>());
+  return align_up(sb, 256) + 256;
+}
+
 __global__ void k_nbr_err(const int* err, int* max_count) {
   if (*err) *max_count = -1;
 }
@@ -216,13 +423,19 @@ extern "C" size_t spr_radius_neighbors_workspace_bytes(int nq, int ns, int nb) {
   b += align_up(16 * N, 256);
   b += 256;
   b += nbr_sort_temp_bytes(ns);
+  // cell-table path
+  const size_t cap = table_cap_cells(ns);
+  b += align_up(sizeof(GridCloud) * B, 256);
+  b += 3 * align_up(4 * (cap + 1), 256);  // count, start, cursor
+  b += align_up(4 * N, 256);              // cell_of
+  b += scan_temp_bytes(cap + 1);
   return b;
 }
 
 extern "C" int spr_radius_neighbors(const float* q_xyz, const int* q_cu, int nq,
                                     const float* s_xyz, const int* s_cu, int ns, int nb,
-                                    float radius, int limit, int* out_idx, int* max_count,
-                                    void* ws, size_t ws_bytes, void* stream_) {
+                                    float radius, int limit, int algo, int* out_idx,
+                                    int* max_count, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(nq > 0 && ns > 0 && nb >= 1, "radius_neighbors: empty input (nq=%d ns=%d)", nq, ns);
   SPR_REQUIRE(nb < 65536, "radius_neighbors: at most 65535 clouds per call");
@@ -250,6 +463,43 @@ extern "C" int spr_radius_neighbors(const float* q_xyz, const int* q_cu, int nq,
   SPR_HIP_CHECK(hipMemsetAsync(err, 0, 16 * sizeof(int), stream));
   SPR_HIP_CHECK(hipMemsetAsync(max_count, 0, sizeof(int), stream));
   const int TB = 256;
+  if (algo == 0) {
+    const size_t cap = table_cap_cells(ns);
+    GridCloud* ginfo = w.take<GridCloud>(nb);
+    int* count = w.take<int>(cap + 1);
+    int* start = w.take<int>(cap + 1);
+    int* cursor = w.take<int>(cap + 1);
+    int* cell_of = w.take<int>(N);
+    const size_t stemp_bytes = scan_temp_bytes(cap + 1);
+    void* stemp = w.take<char>(stemp_bytes);
+    SPR_REQUIRE(stemp != nullptr, "radius_neighbors: workspace carve failed (table)");
+    SPR_HIP_CHECK(hipMemsetAsync(count, 0, (cap + 1) * sizeof(int), stream));
+    SPR_HIP_CHECK(hipMemsetAsync(cursor, 0, (cap + 1) * sizeof(int), stream));
+    hipLaunchKernelGGL(k_grid_dims, dim3(nb), dim3(256), 0, stream, s_xyz, s_cu, inv_cell, ginfo, err);
+    hipLaunchKernelGGL(k_grid_offsets, dim3(1), dim3(64), 0, stream, ginfo, nb, (long long)cap, err);
+    hipLaunchKernelGGL(k_cell_count, dim3(cdiv(ns, TB)), dim3(TB), 0, stream, s_xyz, s_cu, ns, nb,
+                       inv_cell, ginfo, err, count, cell_of);
+    SPR_LAUNCH_CHECK();
+    size_t sb = stemp_bytes;
+    SPR_HIP_CHECK(rocprim::exclusive_scan(stemp, sb, count, start, 0, cap + 1, rocprim::plus<int>(),
+                                          stream));
+    hipLaunchKernelGGL(k_cell_scatter, dim3(cdiv(ns, TB)), dim3(TB), 0, stream, s_xyz, ns, err, cell_of,
+                       start, cursor, rec);
+    if (limit <= 64) {
+      constexpr int BLOCK = 128;
+      hipLaunchKernelGGL(k_query_table<BLOCK>, dim3(cdiv(nq, BLOCK)), dim3(BLOCK),
+                         (size_t)limit * BLOCK * 8, stream, q_xyz, q_cu, nq, ns, nb, ginfo, start, rec,
+                         err, r2, inv_cell, limit, out_idx, max_count);
+    } else {
+      constexpr int BLOCK = 64;
+      hipLaunchKernelGGL(k_query_table<BLOCK>, dim3(cdiv(nq, BLOCK)), dim3(BLOCK),
+                         (size_t)limit * BLOCK * 8, stream, q_xyz, q_cu, nq, ns, nb, ginfo, start, rec,
+                         err, r2, inv_cell, limit, out_idx, max_count);
+    }
+    hipLaunchKernelGGL(k_nbr_err2, dim3(1), dim3(1), 0, stream, err, max_count);
+    SPR_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_min, dim3(nb), dim3(256), 0, stream, s_xyz, s_cu, info);
   hipLaunchKernelGGL(k_cellkeys, dim3(cdiv(ns, TB)), dim3(TB), 0, stream, s_xyz, s_cu, ns, nb,
                      inv_cell, info, keys, vals, err);

@@ -90,7 +90,7 @@ def grid_subsample(points: torch.Tensor, cu: torch.Tensor, dl: float, max_p: int
 
 def radius_neighbors(queries: torch.Tensor, supports: torch.Tensor, q_cu: torch.Tensor,
                      s_cu: torch.Tensor, radius: float, limit: int,
-                     exact_width: bool = True) -> Tuple[torch.Tensor, int]:
+                     exact_width: bool = True, algo: int = 0) -> Tuple[torch.Tensor, int]:
     """a2.  int32 [Nq, W] neighbour indices (shadow = Ns) and the untruncated
     max count.  exact_width=True slices to W = min(max_count, limit) like the
     reference (one device->host read); False keeps W = limit (no sync)."""
@@ -104,11 +104,13 @@ def radius_neighbors(queries: torch.Tensor, supports: torch.Tensor, q_cu: torch.
     out = torch.empty((nq, limit), dtype=torch.int32, device=queries.device)
     mc = torch.empty((1,), dtype=torch.int32, device=queries.device)
     _lib.check(L.spr_radius_neighbors(_ptr(queries), _ptr(q_cu), nq, _ptr(supports), _ptr(s_cu), ns,
-                                      nb, float(radius), int(limit), _ptr(out), _ptr(mc), _ptr(ws),
-                                      ws.numel(), _stream(queries)), "spr_radius_neighbors")
+                                      nb, float(radius), int(limit), int(algo), _ptr(out), _ptr(mc),
+                                      _ptr(ws), ws.numel(), _stream(queries)), "spr_radius_neighbors")
     if not exact_width:
         return out, -1
     m = int(mc.item())
+    if m == -2 and algo == 0:   # cell table too small for this geometry: exact same result, slower path
+        return radius_neighbors(queries, supports, q_cu, s_cu, radius, limit, exact_width, algo=1)
     if m < 0:
         raise RuntimeError("spr_radius_neighbors: cloud extent / radius exceeds 8191 cells per axis")
     if m < 1:  # cpp_neighbors/wrapper.cpp:201-205

@@ -71,6 +71,28 @@ def test_radius_neighbors_vs_reference_golden(gold, device, case, which):
         assert np.array_equal(got, ref[:, :w])      # tie-free: bit-exact vs the reference itself
 
 
+@pytest.mark.parametrize("case", CASES)
+def test_both_search_algorithms_agree(gold, device, case):
+    """algo 0 (dense cell table) and algo 1 (sorted keys + binary search) are
+    the same function."""
+    pts, lens, r = gold[f"{case}.pts"], gold[f"{case}.lens"], float(gold[f"{case}.radius"])
+    d, cu = torch.from_numpy(pts).to(device), _cu(lens, device)
+    a, ma = ops.radius_neighbors(d, d, cu, cu, r, 64, algo=0)
+    b, mb = ops.radius_neighbors(d, d, cu, cu, r, 64, algo=1)
+    assert ma == mb and torch.equal(a, b)
+
+
+def test_cell_table_overflow_falls_back(device):
+    # two far-apart clusters in one cloud: bounding box needs far more cells than the table holds
+    rng = np.random.default_rng(0)
+    a = rng.uniform(0, 0.05, (300, 3)).astype(np.float32)
+    pts = np.concatenate([a, a + np.float32(60.0)])
+    d, cu = torch.from_numpy(pts).to(device), _cu([600], device)
+    got, mc = ops.radius_neighbors(d, d, cu, cu, 0.01, 32)           # silently retried with algo 1
+    orc, mc2 = native.radius_neighbors(pts, pts, [600], [600], 0.01, limit=32)
+    assert mc == mc2 and np.array_equal(got.cpu().numpy(), orc)
+
+
 def test_limit_below_max_count_keeps_k_nearest(gold, device):
     pts, lens, r = gold["dense.pts"], gold["dense.lens"], float(gold["dense.radius"])
     got, mc = ops.radius_neighbors(torch.from_numpy(pts).to(device), torch.from_numpy(pts).to(device),
