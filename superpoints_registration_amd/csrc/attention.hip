@@ -35,8 +35,9 @@ __global__ __launch_bounds__(256) void k_attn(
     const float* __restrict__ v, int v_stride, const int* __restrict__ cu,
     const int* __restrict__ kv_seg, int nhead, float scale, float* __restrict__ out,
     int o_stride) {
-  __shared__ float Ks[KT * KS];
-  __shared__ float Vs[KT * HD];
+  // two LDS stages: tile t+1 is written while tile t is being read; one barrier per tile
+  __shared__ float Ks[2][KT * KS];
+  __shared__ float Vs[2][KT * HD];
   const int seg = blockIdx.z, head = blockIdx.y;
   const int qbeg = cu[seg], qlen = cu[seg + 1] - qbeg;
   const int q0 = blockIdx.x * QB;
@@ -51,12 +52,14 @@ __global__ __launch_bounds__(256) void k_attn(
   const int hoff = head * HD;
 
   // Q^T as B operand of S^T = K Q^T:  B[k = d][col = query]; step s covers
-  // d = 2s + lh.  Pre-scaled by 1/sqrt(head_dim).
+  // d = 2s + lh.  Pre-scaled by log2(e)/sqrt(head_dim): softmax runs in base 2
+  // (v_exp_f32 is a base-2 exponential), mathematically identical.
   float qreg[16];
   {
+    const float sc = scale * 1.4426950408889634f;
     const float* qp = q + (size_t)(qbeg + (qok ? qi : 0)) * q_stride + hoff;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) qreg[s] = qok ? qp[2 * s + lh] * scale : 0.f;
+    for (int s = 0; s < 16; ++s) qreg[s] = qok ? qp[2 * s + lh] * sc : 0.f;
   }
 
   f32x16 o;  // O^T[d][query]: lane = query, d = (r&3) + 8*(r>>2) + 4*lh
@@ -64,34 +67,65 @@ __global__ __launch_bounds__(256) void k_attn(
   for (int r = 0; r < 16; ++r) o[r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
-  for (int kt = 0; kt < klen; kt += KT) {
-    __syncthreads();  // previous tile fully consumed
-    {
-      // 256 threads stage 32 keys x 32 dims of K and V (one float4 each)
-      const int r = tid >> 3, c4 = (tid & 7) * 4;
-      float4 kv4 = make_float4(0.f, 0.f, 0.f, 0.f), vv4 = kv4;
-      if (kt + r < klen) {
-        const size_t row = (size_t)(kbeg + kt + r);
-        kv4 = *reinterpret_cast<const float4*>(k + row * k_stride + hoff + c4);
-        vv4 = *reinterpret_cast<const float4*>(v + row * v_stride + hoff + c4);
-      }
-      float* kd = Ks + r * KS + c4;
-      kd[0] = kv4.x;
-      kd[1] = kv4.y;
-      kd[2] = kv4.z;
-      kd[3] = kv4.w;
-      *reinterpret_cast<float4*>(Vs + r * HD + c4) = vv4;
-    }
-    __syncthreads();
+  // staging role of this thread: key row sr (0..31), 4 dims starting at sc4
+  const int sr = tid >> 3, sc4 = (tid & 7) * 4;
+  f32x4 kreg, vreg;
+  // The prefetch must stay in flight across the MFMA block; hipcc sinks plain
+  // loads to their first use, so the two loads are issued by inline asm and
+  // retired by an explicit s_waitcnt (nothing else is on the vector-memory
+  // queue inside the loop).
+  auto fetch = [&](int kt) {
+    const int r = min(kt + sr, klen - 1);          // clamp: always a valid row
+    const size_t row = (size_t)(kbeg + r);
+    const float* kp_ = k + row * k_stride + hoff + sc4;
+    const float* vp_ = v + row * v_stride + hoff + sc4;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(kreg) : "v"(kp_));
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vreg) : "v"(vp_));
+  };
+  auto stash = [&](int kt, int buf) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const bool in = kt + sr < klen;                // rows past the segment read as zero
+    float* kd = Ks[buf] + sr * KS + sc4;
+    kd[0] = in ? kreg[0] : 0.f;
+    kd[1] = in ? kreg[1] : 0.f;
+    kd[2] = in ? kreg[2] : 0.f;
+    kd[3] = in ? kreg[3] : 0.f;
+    f32x4 vz = {in ? vreg[0] : 0.f, in ? vreg[1] : 0.f, in ? vreg[2] : 0.f, in ? vreg[3] : 0.f};
+    *reinterpret_cast<f32x4*>(Vs[buf] + sr * HD + sc4) = vz;
+  };
+
+  if (klen > 0) {
+    fetch(0);
+    stash(0, 0);
+  }
+  __syncthreads();
+
+  int buf = 0;
+  for (int kt = 0; kt < klen; kt += KT, buf ^= 1) {
+    const bool more = kt + KT < klen;
+    if (more) fetch(kt + KT);
+    __builtin_amdgcn_sched_barrier(0);
 
     // S^T tile: rows = keys, cols = queries.  A[row = key l31][k = d = 2s+lh]
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
-    const float* kp = Ks + l31 * KS + lh;
+    // all 16 A fragments are read from LDS up front (one exposed LDS latency
+    // per tile instead of one per MFMA pair); V fragments are fetched before
+    // the softmax so their latency hides under the VALU work.
+    const float* kp = Ks[buf] + l31 * KS + lh;
+    const float* vp = Vs[buf] + l31;
+    float ka[16], va[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) ka[s] = kp[2 * s];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 16; ++s)
-      st = __builtin_amdgcn_mfma_f32_32x32x2f32(kp[2 * s], qreg[s], st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s], qreg[s], st, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) va[r] = vp[((r & 3) + 8 * (r >> 2) + 4 * lh) * HD];
+    __builtin_amdgcn_sched_barrier(0);
 
     // lane holds, for its query, the 16 keys  j(r) = (r&3) + 8*(r>>2) + 4*lh
     float mx = -INFINITY;
@@ -103,11 +137,11 @@ __global__ __launch_bounds__(256) void k_attn(
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // other half-lane: other 16 keys
     const float m_new = fmaxf(m_run, mx);    // finite: every tile has >= 1 key
-    const float corr = expf(m_run - m_new);
+    const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      st[r] = expf(st[r] - m_new);
+      st[r] = __builtin_amdgcn_exp2f(st[r] - m_new);
       psum += st[r];
     }
     psum += __shfl_xor(psum, 32, 64);
@@ -120,10 +154,11 @@ __global__ __launch_bounds__(256) void k_attn(
     // j0(r) = (r&3) + 8*(r>>2); B operand = st[r] (already in place),
     // A[row = d = l31][k = h] = V[j0(r) + 4h][d].
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      o = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[j * HD + l31], st[r], o, 0, 0, 0);
-    }
+    for (int r = 0; r < 16; ++r)
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(va[r], st[r], o, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) stash(kt + KT, buf ^ 1);
+    __syncthreads();
   }
 
   if (qok) {

@@ -42,40 +42,45 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt(
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  float4 ra[A_PT], rb[B_PT];
+  // Next K-slab prefetch: hipcc sinks plain loads to their first use (after the
+  // MFMA block), which exposes a full memory round trip per slab, so the slab is
+  // fetched with inline-asm loads and retired with an explicit s_waitcnt; no
+  // other vector-memory operation is in flight inside the K loop.
+  f32x4 ra[A_PT], rb[B_PT];
   auto load_slab = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
       const int f = tid + i * NT;
-      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < A_F4) {
+      if (f < A_F4) {   // compile-time true except for partial last pass
         const int r = f / (BK / 4), c4 = f % (BK / 4);
-        if (m0 + r < M)
-          ra[i] = *reinterpret_cast<const float4*>(X + (size_t)(m0 + r) * K + k0 + c4 * 4);
+        const float* p = X + (size_t)min(m0 + r, M - 1) * K + k0 + c4 * 4;   // clamped row
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[i]) : "v"(p));
       }
     }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
       const int f = tid + i * NT;
-      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (f < B_F4) {
         const int r = f / (BK / 4), c4 = f % (BK / 4);
-        if (n0 + r < N)
-          rb[i] = *reinterpret_cast<const float4*>(Wt + (size_t)(n0 + r) * K + k0 + c4 * 4);
+        const float* p = Wt + (size_t)min(n0 + r, N - 1) * K + k0 + c4 * 4;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[i]) : "v"(p));
       }
     }
   };
   auto store_slab = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
       const int f = tid + i * NT;
       if (f < A_F4) {
         const int r = f / (BK / 4), c4 = f % (BK / 4);
+        const bool in = m0 + r < M;                     // rows past M contribute zeros
         float* d = As + r * LDSK + c4 * 4;
-        d[0] = ra[i].x;
-        d[1] = ra[i].y;
-        d[2] = ra[i].z;
-        d[3] = ra[i].w;
+        d[0] = in ? ra[i][0] : 0.f;
+        d[1] = in ? ra[i][1] : 0.f;
+        d[2] = in ? ra[i][2] : 0.f;
+        d[3] = in ? ra[i][3] : 0.f;
       }
     }
 #pragma unroll
@@ -83,11 +88,12 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt(
       const int f = tid + i * NT;
       if (f < B_F4) {
         const int r = f / (BK / 4), c4 = f % (BK / 4);
+        const bool in = n0 + r < N;
         float* d = Bs + r * LDSK + c4 * 4;
-        d[0] = rb[i].x;
-        d[1] = rb[i].y;
-        d[2] = rb[i].z;
-        d[3] = rb[i].w;
+        d[0] = in ? rb[i][0] : 0.f;
+        d[1] = in ? rb[i][1] : 0.f;
+        d[2] = in ? rb[i][2] : 0.f;
+        d[3] = in ? rb[i][3] : 0.f;
       }
     }
   };
@@ -97,15 +103,24 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt(
     store_slab();
     __syncthreads();
     if (k0 + BK < K) load_slab(k0 + BK);
+    __builtin_amdgcn_sched_barrier(0);
     const float* ap = As + (wm * 32 + l31) * LDSK + lh;
     const float* bp = Bs + (wn * 32 + l31) * LDSK + lh;
+    // all fragments of the slab first (one exposed LDS latency), then 16 MFMAs
+    float fa[BK / 2], fb[BK / 2];
 #pragma unroll
     for (int s = 0; s < BK / 2; ++s) {
-      // A[i = l&31][k = 2s + (l>>5)],  B[k][j = l&31]
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s], bp[2 * s], acc, 0, 0, 0);
+      fa[s] = ap[2 * s];   // A[i = l&31][k = 2s + (l>>5)]
+      fb[s] = bp[2 * s];   // B[k][j = l&31]
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // C/D: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int col = n0 + wn * 32 + l31;
   if (col < N) {

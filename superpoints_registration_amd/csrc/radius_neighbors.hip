@@ -334,7 +334,14 @@ __global__ __launch_bounds__(BLOCK) void k_query_table(
       rb[k] = start[L0];
       re[k] = in ? start[L1] : rb[k];
     }
+    // K-nearest selection without a sorted insert (whose dependent LDS
+    // read-compare-write chain costs ~limit LDS latencies per candidate):
+    // append while there is room; once full, replace the current worst entry
+    // and rescan for the new worst (independent reads, pipelined).  Rows are
+    // ordered at the end by ranking.
     int kept = 0;
+    float w_d2 = -1.f;   // current worst (largest (d2, index)) when full
+    int w_id = -1, w_pos = 0;
     auto consider = [&](const float4 s) {
       // nanoflann.hpp:432-440: diff = query - support; result += diff*diff
       const float dx = __fsub_rn(qx, s.x), dy = __fsub_rn(qy, s.y), dz = __fsub_rn(qz, s.z);
@@ -344,22 +351,31 @@ __global__ __launch_bounds__(BLOCK) void k_query_table(
       if (!(d2 < r2)) return;  // strict, nanoflann.hpp:249
       total++;
       const int sid = __float_as_int(s.w);
-      int pos;
       if (kept < limit) {
-        pos = kept++;
-      } else {
-        const int last = limit - 1;
-        if (!nbr_less(d2, sid, l_d2[last * BLOCK + t], l_id[last * BLOCK + t])) return;
-        pos = last;
+        l_d2[kept * BLOCK + t] = d2;
+        l_id[kept * BLOCK + t] = sid;
+        if (kept == 0 || nbr_less(w_d2, w_id, d2, sid)) {
+          w_d2 = d2;
+          w_id = sid;
+          w_pos = kept;
+        }
+        ++kept;
+        return;
       }
-      while (pos > 0 &&
-             nbr_less(d2, sid, l_d2[(pos - 1) * BLOCK + t], l_id[(pos - 1) * BLOCK + t])) {
-        l_d2[pos * BLOCK + t] = l_d2[(pos - 1) * BLOCK + t];
-        l_id[pos * BLOCK + t] = l_id[(pos - 1) * BLOCK + t];
-        --pos;
+      if (!nbr_less(d2, sid, w_d2, w_id)) return;
+      l_d2[w_pos * BLOCK + t] = d2;
+      l_id[w_pos * BLOCK + t] = sid;
+      w_d2 = d2;
+      w_id = sid;
+      for (int k = 0; k < limit; ++k) {
+        const float dk = l_d2[k * BLOCK + t];
+        const int ik = l_id[k * BLOCK + t];
+        if (nbr_less(w_d2, w_id, dk, ik)) {
+          w_d2 = dk;
+          w_id = ik;
+          w_pos = k;
+        }
       }
-      l_d2[pos * BLOCK + t] = d2;
-      l_id[pos * BLOCK + t] = sid;
     };
 #pragma unroll 1
     for (int k = 0; k < 9; ++k) {
@@ -374,8 +390,17 @@ __global__ __launch_bounds__(BLOCK) void k_query_table(
       }
       for (; j < e; ++j) consider(rec[j]);
     }
+    // rank sort: position of entry a = #{b : b < a} under the (d2, index) order
     int* row = out + (size_t)i * limit;
-    for (int k = 0; k < limit; ++k) row[k] = (k < kept) ? l_id[k * BLOCK + t] : ns;
+    for (int a = 0; a < kept; ++a) {
+      const float da = l_d2[a * BLOCK + t];
+      const int ia = l_id[a * BLOCK + t];
+      int rank = 0;
+      for (int b = 0; b < kept; ++b)
+        rank += nbr_less(l_d2[b * BLOCK + t], l_id[b * BLOCK + t], da, ia) ? 1 : 0;
+      row[rank] = ia;
+    }
+    for (int k = kept; k < limit; ++k) row[k] = ns;
   }
   int m = total;
 #pragma unroll
