@@ -108,9 +108,8 @@ def cpu_baseline(cfg, model_sd, n_points):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from superpoints_registration_amd import sharding
+    rank, local_rank, world = sharding.rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     torch.cuda.set_device(local_rank)
@@ -131,7 +130,7 @@ def main():
     model = model.to(dev).eval()
 
     B = args.pairs_per_step
-    pairs = [synthetic.make_pair(args.points, seed=1000 * rank + i) for i in range(B)]
+    pairs = [synthetic.make_pair(args.points, seed=sd) for sd in sharding.pair_seeds(rank, B)]
     batch = {"src_xyz": [torch.from_numpy(p[0]).to(dev) for p in pairs],
              "tgt_xyz": [torch.from_numpy(p[1]).to(dev) for p in pairs]}
 
@@ -143,22 +142,9 @@ def main():
     torch.cuda.synchronize()
     L = _lib.lib()
 
-    # ---- timed region --------------------------------------------------------
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
+    # ---- timed region: barrier + sync, K steps, sync + barrier, MAX over ranks ----
     L.spr_prof_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.timed_steps(step, args.steps, dist=dist, sync=torch.cuda.synchronize, device=dev)
 
     # ---- roofline of the dominant kernel (rank 0) -----------------------------
     roofline = None
@@ -217,10 +203,9 @@ def main():
             dist.destroy_process_group()
         return
 
-    total_pairs = B * args.steps * world
     result = {
         "metric": "point-cloud pairs/sec (16 384 pts/cloud)",
-        "value": round(total_pairs / elapsed, 3),
+        "value": round(sharding.throughput(B, args.steps, world, elapsed), 3),
         "unit": "pairs/s",
         "n_gpus": world,
         "steps": args.steps,
