@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs-per-step", type=int, default=4)
+    ap.add_argument("--pairs-per-step", type=int, default=16)
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--config", default="3dmatch")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -132,6 +132,11 @@ int spr_maxpool_gather(const float* x, int ns, int c, const int* idx, int nq,
 int spr_linear(const float* x, int m, int k, const float* w, int n,
                const float* bias, const float* residual, int act, float* out,
                void* stream);
+/* Arithmetic of spr_linear (and of the correlation GEMMs inside the matching
+ * head): 1 (default) = split-fp16 MFMA, x = hi + 2^-11 lo with fp32
+ * accumulation -- fp32-level accuracy (~2^-22 relative per product) at ~5x the
+ * exact-f32 MFMA rate, needs |x| < 65504;  0 = exact f32 MFMA. */
+int spr_set_gemm_mode(int mode);
 
 /* ---- LayerNorm (+ positional embedding add) --------------------------------
  * Replaces norm1/2/3 + with_pos_embed (transformers.py:121,:196-197,:212-214,
@@ -165,6 +170,11 @@ int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k,
                         const int* cu, const int* kv_seg, int nseg,
                         int max_len_host, int nhead, int head_dim, float scale,
                         float* out, int o_stride, void* stream);
+
+/* Arithmetic of the attention core: 1 (default) = split-fp16 MFMA (operands
+ * carried as hi + 2^-11 lo, fp32 accumulation and softmax; fp32-level
+ * accuracy), 0 = exact f32 MFMA. */
+int spr_set_attn_mode(int mode);
 
 /* ---- a11: dual-softmax matching ---------------------------------------------
  * Replaces the correlation / dual softmax / arg-max block of

@@ -174,6 +174,208 @@ __global__ __launch_bounds__(256) void k_attn(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Split-fp16 variant ("h3"): same structure, fp32-level accuracy, ~5x less
+// matrix-core time.  Every operand x is carried as hi = fp16(x) and
+// lo = fp16((x - hi) * 2^11); a.b ~= ah.bh + 2^-11 (ah.bl + al.bh) with fp32
+// accumulation (two accumulators per product: hi.hi and the cross terms).
+//   S^T = K Q^T : 2 k-steps x 3 v_mfma_f32_32x32x16_f16  (head_dim 32)
+//   O^T = V^T P^T: the f32 probabilities in the S^T accumulator are converted
+//     in place -- registers 8s..8s+7 of a lane are exactly the B fragment of
+//     k-step s, with key order kappa(s,h,j) = 16s + 8(j>>2) + 4h + (j&3); the
+//     V^T A-fragment is read with the same order from a TRANSPOSED fp16 V tile
+//     (two 8-byte reads).  P is scaled by 2^10 before the split so that small
+//     probabilities stay in fp16's normal range (undone in the final 1/l).
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+constexpr int KH = 40;   // K tile row stride in halves (80 B: conflict-free ds_read_b128)
+constexpr int VH = 36;   // V^T tile row stride in halves (72 B: conflict-free ds_read_b64)
+constexpr float kLo = 2048.0f, kPScale = 1024.0f;
+
+__device__ __forceinline__ void split_h(float x, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)x;
+  lo = (_Float16)((x - (float)hi) * kLo);
+}
+
+__global__ __launch_bounds__(256) void k_attn_h3(
+    const float* __restrict__ q, int q_stride, const float* __restrict__ k, int k_stride,
+    const float* __restrict__ v, int v_stride, const int* __restrict__ cu,
+    const int* __restrict__ kv_seg, int nhead, float scale, float* __restrict__ out,
+    int o_stride) {
+  __shared__ __align__(16) _Float16 Kh[2][KT * KH], Kl[2][KT * KH];
+  __shared__ __align__(16) _Float16 Vth[2][HD * VH], Vtl[2][HD * VH];
+  const int seg = blockIdx.z, head = blockIdx.y;
+  const int qbeg = cu[seg], qlen = cu[seg + 1] - qbeg;
+  const int q0 = blockIdx.x * QB;
+  if (q0 >= qlen) return;
+  const int ks = kv_seg[seg];
+  const int kbeg = cu[ks], klen = cu[ks + 1] - kbeg;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int qi = q0 + wave * QW + l31;
+  const bool qok = qi < qlen;
+  const int hoff = head * HD;
+
+  // Q^T B-fragments: lane (query l31, half lh), k-step s: d = 16 s + 8 lh + j
+  h16x8 qh[2], ql[2];
+  {
+    const float sc = scale * 1.4426950408889634f;   // base-2 softmax
+    const float* qp = q + (size_t)(qbeg + (qok ? qi : 0)) * q_stride + hoff + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = qok ? qp[16 * s + j] * sc : 0.f;
+        _Float16 a, b;
+        split_h(x, a, b);
+        qh[s][j] = a;
+        ql[s][j] = b;
+      }
+  }
+
+  f32x16 o_hh, o_x;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    o_hh[r] = 0.f;
+    o_x[r] = 0.f;
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int sr = tid >> 3, sc4 = (tid & 7) * 4;   // staging role: key row, 4 dims
+  f32x4 kreg, vreg;
+  auto fetch = [&](int kt) {
+    const int r = min(kt + sr, klen - 1);
+    const size_t row = (size_t)(kbeg + r);
+    const float* kp_ = k + row * k_stride + hoff + sc4;
+    const float* vp_ = v + row * v_stride + hoff + sc4;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(kreg) : "v"(kp_));
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vreg) : "v"(vp_));
+  };
+  auto stash = [&](int kt, int buf) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const bool in = kt + sr < klen;
+    h16x4 kh4, kl4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      _Float16 a, b;
+      split_h(in ? kreg[e] : 0.f, a, b);
+      kh4[e] = a;
+      kl4[e] = b;
+      split_h(in ? vreg[e] : 0.f, a, b);
+      Vth[buf][(sc4 + e) * VH + sr] = a;     // transposed: [d][key]
+      Vtl[buf][(sc4 + e) * VH + sr] = b;
+    }
+    *reinterpret_cast<h16x4*>(Kh[buf] + sr * KH + sc4) = kh4;
+    *reinterpret_cast<h16x4*>(Kl[buf] + sr * KH + sc4) = kl4;
+  };
+
+  if (klen > 0) {
+    fetch(0);
+    stash(0, 0);
+  }
+  __syncthreads();
+
+  int buf = 0;
+  for (int kt = 0; kt < klen; kt += KT, buf ^= 1) {
+    const bool more = kt + KT < klen;
+    if (more) fetch(kt + KT);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- S^T = K Q^T (rows = keys, cols = queries) ----
+    f32x16 s_hh, s_x;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s_hh[r] = 0.f;
+      s_x[r] = 0.f;
+    }
+    h16x8 kfh[2], kfl[2], vfh[2], vfl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      kfh[s] = *reinterpret_cast<const h16x8*>(Kh[buf] + l31 * KH + 16 * s + 8 * lh);
+      kfl[s] = *reinterpret_cast<const h16x8*>(Kl[buf] + l31 * KH + 16 * s + 8 * lh);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      s_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], qh[s], s_hh, 0, 0, 0);
+      s_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], ql[s], s_x, 0, 0, 0);
+      s_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[s], qh[s], s_x, 0, 0, 0);
+    }
+    // V^T A-fragments (issued early: their LDS latency hides under the softmax)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const _Float16* ph_ = Vth[buf] + l31 * VH + 16 * s + 4 * lh;
+      const _Float16* pl_ = Vtl[buf] + l31 * VH + 16 * s + 4 * lh;
+      const h16x4 a0 = *reinterpret_cast<const h16x4*>(ph_);
+      const h16x4 a1 = *reinterpret_cast<const h16x4*>(ph_ + 8);
+      const h16x4 b0 = *reinterpret_cast<const h16x4*>(pl_);
+      const h16x4 b1 = *reinterpret_cast<const h16x4*>(pl_ + 8);
+      vfh[s] = (h16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      vfl[s] = (h16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    }
+
+    // ---- online softmax (lane = query; reg r <-> key (r&3) + 8 (r>>2) + 4 lh) ----
+    float st[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      st[r] = (j < klen) ? s_hh[r] + s_x[r] * (1.0f / kLo) : -INFINITY;
+      mx = fmaxf(mx, st[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
+    float psum = 0.f;
+    h16x8 pbh[2], pbl[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __builtin_amdgcn_exp2f(st[r] - m_new);
+      psum += p;
+      _Float16 a, b;
+      split_h(p * kPScale, a, b);
+      pbh[r >> 3][r & 7] = a;       // registers 8s..8s+7 = B fragment of k-step s
+      pbl[r >> 3][r & 7] = b;
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o_hh[r] *= corr;
+      o_x[r] *= corr;
+    }
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      o_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbh[s], o_hh, 0, 0, 0);
+      o_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbl[s], o_x, 0, 0, 0);
+      o_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[s], pbh[s], o_x, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) stash(kt + KT, buf ^ 1);
+    __syncthreads();
+  }
+
+  if (qok) {
+    const float inv = l_run > 0.f ? (1.0f / kPScale) / l_run : 0.f;
+    float* op = out + (size_t)(qbeg + qi) * o_stride + hoff;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 w4;
+      w4.x = (o_hh[4 * g + 0] + o_x[4 * g + 0] * (1.0f / kLo)) * inv;
+      w4.y = (o_hh[4 * g + 1] + o_x[4 * g + 1] * (1.0f / kLo)) * inv;
+      w4.z = (o_hh[4 * g + 2] + o_x[4 * g + 2] * (1.0f / kLo)) * inv;
+      w4.w = (o_hh[4 * g + 3] + o_x[4 * g + 3] * (1.0f / kLo)) * inv;
+      *reinterpret_cast<float4*>(op + 8 * g + 4 * lh) = w4;
+    }
+  }
+}
+
+static int g_attn_mode = 1;   // 1 = split-fp16 (default), 0 = exact f32 MFMA
+
 }  // namespace
 }  // namespace spr
 
@@ -191,8 +393,18 @@ extern "C" int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k,
               "attention: row strides must be multiples of 4 floats");
   SPR_REQUIRE(nseg <= 65535 && nhead <= 65535, "attention: grid too large");
   dim3 grid(cdiv(max_len_host, QB), nhead, nseg);
-  hipLaunchKernelGGL(k_attn, grid, dim3(256), 0, stream, q, q_stride, k, k_stride, v, v_stride, cu,
-                     kv_seg, nhead, scale, out, o_stride);
+  if (spr::g_attn_mode == 1)
+    hipLaunchKernelGGL(k_attn_h3, grid, dim3(256), 0, stream, q, q_stride, k, k_stride, v, v_stride, cu,
+                       kv_seg, nhead, scale, out, o_stride);
+  else
+    hipLaunchKernelGGL(k_attn, grid, dim3(256), 0, stream, q, q_stride, k, k_stride, v, v_stride, cu,
+                       kv_seg, nhead, scale, out, o_stride);
   SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_set_attn_mode(int mode) {
+  SPR_REQUIRE(mode == 0 || mode == 1, "attention mode must be 0 (exact f32 MFMA) or 1 (split-fp16)");
+  spr::g_attn_mode = mode;
   return 0;
 }

@@ -22,11 +22,39 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDSK = BK + 1;
 
+// Epilogue of one 32x32 accumulator tile (C/D layout, dtype independent:
+// col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)).  ACT / RES are
+// compile-time so the 16 residual loads are issued back to back (one exposed
+// round trip per tile, not one per element) and no per-element branch remains.
+template <int ACT, bool RES>
+__device__ __forceinline__ void store_tile(const f32x16& acc, int row0, int col, int M, int N,
+                                           float bv, const float* __restrict__ residual,
+                                           float* __restrict__ out, int lh) {
+  if (col >= N) return;
+  float res[16];
+  if (RES) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = min(row0 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1);
+      res[r] = residual[(size_t)row * N + col];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    float v = acc[r] + bv;
+    if (RES) v += res[r];
+    if (ACT == SPR_ACT_RELU) v = fmaxf(v, 0.f);
+    if (ACT == SPR_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+    if (row < M) out[(size_t)row * N + col] = v;
+  }
+}
+
 // WM x WN waves, each a 32x32 tile.  256 threads when WM*WN == 4.
-template <int WM, int WN>
+template <int WM, int WN, int ACT, bool RES>
 __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt(
     const float* __restrict__ X, int M, int K, const float* __restrict__ Wt, int N,
-    const float* __restrict__ bias, const float* __restrict__ residual, int act,
+    const float* __restrict__ bias, const float* __restrict__ residual,
     float* __restrict__ out) {
   constexpr int BM = WM * 32, BN = WN * 32, NT = WM * WN * 64;
   constexpr int A_F4 = BM * BK / 4, B_F4 = BN * BK / 4;  // float4 per slab
@@ -121,23 +149,153 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt(
     __syncthreads();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  // C/D: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int col = n0 + wn * 32 + l31;
-  if (col < N) {
-    const float bv = bias ? bias[col] : 0.f;
+  const float bv = (bias && col < N) ? bias[col] : 0.f;
+  store_tile<ACT, RES>(acc, m0 + wm * 32, col, M, N, bv, residual, out, lh);
+}
+
+// ---------------------------------------------------------------------------
+// Split-fp16 GEMM ("h3"): fp32 accuracy at ~5x the exact-f32 MFMA rate.
+//   x = hi + lo * 2^-11,  hi = fp16(x),  lo = fp16((x - hi) * 2^11)
+//   a.b ~= ah.bh + 2^-11 (ah.bl + al.bh)          (al.bl ~ 2^-22 |a.b| dropped)
+// hi and lo together carry 22 significand bits, so the operand representation
+// error is ~2^-23 relative -- the same order as one fp32 rounding; products
+// are exact in the MFMA and accumulate in fp32.  Three v_mfma_f32_32x32x16_f16
+// per 16-deep k-step (32 cycles each) replace eight v_mfma_f32_32x32x2_f32
+// (64 cycles each).  Operands are split on the fly while a K-slab is staged
+// into LDS (fp16 rows of 32+8 halves: 80-byte stride -> conflict-free
+// ds_read_b128 fragment reads).  Requires |x| < 65504 (activations here are
+// normalised, O(10)); spr_set_gemm_mode(0) selects the exact-f32 kernel.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HS = 40;                 // LDS row stride in halves (BK = 32 + 8 pad)
+constexpr float kLoScale = 2048.0f;    // 2^11
+
+template <int BM, int BN, int WM, int WN, int ACT, bool RES>
+__global__ __launch_bounds__(256) void k_gemm_nt_h3(
+    const float* __restrict__ X, int M, int K, const float* __restrict__ Wt, int N,
+    const float* __restrict__ bias, const float* __restrict__ residual,
+    float* __restrict__ out) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);   // 32x32 sub-tiles per wave
+  constexpr int A_F4 = BM * BK / 4, B_F4 = BN * BK / 4;
+  constexpr int A_PT = A_F4 / 256, B_PT = B_F4 / 256;
+  static_assert(A_F4 % 256 == 0 && B_F4 % 256 == 0, "slab must divide over 256 threads");
+  __shared__ __align__(16) _Float16 Ah[BM * HS], Al[BM * HS], Bh[BN * HS], Bl[BN * HS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc_hh[TM][TN], acc_x[TM][TN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (row < M) {
-        float v = acc[r] + bv;
-        if (residual) v += residual[(size_t)row * N + col];
-        if (act == SPR_ACT_RELU) v = fmaxf(v, 0.f);
-        if (act == SPR_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-        out[(size_t)row * N + col] = v;
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc_hh[i][j][r] = 0.f;
+        acc_x[i][j][r] = 0.f;
       }
+
+  f32x4 ra[A_PT], rb[B_PT];
+  auto load_slab = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) {
+      const int f = tid + i * 256;
+      const int r = f / (BK / 4), c4 = f % (BK / 4);
+      const float* p = X + (size_t)min(m0 + r, M - 1) * K + k0 + c4 * 4;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[i]) : "v"(p));
+    }
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) {
+      const int f = tid + i * 256;
+      const int r = f / (BK / 4), c4 = f % (BK / 4);
+      const float* p = Wt + (size_t)min(n0 + r, N - 1) * K + k0 + c4 * 4;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[i]) : "v"(p));
+    }
+  };
+  auto split_store = [&](const f32x4& v, bool in, _Float16* hi, _Float16* lo) {
+    f16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = in ? v[e] : 0.f;
+      const _Float16 xh = (_Float16)x;
+      h[e] = xh;
+      l[e] = (_Float16)((x - (float)xh) * kLoScale);
+    }
+    *reinterpret_cast<f16x4*>(hi) = h;
+    *reinterpret_cast<f16x4*>(lo) = l;
+  };
+  auto store_slab = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) {
+      const int f = tid + i * 256;
+      const int r = f / (BK / 4), c4 = f % (BK / 4);
+      split_store(ra[i], m0 + r < M, Ah + r * HS + c4 * 4, Al + r * HS + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) {
+      const int f = tid + i * 256;
+      const int r = f / (BK / 4), c4 = f % (BK / 4);
+      split_store(rb[i], n0 + r < N, Bh + r * HS + c4 * 4, Bl + r * HS + c4 * 4);
+    }
+  };
+
+  load_slab(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    store_slab();
+    __syncthreads();
+    if (k0 + BK < K) load_slab(k0 + BK);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      // lane: row (l&31) of its sub-tile, k = 16 s + 8 (l>>5) + 0..7
+      const int ko = 16 * s + 8 * lh;
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + l31;
+        ah[i] = *reinterpret_cast<const f16x8*>(Ah + row * HS + ko);
+        al[i] = *reinterpret_cast<const f16x8*>(Al + row * HS + ko);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = (wn * TN + j) * 32 + l31;
+        bh[j] = *reinterpret_cast<const f16x8*>(Bh + row * HS + ko);
+        bl[j] = *reinterpret_cast<const f16x8*>(Bl + row * HS + ko);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc_hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc_hh[i][j], 0, 0, 0);
+          acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
+          acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + l31;
+    const float bv = (bias && col < N) ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      f32x16 c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[r] = acc_hh[i][j][r] + acc_x[i][j][r] * (1.0f / kLoScale);
+      store_tile<ACT, RES>(c, m0 + (wm * TM + i) * 32, col, M, N, bv, residual, out, lh);
     }
   }
 }
+
+static int g_gemm_mode = 1;   // 1 = split-fp16 (default), 0 = exact f32 MFMA
 
 // N small (overlap_predictor, N = 1): one wave per (row, n).
 __global__ void k_gemv_rows(const float* __restrict__ X, int M, int K, const float* __restrict__ Wt,
@@ -218,10 +376,38 @@ __global__ void k_posemb(const float* __restrict__ xyz, int n, int d_model, int 
 
 using namespace spr;
 
+namespace {
+template <int ACT, bool RES>
+int launch_gemm(const float* x, int m, int k, const float* w, int n, const float* bias,
+                const float* residual, float* out, hipStream_t stream) {
+  if (spr::g_gemm_mode == 1) {
+    if (n % 128 == 0 && m >= 512) {
+      hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 128, 2, 2, ACT, RES>), dim3(n / 128, cdiv(m, 128)),
+                         dim3(256), 0, stream, x, m, k, w, n, bias, residual, out);
+    } else if (n > 32) {
+      hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 64, 4, 1, ACT, RES>), dim3(cdiv(n, 64), cdiv(m, 128)),
+                         dim3(256), 0, stream, x, m, k, w, n, bias, residual, out);
+    } else {
+      hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 32, 4, 1, ACT, RES>), dim3(cdiv(n, 32), cdiv(m, 128)),
+                         dim3(256), 0, stream, x, m, k, w, n, bias, residual, out);
+    }
+  } else if (n % 64 == 0) {
+    hipLaunchKernelGGL((spr::k_gemm_nt<2, 2, ACT, RES>), dim3(n / 64, cdiv(m, 64)), dim3(256), 0, stream,
+                       x, m, k, w, n, bias, residual, out);
+  } else {
+    hipLaunchKernelGGL((spr::k_gemm_nt<4, 1, ACT, RES>), dim3(cdiv(n, 32), cdiv(m, 128)), dim3(256), 0,
+                       stream, x, m, k, w, n, bias, residual, out);
+  }
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
+
 extern "C" int spr_linear(const float* x, int m, int k, const float* w, int n, const float* bias,
                           const float* residual, int act, float* out, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(m > 0 && k > 0 && n > 0, "linear: bad sizes m=%d k=%d n=%d", m, k, n);
+  SPR_REQUIRE(act >= 0 && act <= 2, "linear: unknown activation %d", act);
   if (n < 16 || k % BK != 0) {
     SPR_REQUIRE(n <= 64 || k % BK == 0, "linear: k must be a multiple of %d for n > 64 (k=%d n=%d)", BK, k, n);
     const long waves = (long)m * n;
@@ -230,14 +416,20 @@ extern "C" int spr_linear(const float* x, int m, int k, const float* w, int n, c
     SPR_LAUNCH_CHECK();
     return 0;
   }
-  if (n % 64 == 0) {
-    hipLaunchKernelGGL((k_gemm_nt<2, 2>), dim3(n / 64, cdiv(m, 64)), dim3(256), 0, stream, x, m, k,
-                       w, n, bias, residual, act, out);
-  } else {
-    hipLaunchKernelGGL((k_gemm_nt<4, 1>), dim3(cdiv(n, 32), cdiv(m, 128)), dim3(256), 0, stream, x,
-                       m, k, w, n, bias, residual, act, out);
+  const bool res = residual != nullptr;
+  switch (act * 2 + (res ? 1 : 0)) {
+    case 0: return launch_gemm<SPR_ACT_NONE, false>(x, m, k, w, n, bias, residual, out, stream);
+    case 1: return launch_gemm<SPR_ACT_NONE, true>(x, m, k, w, n, bias, residual, out, stream);
+    case 2: return launch_gemm<SPR_ACT_RELU, false>(x, m, k, w, n, bias, residual, out, stream);
+    case 3: return launch_gemm<SPR_ACT_RELU, true>(x, m, k, w, n, bias, residual, out, stream);
+    case 4: return launch_gemm<SPR_ACT_SIGMOID, false>(x, m, k, w, n, bias, residual, out, stream);
+    default: return launch_gemm<SPR_ACT_SIGMOID, true>(x, m, k, w, n, bias, residual, out, stream);
   }
-  SPR_LAUNCH_CHECK();
+}
+
+extern "C" int spr_set_gemm_mode(int mode) {
+  SPR_REQUIRE(mode == 0 || mode == 1, "gemm mode must be 0 (exact f32 MFMA) or 1 (split-fp16)");
+  spr::g_gemm_mode = mode;
   return 0;
 }
 

@@ -311,6 +311,8 @@ __global__ __launch_bounds__(BLOCK) void k_query_table(
   extern __shared__ __align__(16) unsigned char smem[];
   float* l_d2 = (float*)smem;
   int* l_id = (int*)(smem + sizeof(float) * (size_t)limit * BLOCK);
+  int* l_rb = l_id + (size_t)limit * BLOCK;   // [9][BLOCK] record-run begins
+  int* l_re = l_rb + 9 * BLOCK;               // [9][BLOCK] record-run ends
   const int t = threadIdx.x;
   const int i = blockIdx.x * BLOCK + t;
   if (*err) return;
@@ -324,15 +326,15 @@ __global__ __launch_bounds__(BLOCK) void k_query_table(
     const int cy = cell_coord(qy, g.mn[1], inv_cell);
     const int cz = cell_coord(qz, g.mn[2], inv_cell);
     const int xlo = max(cx - 1, 0), xhi = min(cx + 1, g.dim[0] - 1);
-    int rb[9], re[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const int z = cz + k / 3 - 1, y = cy + k % 3 - 1;
       const bool in = xlo <= xhi && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
       const long long L0 = in ? grid_cell(g, xlo, y, z) : 0;
       const long long L1 = in ? grid_cell(g, xhi, y, z) + 1 : 0;
-      rb[k] = start[L0];
-      re[k] = in ? start[L1] : rb[k];
+      const int b = start[L0];
+      l_rb[k * BLOCK + t] = b;
+      l_re[k * BLOCK + t] = in ? start[L1] : b;
     }
     // K-nearest selection without a sorted insert (whose dependent LDS
     // read-compare-write chain costs ~limit LDS latencies per candidate):
@@ -377,18 +379,31 @@ __global__ __launch_bounds__(BLOCK) void k_query_table(
         }
       }
     };
-#pragma unroll 1
-    for (int k = 0; k < 9; ++k) {
-      int j = rb[k];
-      const int e = re[k];
-      for (; j + 3 < e; j += 4) {
-        const float4 s0 = rec[j], s1 = rec[j + 1], s2 = rec[j + 2], s3 = rec[j + 3];
-        consider(s0);
-        consider(s1);
-        consider(s2);
-        consider(s3);
+    // Stream the 9 record runs as ONE candidate sequence, 8 records in flight:
+    // the cursor (run k, position j) advances across run boundaries while the
+    // addresses are generated, so short runs do not cost a round trip each.
+    {
+      int k = 0, j = l_rb[t], e = l_re[t];
+      while (k < 9) {
+        float4 s8[8];
+        bool v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          while (k < 9 && j >= e) {
+            ++k;
+            if (k < 9) {
+              j = l_rb[k * BLOCK + t];
+              e = l_re[k * BLOCK + t];
+            }
+          }
+          v8[u] = k < 9;
+          s8[u] = rec[v8[u] ? j : 0];
+          j += v8[u] ? 1 : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (v8[u]) consider(s8[u]);
       }
-      for (; j < e; ++j) consider(rec[j]);
     }
     // rank sort: position of entry a = #{b : b < a} under the (d2, index) order
     int* row = out + (size_t)i * limit;
@@ -465,7 +480,7 @@ extern "C" int spr_radius_neighbors(const float* q_xyz, const int* q_cu, int nq,
   SPR_REQUIRE(nq > 0 && ns > 0 && nb >= 1, "radius_neighbors: empty input (nq=%d ns=%d)", nq, ns);
   SPR_REQUIRE(nb < 65536, "radius_neighbors: at most 65535 clouds per call");
   SPR_REQUIRE(radius > 0.f, "radius_neighbors: radius must be > 0");
-  SPR_REQUIRE(limit >= 1 && limit <= 128, "radius_neighbors: limit must be in [1,128], got %d", limit);
+  SPR_REQUIRE(limit >= 1 && limit <= 119, "radius_neighbors: limit must be in [1,119], got %d", limit);
   SPR_REQUIRE(ws_bytes >= spr_radius_neighbors_workspace_bytes(nq, ns, nb),
               "radius_neighbors: workspace too small");
   Workspace w(ws, ws_bytes);
@@ -510,16 +525,16 @@ extern "C" int spr_radius_neighbors(const float* q_xyz, const int* q_cu, int nq,
                                           stream));
     hipLaunchKernelGGL(k_cell_scatter, dim3(cdiv(ns, TB)), dim3(TB), 0, stream, s_xyz, ns, err, cell_of,
                        start, cursor, rec);
-    if (limit <= 64) {
+    if ((size_t)(limit * 8 + 72) * 128 <= 65536) {
       constexpr int BLOCK = 128;
       hipLaunchKernelGGL(k_query_table<BLOCK>, dim3(cdiv(nq, BLOCK)), dim3(BLOCK),
-                         (size_t)limit * BLOCK * 8, stream, q_xyz, q_cu, nq, ns, nb, ginfo, start, rec,
-                         err, r2, inv_cell, limit, out_idx, max_count);
+                         (size_t)(limit * 8 + 72) * BLOCK, stream, q_xyz, q_cu, nq, ns, nb, ginfo, start,
+                         rec, err, r2, inv_cell, limit, out_idx, max_count);
     } else {
       constexpr int BLOCK = 64;
       hipLaunchKernelGGL(k_query_table<BLOCK>, dim3(cdiv(nq, BLOCK)), dim3(BLOCK),
-                         (size_t)limit * BLOCK * 8, stream, q_xyz, q_cu, nq, ns, nb, ginfo, start, rec,
-                         err, r2, inv_cell, limit, out_idx, max_count);
+                         (size_t)(limit * 8 + 72) * BLOCK, stream, q_xyz, q_cu, nq, ns, nb, ginfo, start,
+                         rec, err, r2, inv_cell, limit, out_idx, max_count);
     }
     hipLaunchKernelGGL(k_nbr_err2, dim3(1), dim3(1), 0, stream, err, max_count);
     SPR_LAUNCH_CHECK();

@@ -203,6 +203,11 @@ def linear(x, weight, bias=None, residual=None, act: int = ACT_NONE) -> torch.Te
     return out
 
 
+def set_gemm_mode(mode: int) -> None:
+    """1 = split-fp16 MFMA (default), 0 = exact f32 MFMA."""
+    _lib.check(_lib.lib().spr_set_gemm_mode(int(mode)), "spr_set_gemm_mode")
+
+
 def layernorm(x, gamma, beta, eps: float = 1e-5, pos=None, want_norm: bool = True):
     """Returns (LN(x) or None, LN(x)+pos or None)."""
     x = _dev(x, "x", torch.float32)
@@ -246,6 +251,11 @@ def attention(q, k, v, cu, kv_seg, max_len: int, nhead: int, out=None) -> torch.
                                               nhead, hd, 1.0 / math.sqrt(hd), _ptr(out), out.stride(0),
                                               _stream(q)), "spr_attn_varlen_fwd")
     return out
+
+
+def set_attn_mode(mode: int) -> None:
+    """1 = split-fp16 MFMA (default), 0 = exact f32 MFMA."""
+    _lib.check(_lib.lib().spr_set_attn_mode(int(mode)), "spr_set_attn_mode")
 
 
 def _cu_host_arr(cu_host: Sequence[int]):

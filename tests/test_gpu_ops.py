@@ -85,15 +85,20 @@ def test_posemb(gold, inp, device):
 
 @pytest.mark.parametrize("m,k,n", [(600, 64, 32), (1000, 128, 512), (333, 512, 128), (77, 256, 768),
                                    (2500, 1024, 256), (130, 256, 1), (64, 32, 96)])
-def test_linear_exact_f32(device, m, k, n):
-    x, w = synthetic.rand((m, k), 1), synthetic.rand((n, k), 2, -0.2, 0.2)
+@pytest.mark.parametrize("mode", [1, 0])
+def test_linear_exact_f32(device, m, k, n, mode):
+    """mode 1 = split-fp16 MFMA (hi + 2^-11 lo, fp32 accumulate), mode 0 = exact
+    f32 MFMA; both must hold the same fp32-level tolerance vs float64."""
+    ops.set_gemm_mode(mode)
+    x, w = synthetic.rand((m, k), 1, -3.0, 3.0), synthetic.rand((n, k), 2, -0.2, 0.2)
     b, r = synthetic.rand((n,), 3), synthetic.rand((m, n), 4)
     ref = (x.double() @ w.double().t() + b.double() + r.double())
     for act, f in ((ops.ACT_NONE, lambda t: t), (ops.ACT_RELU, torch.relu), (ops.ACT_SIGMOID, torch.sigmoid)):
         y = ops.linear(x.to(device), w.to(device), b.to(device), r.to(device), act)
-        _close(y.cpu().numpy(), f(ref).numpy(), 2e-6, f"linear {m}x{k}x{n} act {act}")
+        _close(y.cpu().numpy(), f(ref).numpy(), 2e-6 * max(1, k // 256), f"linear {m}x{k}x{n} act {act}")
     y = ops.linear(x.to(device), w.to(device))
-    _close(y.cpu().numpy(), (x.double() @ w.double().t()).numpy(), 2e-6, "linear plain")
+    _close(y.cpu().numpy(), (x.double() @ w.double().t()).numpy(), 2e-6 * max(1, k // 256), "linear plain")
+    ops.set_gemm_mode(1)
 
 
 def test_layernorm(device):
@@ -105,7 +110,9 @@ def test_layernorm(device):
     _close(npos.cpu().numpy(), (ref + p.double()).numpy(), 2e-6, "layernorm+pos")
 
 
-def test_attention_core_vs_fp64(device):
+@pytest.mark.parametrize("mode", [1, 0])
+def test_attention_core_vs_fp64(device, mode):
+    ops.set_attn_mode(mode)
     lens = [70, 33, 129, 1]
     tot = sum(lens)
     qkv = synthetic.rand((tot, 768), 9, -2, 2)
@@ -123,7 +130,8 @@ def test_attention_core_vs_fp64(device):
             v = qkv[offs[ks]:offs[ks + 1], 512:].double().view(-1, 8, 32).transpose(0, 1)
             a = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(32), -1)
             ref[offs[s]:offs[s + 1]] = (a @ v).transpose(0, 1).reshape(-1, 256)
-        _close(o.cpu().numpy(), ref.numpy(), 3e-6, f"attention kv_seg={kv_seg}")
+        _close(o.cpu().numpy(), ref.numpy(), 3e-6, f"attention mode={mode} kv_seg={kv_seg}")
+    ops.set_attn_mode(1)
 
 
 def _layer(device, seed=21):

@@ -54,7 +54,7 @@ def test_radius_neighbors_vs_reference_golden(gold, device, case, which):
     q, s, ql, sl, rad = {"nb": (pts, pts, lens, lens, r), "pool": (sub, pts, sub_lens, lens, r),
                          "up": (pts, sub, lens, sub_lens, 2 * r)}[which]
     ref = gold[f"{case}.{which}"].astype(np.int64)
-    limit = 128
+    limit = 119
     got, mc = ops.radius_neighbors(torch.from_numpy(q).to(device), torch.from_numpy(s).to(device),
                                    _cu(ql, device), _cu(sl, device), rad, limit)
     got = got.cpu().numpy().astype(np.int64)
