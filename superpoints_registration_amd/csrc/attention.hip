@@ -33,14 +33,32 @@ constexpr int KS = HD + 1;    // K tile row stride (words)
 __global__ __launch_bounds__(256) void k_attn(
     const float* __restrict__ q, int q_stride, const float* __restrict__ k, int k_stride,
     const float* __restrict__ v, int v_stride, const int* __restrict__ cu,
-    const int* __restrict__ kv_seg, int nhead, float scale, float* __restrict__ out,
+    const int* __restrict__ kv_seg, int nseg, int nhead, float scale, float* __restrict__ out,
     int o_stride) {
   // two LDS stages: tile t+1 is written while tile t is being read; one barrier per tile
   __shared__ float Ks[2][KT * KS];
   __shared__ float Vs[2][KT * HD];
-  const int seg = blockIdx.z, head = blockIdx.y;
+  // 1-D grid: all query tiles of one (segment, head) -- which stream the same
+  // K/V -- are placed on one XCD (ids b and b+8 share an L2)
+  int seg, head, qt;
+  {
+    const int nqt = gridDim.x / (nhead * nseg);
+    const int ngrp = nhead * nseg;
+    const int b = blockIdx.x;
+    if ((ngrp & 7) == 0) {
+      const int xcd = b & 7, idx = b >> 3;
+      const int g = xcd + 8 * (idx / nqt);
+      qt = idx % nqt;
+      head = g % nhead;
+      seg = g / nhead;
+    } else {
+      qt = b % nqt;
+      head = (b / nqt) % nhead;
+      seg = b / (nqt * nhead);
+    }
+  }
   const int qbeg = cu[seg], qlen = cu[seg + 1] - qbeg;
-  const int q0 = blockIdx.x * QB;
+  const int q0 = qt * QB;
   if (q0 >= qlen) return;  // uniform for the workgroup
   const int ks = kv_seg[seg];
   const int kbeg = cu[ks], klen = cu[ks + 1] - kbeg;
@@ -200,13 +218,31 @@ __device__ __forceinline__ void split_h(float x, _Float16& hi, _Float16& lo) {
 __global__ __launch_bounds__(256) void k_attn_h3(
     const float* __restrict__ q, int q_stride, const float* __restrict__ k, int k_stride,
     const float* __restrict__ v, int v_stride, const int* __restrict__ cu,
-    const int* __restrict__ kv_seg, int nhead, float scale, float* __restrict__ out,
+    const int* __restrict__ kv_seg, int nseg, int nhead, float scale, float* __restrict__ out,
     int o_stride) {
   __shared__ __align__(16) _Float16 Kh[2][KT * KH], Kl[2][KT * KH];
   __shared__ __align__(16) _Float16 Vth[2][HD * VH], Vtl[2][HD * VH];
-  const int seg = blockIdx.z, head = blockIdx.y;
+  // 1-D grid: all query tiles of one (segment, head) -- which stream the same
+  // K/V -- are placed on one XCD (ids b and b+8 share an L2)
+  int seg, head, qt;
+  {
+    const int nqt = gridDim.x / (nhead * nseg);
+    const int ngrp = nhead * nseg;
+    const int b = blockIdx.x;
+    if ((ngrp & 7) == 0) {
+      const int xcd = b & 7, idx = b >> 3;
+      const int g = xcd + 8 * (idx / nqt);
+      qt = idx % nqt;
+      head = g % nhead;
+      seg = g / nhead;
+    } else {
+      qt = b % nqt;
+      head = (b / nqt) % nhead;
+      seg = b / (nqt * nhead);
+    }
+  }
   const int qbeg = cu[seg], qlen = cu[seg + 1] - qbeg;
-  const int q0 = blockIdx.x * QB;
+  const int q0 = qt * QB;
   if (q0 >= qlen) return;
   const int ks = kv_seg[seg];
   const int kbeg = cu[ks], klen = cu[ks + 1] - kbeg;
@@ -391,14 +427,14 @@ extern "C" int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k,
   SPR_REQUIRE(nseg >= 1 && nhead >= 1 && max_len_host >= 1, "attention: bad sizes");
   SPR_REQUIRE(q_stride % 4 == 0 && k_stride % 4 == 0 && v_stride % 4 == 0 && o_stride % 4 == 0,
               "attention: row strides must be multiples of 4 floats");
-  SPR_REQUIRE(nseg <= 65535 && nhead <= 65535, "attention: grid too large");
-  dim3 grid(cdiv(max_len_host, QB), nhead, nseg);
+  SPR_REQUIRE((long)cdiv(max_len_host, QB) * nhead * nseg < (1l << 31), "attention: grid too large");
+  dim3 grid(cdiv(max_len_host, QB) * nhead * nseg);
   if (spr::g_attn_mode == 1)
     hipLaunchKernelGGL(k_attn_h3, grid, dim3(256), 0, stream, q, q_stride, k, k_stride, v, v_stride, cu,
-                       kv_seg, nhead, scale, out, o_stride);
+                       kv_seg, nseg, nhead, scale, out, o_stride);
   else
     hipLaunchKernelGGL(k_attn, grid, dim3(256), 0, stream, q, q_stride, k, k_stride, v, v_stride, cu,
-                       kv_seg, nhead, scale, out, o_stride);
+                       kv_seg, nseg, nhead, scale, out, o_stride);
   SPR_LAUNCH_CHECK();
   return 0;
 }

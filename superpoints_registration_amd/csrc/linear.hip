@@ -63,7 +63,10 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt(
   __shared__ float Bs[BN * LDSK];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // 1-D grid, XCD-swizzled: the column tiles of one row panel share an L2
+  const int gx = (N + BN - 1) / BN;
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int m0 = (lid / gx) * BM, n0 = (lid % gx) * BN;
   const int l31 = lane & 31, lh = lane >> 5;
 
   f32x16 acc;
@@ -185,7 +188,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt_h3(
   __shared__ __align__(16) _Float16 Ah[BM * HS], Al[BM * HS], Bh[BN * HS], Bl[BN * HS];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // 1-D grid, XCD-swizzled: the column tiles of one row panel share an L2
+  const int gx = (N + BN - 1) / BN;
+  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int m0 = (lid / gx) * BM, n0 = (lid % gx) * BN;
   const int l31 = lane & 31, lh = lane >> 5;
 
   f32x16 acc_hh[TM][TN], acc_x[TM][TN];
@@ -381,21 +387,20 @@ template <int ACT, bool RES>
 int launch_gemm(const float* x, int m, int k, const float* w, int n, const float* bias,
                 const float* residual, float* out, hipStream_t stream) {
   if (spr::g_gemm_mode == 1) {
-    if (n % 128 == 0 && m >= 512) {
-      hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 128, 2, 2, ACT, RES>), dim3(n / 128, cdiv(m, 128)),
-                         dim3(256), 0, stream, x, m, k, w, n, bias, residual, out);
-    } else if (n > 32) {
-      hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 64, 4, 1, ACT, RES>), dim3(cdiv(n, 64), cdiv(m, 128)),
+    // 128x64 tiles (2 accumulator pairs per wave) keep the kernel at 3 waves/SIMD;
+    // 128x128 (4 pairs, >256 registers) drops to 1 wave/SIMD and measured 1.4x slower
+    if (n > 32) {
+      hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 64, 4, 1, ACT, RES>), dim3(cdiv(n, 64) * cdiv(m, 128)),
                          dim3(256), 0, stream, x, m, k, w, n, bias, residual, out);
     } else {
-      hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 32, 4, 1, ACT, RES>), dim3(cdiv(n, 32), cdiv(m, 128)),
+      hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 32, 4, 1, ACT, RES>), dim3(cdiv(n, 32) * cdiv(m, 128)),
                          dim3(256), 0, stream, x, m, k, w, n, bias, residual, out);
     }
   } else if (n % 64 == 0) {
-    hipLaunchKernelGGL((spr::k_gemm_nt<2, 2, ACT, RES>), dim3(n / 64, cdiv(m, 64)), dim3(256), 0, stream,
+    hipLaunchKernelGGL((spr::k_gemm_nt<2, 2, ACT, RES>), dim3((n / 64) * cdiv(m, 64)), dim3(256), 0, stream,
                        x, m, k, w, n, bias, residual, out);
   } else {
-    hipLaunchKernelGGL((spr::k_gemm_nt<4, 1, ACT, RES>), dim3(cdiv(n, 32), cdiv(m, 128)), dim3(256), 0,
+    hipLaunchKernelGGL((spr::k_gemm_nt<4, 1, ACT, RES>), dim3(cdiv(n, 32) * cdiv(m, 128)), dim3(256), 0,
                        stream, x, m, k, w, n, bias, residual, out);
   }
   SPR_LAUNCH_CHECK();

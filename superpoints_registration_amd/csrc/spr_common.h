@@ -80,6 +80,18 @@ __device__ __forceinline__ int find_segment(const int* __restrict__ cu, int nseg
   return lo;
 }
 
+// XCD-aware remap of a linear workgroup id (MI355X: 8 XCDs, each with its own
+// L2; the dispatcher deals workgroups round-robin over them, so ids b and b+8
+// share an L2).  Returns a bijective logical id such that CONSECUTIVE logical
+// ids run on the same XCD -- tiles that share an operand panel then hit one L2
+// instead of eight.  Speed only: correctness never depends on placement.
+__device__ __forceinline__ int xcd_swizzle(int b, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = b & 7, idx = b >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

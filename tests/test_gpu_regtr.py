@@ -75,3 +75,34 @@ def test_state_dict_round_trip(device, tmp_path):
     b = RegTR(cfg)
     missing = b.load_state_dict(torch.load(tmp_path / "model-1.pth")["state_dict"], strict=False)
     assert not missing.missing_keys and not missing.unexpected_keys
+
+
+def test_full_size_pairs_order_and_arithmetic_invariance(device):
+    """BASELINE config 2 sizes (2 pairs x 16 384 pts/cloud, full 3DMatch model):
+    size-independent properties instead of a (minutes-long) CPU oracle run --
+    (1) the reference point order and the canonical (ascending voxel key) order
+        are relabellings of the same computation: poses agree < 1e-4;
+    (2) split-fp16 MFMA arithmetic vs exact-f32 MFMA: poses agree < 1e-4,
+        conditioned features < 2e-5 relative."""
+    cfg = get_config("3dmatch")
+    pairs = [synthetic.make_pair(16384, seed=70 + i) for i in range(2)]
+    batch = lambda: {"src_xyz": [torch.from_numpy(p[0]).to(device) for p in pairs],
+                     "tgt_xyz": [torch.from_numpy(p[1]).to(device) for p in pairs]}
+    outs = {}
+    for tag, order, mode in (("ref", ops.ORDER_REFERENCE, 1), ("canon", ops.ORDER_CANONICAL, 1),
+                             ("exact", ops.ORDER_REFERENCE, 0)):
+        ops.set_gemm_mode(mode)
+        ops.set_attn_mode(mode)
+        model = RegTR(cfg, order=order)
+        synthetic.fill_parameters(model, seed=0)
+        model = model.to(device).eval()
+        outs[tag] = model(batch())
+    ops.set_gemm_mode(1)
+    ops.set_attn_mode(1)
+    for b in range(2):
+        ref = outs["ref"]["pose"][b].cpu().numpy()
+        assert np.linalg.norm(ref - outs["canon"]["pose"][b].cpu().numpy()) < 1e-4
+        assert np.linalg.norm(ref - outs["exact"]["pose"][b].cpu().numpy()) < 1e-4
+        f_ref, f_ex = outs["ref"]["src_feat"][b][0], outs["exact"]["src_feat"][b][0]
+        assert float((f_ref - f_ex).abs().max()) <= 2e-5 * float(f_ex.abs().max())
+        assert outs["ref"]["src_feat"][b].shape[1] > 1000          # ~1.9 k superpoints per cloud
