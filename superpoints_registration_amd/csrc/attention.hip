@@ -195,8 +195,9 @@ __global__ __launch_bounds__(256) void k_attn(
 // ---------------------------------------------------------------------------
 // Split-fp16 variant ("h3"): same structure, fp32-level accuracy, ~5x less
 // matrix-core time.  Every operand x is carried as hi = fp16(x) and
-// lo = fp16((x - hi) * 2^11); a.b ~= ah.bh + 2^-11 (ah.bl + al.bh) with fp32
-// accumulation (two accumulators per product: hi.hi and the cross terms).
+// lo = fp16(x - hi); a.b ~= ah.bh + ah.bl + al.bh in ONE fp32 accumulator
+// (the matrix cores honour fp16 subnormals, scripts/abl/denorm.hip, so lo needs
+// no rescaling; its absolute resolution is 2^-24).
 //   S^T = K Q^T : 2 k-steps x 3 v_mfma_f32_32x32x16_f16  (head_dim 32)
 //   O^T = V^T P^T: the f32 probabilities in the S^T accumulator are converted
 //     in place -- registers 8s..8s+7 of a lane are exactly the B fragment of
@@ -206,13 +207,14 @@ __global__ __launch_bounds__(256) void k_attn(
 //     probabilities stay in fp16's normal range (undone in the final 1/l).
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KH = 40;   // K tile row stride in halves (80 B: conflict-free ds_read_b128)
 constexpr int VH = 36;   // V^T tile row stride in halves (72 B: conflict-free ds_read_b64)
-constexpr float kLo = 2048.0f, kPScale = 1024.0f;
 
 __device__ __forceinline__ void split_h(float x, _Float16& hi, _Float16& lo) {
   hi = (_Float16)x;
-  lo = (_Float16)((x - (float)hi) * kLo);
+  lo = (_Float16)(x - (float)hi);
 }
 
 __global__ __launch_bounds__(256) void k_attn_h3(
@@ -270,12 +272,9 @@ __global__ __launch_bounds__(256) void k_attn_h3(
       }
   }
 
-  f32x16 o_hh, o_x;
+  f32x16 o;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    o_hh[r] = 0.f;
-    o_x[r] = 0.f;
-  }
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
 
   const int sr = tid >> 3, sc4 = (tid & 7) * 4;   // staging role: key row, 4 dims
@@ -320,12 +319,9 @@ __global__ __launch_bounds__(256) void k_attn_h3(
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- S^T = K Q^T (rows = keys, cols = queries) ----
-    f32x16 s_hh, s_x;
+    f32x16 sacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s_hh[r] = 0.f;
-      s_x[r] = 0.f;
-    }
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
     h16x8 kfh[2], kfl[2], vfh[2], vfl[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -334,9 +330,9 @@ __global__ __launch_bounds__(256) void k_attn_h3(
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      s_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], qh[s], s_hh, 0, 0, 0);
-      s_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], ql[s], s_x, 0, 0, 0);
-      s_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[s], qh[s], s_x, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], ql[s], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[s], qh[s], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], qh[s], sacc, 0, 0, 0);
     }
     // V^T A-fragments (issued early: their LDS latency hides under the softmax)
 #pragma unroll
@@ -352,43 +348,60 @@ __global__ __launch_bounds__(256) void k_attn_h3(
     }
 
     // ---- online softmax (lane = query; reg r <-> key (r&3) + 8 (r>>2) + 4 lh) ----
-    float st[16];
-    float mx = -INFINITY;
+    if (kt + KT > klen) {             // wave-uniform: only the last tile has a tail
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      st[r] = (j < klen) ? s_hh[r] + s_x[r] * (1.0f / kLo) : -INFINITY;
-      mx = fmaxf(mx, st[r]);
+      for (int r = 0; r < 16; ++r) {
+        const int j = kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (j >= klen) sacc[r] = -INFINITY;
+      }
     }
+    float mx = sacc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
-    float psum = 0.f;
-    h16x8 pbh[2], pbl[2];
+    // the running maximum rarely moves after the first tiles: skip the rescale
+    // of the 16 output registers unless some lane of the wave needs it
+    if (__ballot(m_new != m_run) != 0ull) {
+      const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= corr;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f(st[r] - m_new);
-      psum += p;
-      _Float16 a, b;
-      split_h(p * kPScale, a, b);
-      pbh[r >> 3][r & 7] = a;       // registers 8s..8s+7 = B fragment of k-step s
-      pbl[r >> 3][r & 7] = b;
+      for (int r = 0; r < 16; ++r) o[r] *= corr;
+      m_run = m_new;
+    }
+    // p' = 2^10 * exp2(s - m): the 2^10 keeps small probabilities inside fp16's
+    // normal range; l_run accumulates the same scaled values, so it cancels in
+    // the final 1/l.  hi by packed round-toward-zero conversion, lo = p' - hi.
+    const float mshift = m_run - 10.0f;
+    float psum = 0.f;
+    unsigned int ph_u[8], pl_u[8];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float p0 = __builtin_amdgcn_exp2f(sacc[r] - mshift);
+      const float p1 = __builtin_amdgcn_exp2f(sacc[r + 1] - mshift);
+      psum += p0 + p1;
+      const h16x2 hi = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+      const h16x2 lo = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(p0 - (float)hi[0], p1 - (float)hi[1]));
+      ph_u[r >> 1] = __builtin_bit_cast(unsigned int, hi);
+      pl_u[r >> 1] = __builtin_bit_cast(unsigned int, lo);
     }
     psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * corr + psum;
-    m_run = m_new;
+    l_run += psum;
+    h16x8 pbh[2], pbl[2];   // registers 8s..8s+7 = B fragment of k-step s
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o_hh[r] *= corr;
-      o_x[r] *= corr;
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const u32x4 a = {ph_u[4 * s2], ph_u[4 * s2 + 1], ph_u[4 * s2 + 2], ph_u[4 * s2 + 3]};
+      const u32x4 b = {pl_u[4 * s2], pl_u[4 * s2 + 1], pl_u[4 * s2 + 2], pl_u[4 * s2 + 3]};
+      pbh[s2] = __builtin_bit_cast(h16x8, a);
+      pbl[s2] = __builtin_bit_cast(h16x8, b);
     }
 
     // ---- O^T += V^T P^T ----
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      o_hh = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbh[s], o_hh, 0, 0, 0);
-      o_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbl[s], o_x, 0, 0, 0);
-      o_x = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[s], pbh[s], o_x, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbl[s], o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[s], pbh[s], o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbh[s], o, 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (more) stash(kt + KT, buf ^ 1);
@@ -396,15 +409,15 @@ __global__ __launch_bounds__(256) void k_attn_h3(
   }
 
   if (qok) {
-    const float inv = l_run > 0.f ? (1.0f / kPScale) / l_run : 0.f;
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
     float* op = out + (size_t)(qbeg + qi) * o_stride + hoff;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float4 w4;
-      w4.x = (o_hh[4 * g + 0] + o_x[4 * g + 0] * (1.0f / kLo)) * inv;
-      w4.y = (o_hh[4 * g + 1] + o_x[4 * g + 1] * (1.0f / kLo)) * inv;
-      w4.z = (o_hh[4 * g + 2] + o_x[4 * g + 2] * (1.0f / kLo)) * inv;
-      w4.w = (o_hh[4 * g + 3] + o_x[4 * g + 3] * (1.0f / kLo)) * inv;
+      w4.x = o[4 * g + 0] * inv;
+      w4.y = o[4 * g + 1] * inv;
+      w4.z = o[4 * g + 2] * inv;
+      w4.w = o[4 * g + 3] * inv;
       *reinterpret_cast<float4*>(op + 8 * g + 4 * lh) = w4;
     }
   }

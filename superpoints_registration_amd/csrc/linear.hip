@@ -159,8 +159,11 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt(
 
 // ---------------------------------------------------------------------------
 // Split-fp16 GEMM ("h3"): fp32 accuracy at ~5x the exact-f32 MFMA rate.
-//   x = hi + lo * 2^-11,  hi = fp16(x),  lo = fp16((x - hi) * 2^11)
-//   a.b ~= ah.bh + 2^-11 (ah.bl + al.bh)          (al.bl ~ 2^-22 |a.b| dropped)
+//   x = hi + lo,  hi = fp16(x),  lo = fp16(x - hi)
+//   a.b ~= ah.bh + ah.bl + al.bh                   (al.bl ~ 2^-22 |a.b| dropped)
+// (the matrix cores honour fp16 subnormals on both operands -- measured with
+// scripts/abl/denorm.hip -- so lo needs no rescaling and all three products
+// share ONE fp32 accumulator; lo's absolute resolution is 2^-24)
 // hi and lo together carry 22 significand bits, so the operand representation
 // error is ~2^-23 relative -- the same order as one fp32 rounding; products
 // are exact in the MFMA and accumulate in fp32.  Three v_mfma_f32_32x32x16_f16
@@ -173,7 +176,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HS = 40;                 // LDS row stride in halves (BK = 32 + 8 pad)
-constexpr float kLoScale = 2048.0f;    // 2^11
 
 template <int BM, int BN, int WM, int WN, int ACT, bool RES>
 __global__ __launch_bounds__(256) void k_gemm_nt_h3(
@@ -194,16 +196,13 @@ __global__ __launch_bounds__(256) void k_gemm_nt_h3(
   const int m0 = (lid / gx) * BM, n0 = (lid % gx) * BN;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  f32x16 acc_hh[TM][TN], acc_x[TM][TN];
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc_hh[i][j][r] = 0.f;
-        acc_x[i][j][r] = 0.f;
-      }
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   f32x4 ra[A_PT], rb[B_PT];
   auto load_slab = [&](int k0) {
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt_h3(
       const float x = in ? v[e] : 0.f;
       const _Float16 xh = (_Float16)x;
       h[e] = xh;
-      l[e] = (_Float16)((x - (float)xh) * kLoScale);
+      l[e] = (_Float16)(x - (float)xh);
     }
     *reinterpret_cast<f16x4*>(hi) = h;
     *reinterpret_cast<f16x4*>(lo) = l;
@@ -278,9 +277,10 @@ __global__ __launch_bounds__(256) void k_gemm_nt_h3(
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc_hh[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc_hh[i][j], 0, 0, 0);
-          acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc_x[i][j], 0, 0, 0);
-          acc_x[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc_x[i][j], 0, 0, 0);
+          // small terms first, then the dominant one
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -292,12 +292,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt_h3(
     const int col = n0 + (wn * TN + j) * 32 + l31;
     const float bv = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      f32x16 c;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) c[r] = acc_hh[i][j][r] + acc_x[i][j][r] * (1.0f / kLoScale);
-      store_tile<ACT, RES>(c, m0 + (wm * TM + i) * 32, col, M, N, bv, residual, out, lh);
-    }
+    for (int i = 0; i < TM; ++i)
+      store_tile<ACT, RES>(acc[i][j], m0 + (wm * TM + i) * 32, col, M, N, bv, residual, out, lh);
   }
 }
 
