@@ -134,18 +134,77 @@ __global__ __launch_bounds__(256) void k_kpconv_cin1(
 }
 
 // ---------------------------------------------------------------------------
+// Weight preparation for phase 2 of the fused kernel: W [15*cin, cout] f32 ->
+// Wt_hi / Wt_lo [cout][15*cin] fp16 (w = hi + lo, lo = fp16(w - hi)); a lane
+// then reads 8 consecutive k of one output channel with one 16-byte load.
+__global__ void k_w_prep(const float* __restrict__ W, int kt, int cout, _Float16* __restrict__ Wh,
+                         _Float16* __restrict__ Wl) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, o = o0 + tx;
+    tile[r][tx] = (k < kt && o < cout) ? W[(size_t)k * cout + o] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int o = o0 + r, k = k0 + tx;
+    if (o < cout && k < kt) {
+      const float w = tile[tx][r];
+      const _Float16 h = (_Float16)w;
+      Wh[(size_t)o * kt + k] = h;
+      Wl[(size_t)o * kt + k] = (_Float16)(w - (float)h);
+    }
+  }
+}
+
+__device__ __forceinline__ void wait_vm(int n) {   // n folds to a constant after unrolling
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+typedef _Float16 kh8 __attribute__((ext_vector_type(8)));
+template <int N> struct VecF;
+template <> struct VecF<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct VecF<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <int N> struct VecH;
+template <> struct VecH<2> { typedef _Float16 type __attribute__((ext_vector_type(2))); };
+template <> struct VecH<4> { typedef _Float16 type __attribute__((ext_vector_type(4))); };
+
+// ---------------------------------------------------------------------------
 // Fused MFMA kernel.
-//   CC    channel chunk (16, 32 or 64); NTC = CC/16 phase-1 n-tiles
+//   CC    channel chunk (32 or 64); NTC = CC/16 phase-1 n-tiles
 //   TQ    queries per workgroup (multiple of 16); MT = TQ/16 m-tiles
 //   NTW   phase-2 n-tiles (of 16 output channels) per wave
-// 256 threads = 4 waves.  Wave w: phase 1 -> queries [w*TQ/4, (w+1)*TQ/4);
-// phase 2 -> m-tile (w % MT), n-tiles [(w / MT) * NTW, +NTW).
-// Requires cout == 16 * NTW * (4 / MT).
+//   NW    waves per workgroup (4 or 8)
+// Wave w: phase 1 -> queries [w*TQ/NW, (w+1)*TQ/NW); phase 2 -> m-tile (w % MT),
+// n-tiles [(w / MT) * NTW, +NTW).  Requires cout == 16 * NTW * (NW / MT).
+// Phase 2 streams the whole [15*Cin, Cout] weight matrix from L2 once per
+// workgroup, and that stream is what bounds the kernel (measured: time is
+// proportional to Cout, independent of gather locality and of the MFMA type),
+// so TQ is as large as LDS allows: 32 queries x 64 channels = 125 KB.
 //
-// Phase 1 is software pipelined over "items" = (query, block of 16
-// neighbours): while item i feeds the MFMAs, the gathers of item i+1 are in
-// flight and the neighbour indices of item i+2 are being fetched, so a wave
-// always has ~2 dependent round trips outstanding instead of stalling on each.
+// Phase 1 (exact f32): "items" = (query, block of 16 neighbours); only LIVE
+// blocks are enumerated (rows are distance sorted with trailing shadow
+// entries, so a query with v valid neighbours owns ceil(v/16) items).  The
+// item loop is software pipelined: while item i feeds the MFMAs, the gathers
+// of item i+1 are in flight; neighbour indices come from LDS.  Lane (p, j)
+// computes ONE influence weight per k-step = the A-operand layout of
+// v_mfma_f32_16x16x4_f32; the B operand is one NTC-wide load per neighbour
+// (lane p takes channels NTC*p .. NTC*p+NTC-1: 16 lanes = one whole row slice).
+// Phase 2 (split fp16, fp32-level accuracy -- see linear.hip): the weighted
+// features leave phase 1 as hi/lo fp16 tiles in LDS and are contracted with the
+// pre-split transposed weights by v_mfma_f32_16x16x32_f16 (3 per 32-deep
+// k-step); the weights stream from L2 through a ring of D k-steps issued by
+// inline asm and retired with counted vmcnt.
 template <int NTC>
 struct KpItem {
   int idx[4];
@@ -153,43 +212,69 @@ struct KpItem {
   float b[4][NTC];
   float qx, qy, qz;
   int fl[4];
-  bool any;
 };
 
-template <int CC, int TQ, int NTW>
-__global__ __launch_bounds__(256) void k_kpconv_mfma(
+template <int CC, int TQ, int NTW, int NW, int SK>
+__global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
     const float* __restrict__ q_xyz, int nq, const float* __restrict__ s_xyz, int ns,
     const int* __restrict__ nbr, int nbr_stride, int kmax, int rows_sorted,
-    const float* __restrict__ x, int cin, const float* __restrict__ W, int cout,
-    const float* __restrict__ kpts, float inv_extent,
+    const float* __restrict__ x, int cin, const _Float16* __restrict__ Wh,
+    const _Float16* __restrict__ Wl, int cout, const float* __restrict__ kpts, float inv_extent,
     const unsigned char* __restrict__ flag, float* __restrict__ out) {
   constexpr int NTC = CC / 16;
   constexpr int MT = TQ / 16;
   constexpr int KW = kKP * CC;       // phase-2 K per chunk
-  constexpr int STRIDE = KW + 2;     // conflict-free A-fragment reads (see header)
-  constexpr int QPW = TQ / 4;        // queries per wave in phase 1
-  extern __shared__ __align__(16) float lds[];
-  float* wf = lds;                   // [TQ][STRIDE]
-  int* lcnt = (int*)(lds + TQ * STRIDE);  // [TQ]
-  int* lidx = lcnt + TQ;             // [TQ][KP] neighbour indices of the tile
+  constexpr int SH = KW + 16;        // LDS row stride in halves: conflict-free ds_read_b128
+  constexpr int QPW = TQ / NW;       // queries per wave in phase 1
+  constexpr int NTHR = 64 * NW;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  _Float16* wfh = (_Float16*)lds_raw;                 // [TQ][SH] hi
+  _Float16* wfl = wfh + TQ * SH;                      // [TQ][SH] lo
+  int* lcnt = (int*)(wfl + TQ * SH);                  // [TQ]
+  int* lnit = lcnt + TQ;                              // [NW] live items per wave
+  int* litem = lnit + NW;                             // [NW][QPW * nblk] (qi << 8) | (last << 7) | b
+  const int nblk = (kmax + 15) >> 4;                  // neighbour blocks per query
+  const int KP = nblk * 16;
+  int* lidx = litem + NW * QPW * nblk;                // [TQ][KP] neighbour indices of the tile
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int p16 = lane & 15, j4 = lane >> 4;
   const int q0 = blockIdx.x * TQ;
-  const int nblk = (kmax + 15) >> 4;      // neighbour blocks per query
-  const int KP = nblk * 16;
-  const int n_items = QPW * nblk;
 
   // Stage the tile's neighbour rows in LDS once (coalesced), padded with the
-  // shadow index: the gather pipeline below then depends on LDS reads only, so
-  // index fetches never drain the vector-memory queue.
-  for (int e = tid; e < TQ * KP; e += 256) {
+  // shadow index: the gather pipeline then depends on LDS reads only.
+  for (int e = tid; e < TQ * KP; e += NTHR) {
     const int q = e / KP, k = e - q * KP;
     const int n = q0 + q;
     lidx[e] = (n < nq && k < kmax) ? nbr[(size_t)n * nbr_stride + k] : ns;
   }
   __syncthreads();
+  // live-item list of this wave
+  {
+    int n_it = 0;
+    for (int qi = 0; qi < QPW; ++qi) {
+      const int* row = lidx + (wave * QPW + qi) * KP;
+      int nb = nblk;
+      if (rows_sorted) {   // valid count = position of the first shadow entry
+        int v = 0;
+        for (int k = lane; k < KP; k += 64) v += (row[k] >= 0 && row[k] < ns) ? 1 : 0;
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        nb = max(1, (v + 15) >> 4);
+      }
+      if (lane < nb) litem[wave * QPW * nblk + n_it + lane] = (qi << 8) | ((lane == nb - 1) ? 128 : 0) | lane;
+      n_it += nb;
+    }
+    if (lane == 0) lnit[wave] = n_it;
+  }
+  __syncthreads();
+  const int n_items = lnit[wave];
+  const int* my_items = litem + wave * QPW * nblk;
 
   // kernel point of this lane (lane 15 of each 16 is padding)
   float kx = 0.f, ky = 0.f, kz = 0.f;
@@ -199,11 +284,22 @@ __global__ __launch_bounds__(256) void k_kpconv_mfma(
     kz = kpts[3 * p16 + 2];
   }
 
-  const int mt = wave % MT;
-  const int ng = wave / MT;
-  f32x4 acc2[NTW];
+  // phase-2 roles.  SK == 1: wave -> (m-tile wave % MT, n-group wave / MT), whole k range.
+  // SK == 2: wave -> (n-group wave % NG, k-half wave / NG) and ALL m-tiles: every weight
+  // fragment is fetched once per workgroup instead of once per m-tile (the weight stream
+  // through the CU's vector memory path is what bounds this phase); the two k-halves are
+  // summed through LDS at the end.
+  constexpr int NG = (SK == 1) ? NW / MT : NW / SK;
+  constexpr int MTW = (SK == 1) ? 1 : MT;                 // m-tiles per wave
+  const int mt = (SK == 1) ? wave % MT : 0;
+  const int ng = (SK == 1) ? wave / MT : wave % NG;
+  const int kh = (SK == 1) ? 0 : wave / NG;
+  f32x4 acc2[MTW][NTW];
 #pragma unroll
-  for (int t = 0; t < NTW; ++t) acc2[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc2[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int ktot = kKP * cin;
 
   for (int c0 = 0; c0 < cin; c0 += CC) {
     // ------------------------------ phase 1 --------------------------------
@@ -212,78 +308,72 @@ __global__ __launch_bounds__(256) void k_kpconv_mfma(
     for (int t = 0; t < NTC; ++t) acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int cnt = 0;
 
-    // neighbour indices of item `it` for this lane's 4 k-steps
-    auto load_idx = [&](int it, int (&idx)[4]) {
-      const bool live = it < n_items;                   // wave-uniform
-      const int itc = live ? it : 0;
-      const int qi = itc / nblk, b = itc - qi * nblk;
-      const int* row = lidx + (wave * QPW + qi) * KP + b * 16 + j4;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int v = row[4 * s];
-        idx[s] = live ? v : ns;
-      }
-    };
-    // issue the gathers of item `it` (indices already in registers)
-    auto issue = [&](int it, const int (&idx)[4], KpItem<NTC>& I) {
-      const int qi = it / nblk;
+    // issue the gathers of live item `it` (out-of-range items re-issue item 0: harmless)
+    auto issue = [&](int it, KpItem<NTC>& I) {
+      const int code = my_items[min(it, n_items - 1)];
+      const int qi = code >> 8, b = code & 127;
       const int n = min(q0 + wave * QPW + qi, nq - 1);
-      bool mine = false;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        I.idx[s] = idx[s];
-        mine |= (idx[s] >= 0 && idx[s] < ns);
-      }
-      I.any = __ballot(mine) != 0ull;   // wave-uniform; loads stay unconditional so that the
+      const int* row = lidx + (wave * QPW + qi) * KP + b * 16 + j4;
       I.qx = q_xyz[3 * (size_t)n];
       I.qy = q_xyz[3 * (size_t)n + 1];
       I.qz = q_xyz[3 * (size_t)n + 2];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const bool ok = idx[s] >= 0 && idx[s] < ns;
-        const size_t id = ok ? (size_t)idx[s] : 0;
-        I.sp[s][0] = s_xyz[3 * id];      // destination registers are the struct itself
+        const int id_ = row[4 * s];
+        I.idx[s] = id_;
+        const bool ok = id_ >= 0 && id_ < ns;
+        const size_t id = ok ? (size_t)id_ : 0;
+        I.sp[s][0] = s_xyz[3 * id];
         I.sp[s][1] = s_xyz[3 * id + 1];
         I.sp[s][2] = s_xyz[3 * id + 2];
+        typedef typename VecF<NTC>::type vec_t;
+        const vec_t xv = *reinterpret_cast<const vec_t*>(x + id * cin + c0 + NTC * p16);
 #pragma unroll
-        for (int t = 0; t < NTC; ++t) I.b[s][t] = x[id * cin + c0 + t * 16 + p16];
+        for (int t = 0; t < NTC; ++t) I.b[s][t] = xv[t];
         I.fl[s] = (int)flag[id];
       }
     };
     // consume item `it`; flush the query's accumulators after its last block
     auto compute = [&](int it, const KpItem<NTC>& I) {
       if (it >= n_items) return;
-      if (I.any) {
+      const int code = my_items[it];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const bool ok = I.idx[s] >= 0 && I.idx[s] < ns;
-          const float dx = (I.sp[s][0] - I.qx) - kx, dy = (I.sp[s][1] - I.qy) - ky,
-                      dz = (I.sp[s][2] - I.qz) - kz;
-          // v_sqrt_f32 (1 ulp) instead of the correctly-rounded expansion: ~8 VALU ops
-          // fewer per influence weight, far inside the 1e-5 feature tolerance
-          float w = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
-          if (!ok || p16 >= kKP) w = 0.f;
-          cnt += (ok && c0 == 0 && p16 == 0) ? I.fl[s] : 0;
-#pragma unroll
-          for (int t = 0; t < NTC; ++t) {
-            const float bv = ok ? I.b[s][t] : 0.f;
-            acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, bv, acc1[t], 0, 0, 0);
-          }
-        }
-      }
-      const int qi = it / nblk;
-      if (it - qi * nblk == nblk - 1) {
-        const int ql = wave * QPW + qi;
-        // C/D layout: row (kernel point) = 4*j4 + r, col (channel) = p16
+      for (int s = 0; s < 4; ++s) {
+        const bool ok = I.idx[s] >= 0 && I.idx[s] < ns;
+        const float dx = (I.sp[s][0] - I.qx) - kx, dy = (I.sp[s][1] - I.qy) - ky,
+                    dz = (I.sp[s][2] - I.qz) - kz;
+        // v_sqrt_f32 (1 ulp) instead of the correctly-rounded expansion
+        float w = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
+        if (!ok || p16 >= kKP) w = 0.f;
+        cnt += (ok && c0 == 0 && p16 == 0) ? I.fl[s] : 0;
 #pragma unroll
         for (int t = 0; t < NTC; ++t) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int p = 4 * j4 + r;
-            if (p < kKP) wf[ql * STRIDE + p * CC + t * 16 + p16] = acc1[t][r];
-          }
-          acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          const float bv = ok ? I.b[s][t] : 0.f;
+          acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, bv, acc1[t], 0, 0, 0);
         }
+      }
+      if (code & 128) {   // last live block of the query
+        const int ql = wave * QPW + (code >> 8);
+        // C/D layout: row (kernel point) = 4*j4 + r, col = p16 <-> channels NTC*p16 + t
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = 4 * j4 + r;
+          typedef typename VecH<NTC>::type hv_t;
+          hv_t hh, ll;
+#pragma unroll
+          for (int t = 0; t < NTC; ++t) {
+            const float v = acc1[t][r];
+            const _Float16 h = (_Float16)v;
+            hh[t] = h;
+            ll[t] = (_Float16)(v - (float)h);
+          }
+          if (p < kKP) {
+            *reinterpret_cast<hv_t*>(wfh + ql * SH + p * CC + NTC * p16) = hh;
+            *reinterpret_cast<hv_t*>(wfl + ql * SH + p * CC + NTC * p16) = ll;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (c0 == 0) {
           int c = cnt;  // lanes with p16 == 0 hold the partial counts (one per j4)
           c += __shfl_xor(c, 16, 64);
@@ -296,113 +386,108 @@ __global__ __launch_bounds__(256) void k_kpconv_mfma(
 
     {
       KpItem<NTC> A, B;
-      int ia[4], ib[4];
-      load_idx(0, ia);
-      issue(0, ia, A);
-      load_idx(1, ib);
+      issue(0, A);
       for (int it = 0; it < n_items; it += 2) {
-        issue(it + 1, ib, B);
-        load_idx(it + 2, ia);
+        issue(it + 1, B);
         compute(it, A);
-        issue(it + 2, ia, A);
-        load_idx(it + 3, ib);
+        issue(it + 2, A);
         compute(it + 1, B);
       }
     }
     __syncthreads();
     // ------------------------------ phase 2 --------------------------------
-    // W streams from L2 straight into registers through a ring of D batches of
-    // U k-steps: the loads of batch i+D are issued right after batch i's MFMAs,
-    // so D-1 batches (~1k cycles of MFMA work) cover the L2 latency.
     {
-      const float* arow = wf + (mt * 16 + p16) * STRIDE + j4;
-      const float* wbase = W + (size_t)c0 * cout + (ng * NTW) * 16 + p16;
-      constexpr int NSTEP = KW / 4;                   // 240 / 120 / 60
-      constexpr int U = (CC == 16 && NTW == 1) ? 4 : 8 / NTW;   // k-steps per batch (<= 8 loads)
-      static_assert(NTW <= 8, "at most 8 n-tiles per wave");
-      constexpr int D = 5;                            // batches in flight
-      constexpr int NBATCH = NSTEP / U;
-      static_assert(NSTEP % U == 0 && NBATCH % D == 0 && NBATCH >= 2 * D, "ring shape");
-      // hipcc sinks ordinary loads down to their first use (one exposed L2 round
-      // trip per k-step), so the ring is issued with inline-asm loads and
-      // retired with hand-counted s_waitcnt vmcnt(N): no other vector memory
-      // operation is in flight in this phase (phase 1 is fully drained by the
-      // barrier above; LDS traffic counts on lgkmcnt).
-      constexpr int LPB = U * NTW;                    // loads per batch
-      float bv[D][U][NTW];
-      // A batch of U k-steps (4U rows of the [15*Cin, Cout] matrix) never straddles
-      // a kernel-point block (CC % 4U == 0), so its rows are contiguous: the row
-      // offset is wave-uniform scalar arithmetic, one 64-bit add gives the batch
-      // pointer and the individual loads use immediate offsets.
-      static_assert(CC % (4 * U) == 0, "batch must stay inside one kernel-point block");
-      const float* lane_base = wbase + (size_t)j4 * cout;
-      auto load_batch = [&](int bi, float (&dst)[U][NTW]) {
-        const int k0 = 4 * U * bi;                        // wave-uniform
-        const int row0 = (k0 / CC) * cin + (k0 % CC);
-        const float* bp0 = lane_base + (size_t)row0 * cout;
+      constexpr int NBATCH = KW / 32 / SK;                          // 32-deep k-steps of this wave
+      const int ks0 = kh * NBATCH;
+      constexpr int LPB = 2 * NTW;                                  // 16-byte loads per k-step
+      constexpr int D = (NTW <= 2) ? 5 : 3;                         // k-steps in flight
+      static_assert(NBATCH % D == 0 && NBATCH >= 2 * D && (D - 1) * LPB <= 16, "ring shape");
+      const _Float16* ah_row = wfh + (mt * 16 + p16) * SH + 8 * j4;
+      const _Float16* al_row = wfl + (mt * 16 + p16) * SH + 8 * j4;
+      const size_t wofs = (size_t)((ng * NTW) * 16 + p16) * ktot + c0 + 8 * j4;
+      kh8 bh[D][NTW], bl[D][NTW];
+      auto load_step = [&](int ks, kh8 (&dh)[NTW], kh8 (&dl)[NTW]) {
+        const int kk0 = 32 * (ks0 + ks);                            // wave-uniform, inside one kernel point
+        const size_t gk = wofs + (size_t)(kk0 / CC) * cin + (kk0 % CC);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const float* wrow = bp0 + (size_t)(4 * u) * cout;
-#pragma unroll
-          for (int t = 0; t < NTW; ++t)
-            asm volatile("global_load_dword %0, %1, off offset:%2"
-                         : "=v"(dst[u][t]) : "v"(wrow), "n"(t * 64));
+        for (int t = 0; t < NTW; ++t) {
+          const _Float16* ph = Wh + gk + (size_t)t * 16 * ktot;
+          const _Float16* pl = Wl + gk + (size_t)t * 16 * ktot;
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dh[t]) : "v"(ph));
+          asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dl[t]) : "v"(pl));
         }
       };
-      auto mma_batch = [&](int bi, const float (&src)[U][NTW]) {
+      auto mma_step = [&](int ks, const kh8 (&sh)[NTW], const kh8 (&sl)[NTW]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const float a = arow[4 * (bi * U + u)];
+        for (int m = 0; m < MTW; ++m) {
+          const kh8 ah = *reinterpret_cast<const kh8*>(ah_row + m * 16 * SH + 32 * (ks0 + ks));
+          const kh8 al = *reinterpret_cast<const kh8*>(al_row + m * 16 * SH + 32 * (ks0 + ks));
 #pragma unroll
-          for (int t = 0; t < NTW; ++t)
-            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, src[u][t], acc2[t], 0, 0, 0);
+          for (int t = 0; t < NTW; ++t) {
+            acc2[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sl[t], acc2[m][t], 0, 0, 0);
+            acc2[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, sh[t], acc2[m][t], 0, 0, 0);
+            acc2[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, sh[t], acc2[m][t], 0, 0, 0);
+          }
         }
       };
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_vm(0);
 #pragma unroll
-      for (int d = 0; d < D; ++d) load_batch(d, bv[d]);
+      for (int d = 0; d < D; ++d) load_step(d, bh[d], bl[d]);
       for (int b0 = 0; b0 < NBATCH - D; b0 += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPB) : "memory");
+          wait_vm((D - 1) * LPB);
           __builtin_amdgcn_sched_barrier(0);
-          mma_batch(b0 + d, bv[d]);
+          mma_step(b0 + d, bh[d], bl[d]);
           __builtin_amdgcn_sched_barrier(0);
-          load_batch(b0 + d + D, bv[d]);
+          load_step(b0 + d + D, bh[d], bl[d]);
         }
       }
-      // drain: batch NBATCH-D+d has (D-1-d) younger batches behind it
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * LPB) : "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      mma_batch(NBATCH - D + 0, bv[0]);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * LPB) : "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      mma_batch(NBATCH - D + 1, bv[1]);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPB) : "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      mma_batch(NBATCH - D + 2, bv[2]);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * LPB) : "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      mma_batch(NBATCH - D + 3, bv[3]);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      mma_batch(NBATCH - D + 4, bv[4]);
-      static_assert(D == 5, "drain sequence is written for D == 5");
+#pragma unroll
+      for (int d = 0; d < D; ++d) {   // drain
+        wait_vm((D - 1 - d) * LPB);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step(NBATCH - D + d, bh[d], bl[d]);
+      }
     }
     __syncthreads();
   }
   // ------------------------------ epilogue ---------------------------------
+  if (SK == 2) {
+    // sum the two k-halves through LDS (the wf tiles are dead after the last barrier)
+    float* red = reinterpret_cast<float*>(lds_raw);            // [NG][MTW][NTW][4][64]
+    if (kh == 1) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int ql = mt * 16 + 4 * j4 + r;
-    const int n = q0 + ql;
-    if (n < nq) {
-      const float inv = 1.f / (float)max(lcnt[ql], 1);
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            red[(((ng * MTW + m) * NTW + t) * 4 + r) * 64 + lane] = acc2[m][t][r];
+    }
+    __syncthreads();
+    if (kh == 1) return;
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
 #pragma unroll
       for (int t = 0; t < NTW; ++t)
-        out[(size_t)n * cout + (ng * NTW + t) * 16 + p16] = acc2[t][r] * inv;
-    }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc2[m][t][r] += red[(((ng * MTW + m) * NTW + t) * 4 + r) * 64 + lane];
   }
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ql = (mt + m) * 16 + 4 * j4 + r;
+      const int n = q0 + ql;
+      if (n < nq) {
+        const float inv = 1.f / (float)max(lcnt[ql], 1);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+          out[(size_t)n * cout + (ng * NTW + t) * 16 + p16] = acc2[m][t][r] * inv;
+      }
+    }
 }
 
 // ---- optional per-launch HIP-event timing (bench.py roofline leg) ------------
@@ -435,27 +520,29 @@ struct ProfScope {
   }
 };
 
-template <int CC, int TQ, int NTW>
+template <int CC, int TQ, int NTW, int NW, int SK>
 int launch_mfma(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
                 int nbr_stride, int kmax, int rows_sorted, const float* x, int cin,
-                const float* W, int cout, const float* kpts, float inv_extent,
-                const unsigned char* flag, float* out, hipStream_t stream) {
-  constexpr int STRIDE = kKP * CC + 2;
-  const int kp = ((kmax + 15) / 16) * 16;
-  const size_t lds = sizeof(float) * (size_t)TQ * STRIDE + sizeof(int) * TQ + sizeof(int) * (size_t)TQ * kp;
-  auto kern = k_kpconv_mfma<CC, TQ, NTW>;
+                const _Float16* Wh, const _Float16* Wl, int cout, const float* kpts,
+                float inv_extent, const unsigned char* flag, float* out, hipStream_t stream) {
+  constexpr int SH = kKP * CC + 16;
+  constexpr int QPW = TQ / NW;
+  const int nblk = (kmax + 15) / 16;
+  const size_t lds = 2 * sizeof(_Float16) * (size_t)TQ * SH + sizeof(int) * (TQ + NW) +
+                     sizeof(int) * (size_t)NW * QPW * nblk + sizeof(int) * (size_t)TQ * nblk * 16;
+  auto kern = k_kpconv_mfma<CC, TQ, NTW, NW, SK>;
   ProfScope prof(stream, cin, cout, nq);
-  SPR_REQUIRE(lds <= 80 * 1024, "kpconv: neighbour rows too wide for the LDS tile (kmax=%d)", kmax);
+  SPR_REQUIRE(lds <= 160 * 1024, "kpconv: neighbour rows too wide for the LDS tile (kmax=%d)", kmax);
   if (lds > 64 * 1024) {
     static bool raised = false;  // per instantiation
     if (!raised) {
       SPR_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       raised = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(cdiv(nq, TQ)), dim3(256), lds, stream, q_xyz, nq, s_xyz, ns,
-                     nbr, nbr_stride, kmax, rows_sorted, x, cin, W, cout, kpts, inv_extent,
+  hipLaunchKernelGGL(kern, dim3(cdiv(nq, TQ)), dim3(64 * NW), lds, stream, q_xyz, nq, s_xyz, ns,
+                     nbr, nbr_stride, kmax, rows_sorted, x, cin, Wh, Wl, cout, kpts, inv_extent,
                      flag, out);
   SPR_LAUNCH_CHECK();
   return 0;
@@ -468,9 +555,8 @@ using namespace spr;
 
 extern "C" size_t spr_kpconv_workspace_bytes(int nq, int ns, int cin, int cout) {
   (void)nq;
-  (void)cin;
-  (void)cout;
-  return align_up((size_t)(ns > 0 ? ns : 1), 256) + 256;
+  // flag bytes + pre-split transposed weights (hi, lo fp16; up to 32 kernel points)
+  return align_up((size_t)(ns > 0 ? ns : 1), 256) + 2 * align_up((size_t)32 * cin * cout * 2, 256) + 256;
 }
 
 extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, int ns,
@@ -486,6 +572,8 @@ extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, in
   SPR_REQUIRE(kp_extent > 0.f, "kpconv: KP_extent must be > 0");
   SPR_REQUIRE(ws_bytes >= spr_kpconv_workspace_bytes(nq, ns, cin, cout), "kpconv: workspace too small");
   unsigned char* flag = (unsigned char*)ws;
+  _Float16* wh = (_Float16*)((char*)ws + align_up((size_t)ns, 256));
+  _Float16* wl = (_Float16*)((char*)wh + align_up((size_t)32 * cin * cout * 2, 256));
   const float inv_extent = 1.0f / kp_extent;
 
   if (cin == 1 && impl == 0 && n_kp <= 16) {
@@ -501,26 +589,23 @@ extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, in
                      flag);
   SPR_LAUNCH_CHECK();
 
-  if (impl == 0 && n_kp == kKP && cin % 16 == 0) {
+  if (impl == 0 && n_kp == kKP && cin % 32 == 0 && cout % 32 == 0 && cout <= 256) {
+    const int ktot = n_kp * cin;
+    hipLaunchKernelGGL(k_w_prep, dim3(cdiv(ktot, 32), cdiv(cout, 32)), dim3(256), 0, stream, weights,
+                       ktot, cout, wh, wl);
 #define SPR_KP_ARGS                                                                         \
-  q_xyz, nq, s_xyz, ns, nbr, nbr_stride, kmax, rows_sorted, x, cin, weights, cout,          \
+  q_xyz, nq, s_xyz, ns, nbr, nbr_stride, kmax, rows_sorted, x, cin, wh, wl, cout,           \
       kernel_points, inv_extent, flag, out, stream
     if (cin % 64 == 0) {
-      // TQ = 16 (MT = 1): the 4 waves split Cout
-      if (cout == 64) return launch_mfma<64, 16, 1>(SPR_KP_ARGS);
-      if (cout == 128) return launch_mfma<64, 16, 2>(SPR_KP_ARGS);
-      if (cout == 256) return launch_mfma<64, 16, 4>(SPR_KP_ARGS);
-      if (cout == 512) return launch_mfma<64, 16, 8>(SPR_KP_ARGS);
-    } else if (cin % 32 == 0) {
-      // TQ = 32 (MT = 2): 2 n-groups
-      if (cout == 32) return launch_mfma<32, 32, 1>(SPR_KP_ARGS);
-      if (cout == 64) return launch_mfma<32, 32, 2>(SPR_KP_ARGS);
-      if (cout == 128) return launch_mfma<32, 32, 4>(SPR_KP_ARGS);
+      // TQ = 32 (MT = 2), 8 waves: 4 n-groups x 2 k-halves, every wave both m-tiles
+      if (cout == 64) return launch_mfma<64, 32, 1, 8, 2>(SPR_KP_ARGS);
+      if (cout == 128) return launch_mfma<64, 32, 2, 8, 2>(SPR_KP_ARGS);
+      if (cout == 256) return launch_mfma<64, 32, 4, 8, 2>(SPR_KP_ARGS);
     } else {
-      // CC = 16, TQ = 64 (MT = 4): each wave all n-tiles
-      if (cout == 16) return launch_mfma<16, 64, 1>(SPR_KP_ARGS);
-      if (cout == 32) return launch_mfma<16, 64, 2>(SPR_KP_ARGS);
-      if (cout == 64) return launch_mfma<16, 64, 4>(SPR_KP_ARGS);
+      // TQ = 64 (MT = 4), 8 waves: 2 n-groups
+      if (cout == 32) return launch_mfma<32, 64, 1, 8, 1>(SPR_KP_ARGS);
+      if (cout == 64) return launch_mfma<32, 64, 2, 8, 1>(SPR_KP_ARGS);
+      if (cout == 128) return launch_mfma<32, 64, 4, 8, 1>(SPR_KP_ARGS);
     }
 #undef SPR_KP_ARGS
   }
