@@ -302,19 +302,32 @@ __global__ void k_cell_scatter(const float* __restrict__ xyz, int n, const int* 
                          __int_as_float(i));
 }
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_query_table(
-    const float* __restrict__ q_xyz, const int* __restrict__ q_cu, int nq, int ns, int nb,
+// Scan kernel: no LDS, ~30 VGPRs -> the CU runs at full wave occupancy, which
+// is what hides the (L2) latency of the record stream.  Candidates inside the
+// radius are appended unsorted to a per-query scratch row in global memory
+// (fire-and-forget stores); only a query whose row is already full (more than
+// `limit` supports in range) pays for reads: it replaces the current worst
+// entry and rescans its row for the new worst.
+__device__ __forceinline__ int pick9(int k, const int (&a)[9]) {
+  int v = a[0];
+#pragma unroll
+  for (int u = 1; u < 9; ++u) v = (k == u) ? a[u] : v;
+  return v;
+}
+
+// (d2, index) packed into one u64 whose unsigned order IS the neighbour order:
+// d2 >= +0 so its bit pattern is monotone, index in the low word breaks ties.
+__device__ __forceinline__ unsigned long long nbr_key(float d2, int id) {
+  return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)id;
+}
+
+__global__ __launch_bounds__(256) void k_scan_table(
+    const float* __restrict__ q_xyz, const int* __restrict__ q_cu, int nq, int nb,
     const GridCloud* __restrict__ info, const int* __restrict__ start,
     const float4* __restrict__ rec, const int* __restrict__ err, float r2, float inv_cell,
-    int limit, int* __restrict__ out, int* max_count) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  float* l_d2 = (float*)smem;
-  int* l_id = (int*)(smem + sizeof(float) * (size_t)limit * BLOCK);
-  int* l_rb = l_id + (size_t)limit * BLOCK;   // [9][BLOCK] record-run begins
-  int* l_re = l_rb + 9 * BLOCK;               // [9][BLOCK] record-run ends
-  const int t = threadIdx.x;
-  const int i = blockIdx.x * BLOCK + t;
+    int limit, unsigned long long* __restrict__ tmp_key, int* __restrict__ kept_out,
+    int* max_count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (*err) return;
   int total = 0;
   if (i < nq) {
@@ -326,24 +339,20 @@ __global__ __launch_bounds__(BLOCK) void k_query_table(
     const int cy = cell_coord(qy, g.mn[1], inv_cell);
     const int cz = cell_coord(qz, g.mn[2], inv_cell);
     const int xlo = max(cx - 1, 0), xhi = min(cx + 1, g.dim[0] - 1);
+    int rb[9], re[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const int z = cz + k / 3 - 1, y = cy + k % 3 - 1;
       const bool in = xlo <= xhi && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
       const long long L0 = in ? grid_cell(g, xlo, y, z) : 0;
       const long long L1 = in ? grid_cell(g, xhi, y, z) + 1 : 0;
-      const int b = start[L0];
-      l_rb[k * BLOCK + t] = b;
-      l_re[k * BLOCK + t] = in ? start[L1] : b;
+      rb[k] = start[L0];
+      re[k] = in ? start[L1] : rb[k];
     }
-    // K-nearest selection without a sorted insert (whose dependent LDS
-    // read-compare-write chain costs ~limit LDS latencies per candidate):
-    // append while there is room; once full, replace the current worst entry
-    // and rescan for the new worst (independent reads, pipelined).  Rows are
-    // ordered at the end by ranking.
+    unsigned long long* row = tmp_key + (size_t)i * limit;
     int kept = 0;
-    float w_d2 = -1.f;   // current worst (largest (d2, index)) when full
-    int w_id = -1, w_pos = 0;
+    unsigned long long worst = 0;   // largest key among the kept entries
+    int w_pos = 0;
     auto consider = [&](const float4 s) {
       // nanoflann.hpp:432-440: diff = query - support; result += diff*diff
       const float dx = __fsub_rn(qx, s.x), dy = __fsub_rn(qy, s.y), dz = __fsub_rn(qz, s.z);
@@ -352,38 +361,31 @@ __global__ __launch_bounds__(BLOCK) void k_query_table(
       d2 = __fadd_rn(d2, __fmul_rn(dz, dz));
       if (!(d2 < r2)) return;  // strict, nanoflann.hpp:249
       total++;
-      const int sid = __float_as_int(s.w);
+      const unsigned long long key = nbr_key(d2, __float_as_int(s.w));
       if (kept < limit) {
-        l_d2[kept * BLOCK + t] = d2;
-        l_id[kept * BLOCK + t] = sid;
-        if (kept == 0 || nbr_less(w_d2, w_id, d2, sid)) {
-          w_d2 = d2;
-          w_id = sid;
+        row[kept] = key;
+        if (kept == 0 || key > worst) {
+          worst = key;
           w_pos = kept;
         }
         ++kept;
         return;
       }
-      if (!nbr_less(d2, sid, w_d2, w_id)) return;
-      l_d2[w_pos * BLOCK + t] = d2;
-      l_id[w_pos * BLOCK + t] = sid;
-      w_d2 = d2;
-      w_id = sid;
+      if (!(key < worst)) return;
+      row[w_pos] = key;
+      __threadfence_block();   // our own store must be visible to the rescan below
+      worst = key;
       for (int k = 0; k < limit; ++k) {
-        const float dk = l_d2[k * BLOCK + t];
-        const int ik = l_id[k * BLOCK + t];
-        if (nbr_less(w_d2, w_id, dk, ik)) {
-          w_d2 = dk;
-          w_id = ik;
+        const unsigned long long rk = row[k];
+        if (rk > worst) {
+          worst = rk;
           w_pos = k;
         }
       }
     };
-    // Stream the 9 record runs as ONE candidate sequence, 8 records in flight:
-    // the cursor (run k, position j) advances across run boundaries while the
-    // addresses are generated, so short runs do not cost a round trip each.
+    // the 9 record runs as ONE candidate sequence, 8 records in flight
     {
-      int k = 0, j = l_rb[t], e = l_re[t];
+      int k = 0, j = rb[0], e = re[0];
       while (k < 9) {
         float4 s8[8];
         bool v8[8];
@@ -391,10 +393,8 @@ __global__ __launch_bounds__(BLOCK) void k_query_table(
         for (int u = 0; u < 8; ++u) {
           while (k < 9 && j >= e) {
             ++k;
-            if (k < 9) {
-              j = l_rb[k * BLOCK + t];
-              e = l_re[k * BLOCK + t];
-            }
+            j = pick9(k, rb);
+            e = pick9(k, re);
           }
           v8[u] = k < 9;
           s8[u] = rec[v8[u] ? j : 0];
@@ -405,22 +405,51 @@ __global__ __launch_bounds__(BLOCK) void k_query_table(
           if (v8[u]) consider(s8[u]);
       }
     }
-    // rank sort: position of entry a = #{b : b < a} under the (d2, index) order
-    int* row = out + (size_t)i * limit;
-    for (int a = 0; a < kept; ++a) {
-      const float da = l_d2[a * BLOCK + t];
-      const int ia = l_id[a * BLOCK + t];
-      int rank = 0;
-      for (int b = 0; b < kept; ++b)
-        rank += nbr_less(l_d2[b * BLOCK + t], l_id[b * BLOCK + t], da, ia) ? 1 : 0;
-      row[rank] = ia;
-    }
-    for (int k = kept; k < limit; ++k) row[k] = ns;
+    kept_out[i] = kept;
   }
   int m = total;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
-  if ((t & 63) == 0 && m > 0) atomicMax(max_count, m);
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(max_count, m);
+}
+
+// Sort kernel: one thread per query row; keys staged slot-major in LDS
+// (conflict-free) and ordered by ranking, four ranks per pass over the row so
+// each LDS read feeds four compares.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_sort_rows(const unsigned long long* __restrict__ tmp_key,
+                                                     const int* __restrict__ kept_in,
+                                                     const int* __restrict__ err, int nq, int ns,
+                                                     int limit, int* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned long long* l_key = (unsigned long long*)smem;
+  const int t = threadIdx.x;
+  const int i = blockIdx.x * BLOCK + t;
+  if (*err || i >= nq) return;
+  const int kept = kept_in[i];
+  const unsigned long long* src = tmp_key + (size_t)i * limit;
+  for (int k = 0; k < kept; ++k) l_key[k * BLOCK + t] = src[k];
+  int* row = out + (size_t)i * limit;
+  constexpr unsigned long long kInf = ~0ull;
+  for (int a = 0; a < kept; a += 4) {
+    const unsigned long long k0 = l_key[a * BLOCK + t];
+    const unsigned long long k1 = a + 1 < kept ? l_key[(a + 1) * BLOCK + t] : kInf;
+    const unsigned long long k2 = a + 2 < kept ? l_key[(a + 2) * BLOCK + t] : kInf;
+    const unsigned long long k3 = a + 3 < kept ? l_key[(a + 3) * BLOCK + t] : kInf;
+    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    for (int b = 0; b < kept; ++b) {
+      const unsigned long long kb = l_key[b * BLOCK + t];
+      r0 += kb < k0 ? 1 : 0;
+      r1 += kb < k1 ? 1 : 0;
+      r2 += kb < k2 ? 1 : 0;
+      r3 += kb < k3 ? 1 : 0;
+    }
+    row[r0] = (int)(unsigned)k0;
+    if (a + 1 < kept) row[r1] = (int)(unsigned)k1;
+    if (a + 2 < kept) row[r2] = (int)(unsigned)k2;
+    if (a + 3 < kept) row[r3] = (int)(unsigned)k3;
+  }
+  for (int k = kept; k < limit; ++k) row[k] = ns;
 }
 
 __global__ void k_nbr_err2(const int* err, int* max_count) {
@@ -454,7 +483,6 @@ size_t nbr_sort_temp_bytes(int n) {
 using namespace spr;
 
 extern "C" size_t spr_radius_neighbors_workspace_bytes(int nq, int ns, int nb) {
-  (void)nq;
   const size_t N = (size_t)(ns > 0 ? ns : 1), B = (size_t)(nb > 0 ? nb : 1);
   size_t b = 0;
   b += align_up(sizeof(NbrCloud) * B, 256);
@@ -469,6 +497,9 @@ extern "C" size_t spr_radius_neighbors_workspace_bytes(int nq, int ns, int nb) {
   b += 3 * align_up(4 * (cap + 1), 256);  // count, start, cursor
   b += align_up(4 * N, 256);              // cell_of
   b += scan_temp_bytes(cap + 1);
+  const size_t Q = (size_t)(nq > 0 ? nq : 1);
+  b += align_up(8 * Q * 128, 256);        // unsorted (d2, id) key rows, limit <= 128
+  b += align_up(4 * Q, 256);              // kept counts
   return b;
 }
 
@@ -480,7 +511,7 @@ extern "C" int spr_radius_neighbors(const float* q_xyz, const int* q_cu, int nq,
   SPR_REQUIRE(nq > 0 && ns > 0 && nb >= 1, "radius_neighbors: empty input (nq=%d ns=%d)", nq, ns);
   SPR_REQUIRE(nb < 65536, "radius_neighbors: at most 65535 clouds per call");
   SPR_REQUIRE(radius > 0.f, "radius_neighbors: radius must be > 0");
-  SPR_REQUIRE(limit >= 1 && limit <= 119, "radius_neighbors: limit must be in [1,119], got %d", limit);
+  SPR_REQUIRE(limit >= 1 && limit <= 128, "radius_neighbors: limit must be in [1,128], got %d", limit);
   SPR_REQUIRE(ws_bytes >= spr_radius_neighbors_workspace_bytes(nq, ns, nb),
               "radius_neighbors: workspace too small");
   Workspace w(ws, ws_bytes);
@@ -525,16 +556,15 @@ extern "C" int spr_radius_neighbors(const float* q_xyz, const int* q_cu, int nq,
                                           stream));
     hipLaunchKernelGGL(k_cell_scatter, dim3(cdiv(ns, TB)), dim3(TB), 0, stream, s_xyz, ns, err, cell_of,
                        start, cursor, rec);
-    if ((size_t)(limit * 8 + 72) * 128 <= 65536) {
-      constexpr int BLOCK = 128;
-      hipLaunchKernelGGL(k_query_table<BLOCK>, dim3(cdiv(nq, BLOCK)), dim3(BLOCK),
-                         (size_t)(limit * 8 + 72) * BLOCK, stream, q_xyz, q_cu, nq, ns, nb, ginfo, start,
-                         rec, err, r2, inv_cell, limit, out_idx, max_count);
-    } else {
-      constexpr int BLOCK = 64;
-      hipLaunchKernelGGL(k_query_table<BLOCK>, dim3(cdiv(nq, BLOCK)), dim3(BLOCK),
-                         (size_t)(limit * 8 + 72) * BLOCK, stream, q_xyz, q_cu, nq, ns, nb, ginfo, start,
-                         rec, err, r2, inv_cell, limit, out_idx, max_count);
+    unsigned long long* tmp_key = w.take<unsigned long long>((size_t)nq * limit);
+    int* kept = w.take<int>((size_t)nq);
+    SPR_REQUIRE(kept != nullptr, "radius_neighbors: workspace carve failed (rows)");
+    hipLaunchKernelGGL(k_scan_table, dim3(cdiv(nq, 256)), dim3(256), 0, stream, q_xyz, q_cu, nq, nb, ginfo,
+                       start, rec, err, r2, inv_cell, limit, tmp_key, kept, max_count);
+    {
+      constexpr int BLOCK = 64;   // limit <= 128 -> at most 64 KB of LDS
+      hipLaunchKernelGGL(k_sort_rows<BLOCK>, dim3(cdiv(nq, BLOCK)), dim3(BLOCK), (size_t)limit * 8 * BLOCK,
+                         stream, tmp_key, kept, err, nq, ns, limit, out_idx);
     }
     hipLaunchKernelGGL(k_nbr_err2, dim3(1), dim3(1), 0, stream, err, max_count);
     SPR_LAUNCH_CHECK();
