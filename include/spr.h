@@ -133,7 +133,7 @@ int spr_linear(const float* x, int m, int k, const float* w, int n,
                const float* bias, const float* residual, int act, float* out,
                void* stream);
 /* Arithmetic of spr_linear (and of the correlation GEMMs inside the matching
- * head): 1 (default) = split-fp16 MFMA, x = hi + 2^-11 lo with fp32
+ * head): 1 (default) = split-fp16 MFMA, x = fp16 hi + fp16 lo with fp32
  * accumulation -- fp32-level accuracy (~2^-22 relative per product) at ~5x the
  * exact-f32 MFMA rate, needs |x| < 65504;  0 = exact f32 MFMA. */
 int spr_set_gemm_mode(int mode);
@@ -163,16 +163,21 @@ int spr_posemb_sine(const float* xyz, int n, int d_model, float scale,
  *   q,k,v: [T, *] f32 with row strides (in floats); head h uses columns
  *   [h*head_dim, (h+1)*head_dim); head_dim must be 32.
  *   cu [nseg+1]; kv_seg [nseg]; out [T, nhead*head_dim] (row stride o_stride)
- *   max_len_host: upper bound of any segment length (sizes the grid).
+ *   t = cu[nseg] (total tokens, host copy); max_len_host: upper bound of any
+ *   segment length (sizes the grid).  ws: spr_attn_workspace_bytes(t, nseg,
+ *   nhead, head_dim) bytes of device scratch (the split-fp16 operand planes;
+ *   may be NULL in mode 0).
  */
+size_t spr_attn_workspace_bytes(int t, int nseg, int nhead, int head_dim);
 int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k,
                         int k_stride, const float* v, int v_stride,
-                        const int* cu, const int* kv_seg, int nseg,
+                        const int* cu, const int* kv_seg, int t, int nseg,
                         int max_len_host, int nhead, int head_dim, float scale,
-                        float* out, int o_stride, void* stream);
+                        float* out, int o_stride, void* ws, size_t ws_bytes,
+                        void* stream);
 
 /* Arithmetic of the attention core: 1 (default) = split-fp16 MFMA (operands
- * carried as hi + 2^-11 lo, fp32 accumulation and softmax; fp32-level
+ * carried as fp16 hi + fp16 lo, fp32 accumulation and softmax; fp32-level
  * accuracy), 0 = exact f32 MFMA. */
 int spr_set_attn_mode(int mode);
 

@@ -34,7 +34,9 @@ SIGNATURES = {
     "spr_set_gemm_mode": (_i, [_i]),
     "spr_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "spr_posemb_sine": (_i, [_vp, _i, _i, _f, _f, _vp, _vp]),
-    "spr_attn_varlen_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _vp]),
+    "spr_attn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "spr_attn_varlen_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i,
+                                 _vp, _sz, _vp]),
     "spr_set_attn_mode": (_i, [_i]),
     "spr_match_workspace_bytes": (_sz, [_vp, _i]),
     "spr_match_dualsoftmax": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),

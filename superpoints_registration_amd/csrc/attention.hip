@@ -20,6 +20,7 @@
 //   K / V tiles of 32 keys are staged in LDS (row stride 33 / 32 words ->
 //   conflict-free fragment reads) and shared by the four waves.
 #include "spr_common.h"
+#include <type_traits>
 
 namespace spr {
 namespace {
@@ -193,36 +194,135 @@ __global__ __launch_bounds__(256) void k_attn(
 }
 
 // ---------------------------------------------------------------------------
-// Split-fp16 variant ("h3"): same structure, fp32-level accuracy, ~5x less
-// matrix-core time.  Every operand x is carried as hi = fp16(x) and
-// lo = fp16(x - hi); a.b ~= ah.bh + ah.bl + al.bh in ONE fp32 accumulator
-// (the matrix cores honour fp16 subnormals, scripts/abl/denorm.hip, so lo needs
-// no rescaling; its absolute resolution is 2^-24).
-//   S^T = K Q^T : 2 k-steps x 3 v_mfma_f32_32x32x16_f16  (head_dim 32)
-//   O^T = V^T P^T: the f32 probabilities in the S^T accumulator are converted
-//     in place -- registers 8s..8s+7 of a lane are exactly the B fragment of
-//     k-step s, with key order kappa(s,h,j) = 16s + 8(j>>2) + 4h + (j&3); the
-//     V^T A-fragment is read with the same order from a TRANSPOSED fp16 V tile
-//     (two 8-byte reads).  P is scaled by 2^10 before the split so that small
-//     probabilities stay in fp16's normal range (undone in the final 1/l).
+// Split-fp16 variant ("h3"): fp32-level accuracy, ~5x less matrix-core time.
+// Every operand x is carried as hi = fp16(x) and lo = fp16(x - hi);
+// a.b ~= ah.bh + ah.bl + al.bh in ONE fp32 accumulator (the matrix cores
+// honour fp16 subnormals, scripts/abl/denorm.hip, so lo needs no rescaling; its
+// absolute resolution is 2^-24).
+//
+// Two kernels:
+//   k_attn_pack  splits Q (pre-scaled by log2(e)/sqrt(d)), K and V ONCE per
+//     call into fp16 hi/lo planes in the workspace.  V is written TRANSPOSED
+//     ([feature][token column]) because the V^T A-fragment of O^T = V^T P^T
+//     wants 4 consecutive keys of one feature.  Token columns of segment s
+//     start at vstart(s) = (cu[s] + 8 s) & ~7 (16-byte aligned rows for the
+//     wide loads); gap and tail columns are written as zeros.
+//   k_attn_h3    streams 64-key tiles of those planes through LDS (pure 16-byte
+//     copies, no conversion in the loop) and runs, per wave of 32 queries:
+//       S^T = K Q^T : 2 key sub-tiles x 2 k-steps x 3 v_mfma_f32_32x32x16_f16
+//       online softmax, lane = query, base 2, lazy rescale; P is scaled by
+//         2^10 so small probabilities stay in fp16's normal range (cancels in
+//         the final 1/l), hi by packed RTZ conversion, lo by v_fma_mix*_f16
+//       O^T = V^T P^T: the probabilities in the S^T accumulator are converted
+//         in place -- registers 8s..8s+7 of a lane are exactly the B fragment
+//         of k-step s with key order kappa(s,h,j) = 16s + 8(j>>2) + 4h + (j&3);
+//         the V^T A-fragment is read with the same order (two 8-byte reads).
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int KT2 = 64;  // keys per tile (two 32-key MFMA sub-tiles)
 constexpr int KH = 40;   // K tile row stride in halves (80 B: conflict-free ds_read_b128)
-constexpr int VH = 36;   // V^T tile row stride in halves (72 B: conflict-free ds_read_b64)
+constexpr int VH = 72;   // V^T tile row stride in halves (144 B: 2-pass ds_read_b64)
+constexpr int PT = 64;   // token columns per pack workgroup
+constexpr int PS = 72;   // pack transposition row stride (halves)
 
-__device__ __forceinline__ void split_h(float x, _Float16& hi, _Float16& lo) {
-  hi = (_Float16)x;
-  lo = (_Float16)(x - (float)hi);
+__device__ __forceinline__ int vstart(const int* __restrict__ cu, int s) {
+  return (cu[s] + 8 * s) & ~7;
+}
+
+// One workgroup = PT token columns x all features.  tp = padded column count.
+__global__ __launch_bounds__(256) void k_attn_pack(
+    const float* __restrict__ q, int q_stride, const float* __restrict__ k, int k_stride,
+    const float* __restrict__ v, int v_stride, const int* __restrict__ cu, int nseg, int d_model,
+    int tp, float qscale, _Float16* __restrict__ qh, _Float16* __restrict__ ql,
+    _Float16* __restrict__ kh, _Float16* __restrict__ kl, _Float16* __restrict__ vth,
+    _Float16* __restrict__ vtl) {
+  __shared__ __align__(16) _Float16 Lh[128 * PS], Ll[128 * PS];
+  __shared__ int tok[PT];
+  const int tid = threadIdx.x;
+  const int col0 = blockIdx.x * PT;
+  if (tid < PT) {
+    const int c = col0 + tid;
+    // last segment whose first column is <= c
+    int lo = 0, hi = nseg;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (vstart(cu, mid) <= c) lo = mid; else hi = mid;
+    }
+    const int j = c - vstart(cu, lo);
+    tok[tid] = (j >= 0 && j < cu[lo + 1] - cu[lo]) ? cu[lo] + j : -1;
+  }
+  __syncthreads();
+  const int c4 = (tid & 31) * 4, r0 = tid >> 5;   // 4 features, 8 token rows per pass
+  for (int half = 0; half < d_model; half += 128) {
+    if (half) __syncthreads();
+#pragma unroll 2
+    for (int it = 0; it < PT / 8; ++it) {
+      const int r = it * 8 + r0;
+      const int t = tok[r];
+      const int f = half + c4;
+      float4 vq = make_float4(0.f, 0.f, 0.f, 0.f), vk = vq, vv = vq;
+      if (t >= 0) {
+        vq = *reinterpret_cast<const float4*>(q + (size_t)t * q_stride + f);
+        vk = *reinterpret_cast<const float4*>(k + (size_t)t * k_stride + f);
+        vv = *reinterpret_cast<const float4*>(v + (size_t)t * v_stride + f);
+      }
+      unsigned int ha, hb, la, lb;
+      if (t >= 0) {
+        split_pk(vq.x * qscale, vq.y * qscale, ha, la);
+        split_pk(vq.z * qscale, vq.w * qscale, hb, lb);
+        *reinterpret_cast<u32x2*>(qh + (size_t)t * d_model + f) = (u32x2){ha, hb};
+        *reinterpret_cast<u32x2*>(ql + (size_t)t * d_model + f) = (u32x2){la, lb};
+        split_pk(vk.x, vk.y, ha, la);
+        split_pk(vk.z, vk.w, hb, lb);
+        *reinterpret_cast<u32x2*>(kh + (size_t)t * d_model + f) = (u32x2){ha, hb};
+        *reinterpret_cast<u32x2*>(kl + (size_t)t * d_model + f) = (u32x2){la, lb};
+      }
+      split_pk(vv.x, vv.y, ha, la);
+      split_pk(vv.z, vv.w, hb, lb);
+      const h16x4 vh4 = __builtin_bit_cast(h16x4, (u32x2){ha, hb});
+      const h16x4 vl4 = __builtin_bit_cast(h16x4, (u32x2){la, lb});
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Lh[(c4 + e) * PS + r] = vh4[e];
+        Ll[(c4 + e) * PS + r] = vl4[e];
+      }
+    }
+    __syncthreads();
+    const int ch = (tid & 7) * 8, d0 = tid >> 3;   // 16-byte chunk, 32 feature rows per pass
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int d = it * 32 + d0;
+      if (half + d < d_model) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(Lh + d * PS + ch);
+        const u32x4 b = *reinterpret_cast<const u32x4*>(Ll + d * PS + ch);
+        *reinterpret_cast<u32x4*>(vth + (size_t)(half + d) * tp + col0 + ch) = a;
+        *reinterpret_cast<u32x4*>(vtl + (size_t)(half + d) * tp + col0 + ch) = b;
+      }
+    }
+  }
+}
+
+constexpr int QW2 = 64;    // queries per wave (two 32-query MFMA column blocks)
+constexpr int QB2 = 256;   // queries per workgroup
+
+// max over the two half-waves (lanes l and l^32) without touching LDS
+__device__ __forceinline__ float half_swap_max(float x) {
+  const unsigned int u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
 __global__ __launch_bounds__(256) void k_attn_h3(
-    const float* __restrict__ q, int q_stride, const float* __restrict__ k, int k_stride,
-    const float* __restrict__ v, int v_stride, const int* __restrict__ cu,
-    const int* __restrict__ kv_seg, int nseg, int nhead, float scale, float* __restrict__ out,
-    int o_stride) {
-  __shared__ __align__(16) _Float16 Kh[2][KT * KH], Kl[2][KT * KH];
+    const _Float16* __restrict__ qh_g, const _Float16* __restrict__ ql_g,
+    const _Float16* __restrict__ kh_g, const _Float16* __restrict__ kl_g,
+    const _Float16* __restrict__ vth_g, const _Float16* __restrict__ vtl_g, int d_model, int tp,
+    const int* __restrict__ cu, const int* __restrict__ kv_seg, int nseg, int nhead,
+    float* __restrict__ out, int o_stride) {
+  __shared__ __align__(16) _Float16 Kh[2][KT2 * KH], Kl[2][KT2 * KH];
   __shared__ __align__(16) _Float16 Vth[2][HD * VH], Vtl[2][HD * VH];
   // 1-D grid: all query tiles of one (segment, head) -- which stream the same
   // K/V -- are placed on one XCD (ids b and b+8 share an L2)
@@ -244,181 +344,212 @@ __global__ __launch_bounds__(256) void k_attn_h3(
     }
   }
   const int qbeg = cu[seg], qlen = cu[seg + 1] - qbeg;
-  const int q0 = qt * QB;
+  const int q0 = qt * QB2;
   if (q0 >= qlen) return;
   const int ks = kv_seg[seg];
   const int kbeg = cu[ks], klen = cu[ks + 1] - kbeg;
+  const int vbeg = vstart(cu, ks);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int qi = q0 + wave * QW + l31;
-  const bool qok = qi < qlen;
   const int hoff = head * HD;
 
-  // Q^T B-fragments: lane (query l31, half lh), k-step s: d = 16 s + 8 lh + j
-  h16x8 qh[2], ql[2];
-  {
-    const float sc = scale * 1.4426950408889634f;   // base-2 softmax
-    const float* qp = q + (size_t)(qbeg + (qok ? qi : 0)) * q_stride + hoff + 8 * lh;
+  // Q^T B-fragments of the wave's two 32-query blocks: lane (query l31, half
+  // lh), k-step s: d = 16 s + 8 lh + j
+  h16x8 qh[2][2], ql[2][2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+  for (int h = 0; h < 2; ++h) {
+    const int qi = min(q0 + wave * QW2 + 32 * h + l31, qlen - 1);
+    const size_t row = (size_t)(qbeg + qi) * d_model + hoff + 8 * lh;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float x = qok ? qp[16 * s + j] * sc : 0.f;
-        _Float16 a, b;
-        split_h(x, a, b);
-        qh[s][j] = a;
-        ql[s][j] = b;
-      }
+    for (int s = 0; s < 2; ++s) {
+      qh[h][s] = *reinterpret_cast<const h16x8*>(qh_g + row + 16 * s);
+      ql[h][s] = *reinterpret_cast<const h16x8*>(ql_g + row + 16 * s);
+    }
   }
 
-  f32x16 o;
+  f32x16 o[2];
+  float m_run[2] = {-INFINITY, -INFINITY};
+  f32x2 psum2[2];   // per-lane partial row sums; the two half-waves are joined at the end
 #pragma unroll
-  for (int r = 0; r < 16; ++r) o[r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int h = 0; h < 2; ++h) {
+    psum2[h] = (f32x2){0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[h][r] = 0.f;
+  }
 
-  const int sr = tid >> 3, sc4 = (tid & 7) * 4;   // staging role: key row, 4 dims
-  f32x4 kreg, vreg;
+  // staging roles: K -- key row tid>>2, 16-byte chunk tid&3; V^T -- feature row
+  // tid>>3, 16-byte chunk tid&7 (hi and lo planes each)
+  const int skr = tid >> 2, skc = (tid & 3) * 8;
+  const int svr = tid >> 3, svc = (tid & 7) * 8;
+  u32x4 rkh, rkl, rvh, rvl;
   auto fetch = [&](int kt) {
-    const int r = min(kt + sr, klen - 1);
-    const size_t row = (size_t)(kbeg + r);
-    const float* kp_ = k + row * k_stride + hoff + sc4;
-    const float* vp_ = v + row * v_stride + hoff + sc4;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(kreg) : "v"(kp_));
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vreg) : "v"(vp_));
+    const size_t krow = (size_t)(kbeg + min(kt + skr, klen - 1)) * d_model + hoff + skc;
+    const size_t vrow = (size_t)(hoff + svr) * tp + vbeg + kt + svc;
+    const _Float16 *a = kh_g + krow, *b = kl_g + krow, *c = vth_g + vrow, *d = vtl_g + vrow;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rkh) : "v"(a));
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rkl) : "v"(b));
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rvh) : "v"(c));
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rvl) : "v"(d));
   };
-  auto stash = [&](int kt, int buf) {
+  auto stash = [&](int buf) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    const bool in = kt + sr < klen;
-    h16x4 kh4, kl4;
+    *reinterpret_cast<u32x4*>(Kh[buf] + skr * KH + skc) = rkh;
+    *reinterpret_cast<u32x4*>(Kl[buf] + skr * KH + skc) = rkl;
+    *reinterpret_cast<u32x4*>(Vth[buf] + svr * VH + svc) = rvh;
+    *reinterpret_cast<u32x4*>(Vtl[buf] + svr * VH + svc) = rvl;
+  };
+
+  // One 64-key tile.  Branch-free inside (the online-softmax rescale is applied
+  // every tile) so that the compiler can run one query block's softmax VALU in
+  // the shadow of the other block's MFMAs.
+  auto tile = [&](int kt, int buf, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    // K A-fragments (shared by both query blocks)
+    h16x8 kfh[2][2], kfl[2][2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      _Float16 a, b;
-      split_h(in ? kreg[e] : 0.f, a, b);
-      kh4[e] = a;
-      kl4[e] = b;
-      split_h(in ? vreg[e] : 0.f, a, b);
-      Vth[buf][(sc4 + e) * VH + sr] = a;     // transposed: [d][key]
-      Vtl[buf][(sc4 + e) * VH + sr] = b;
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        kfh[kk][s] = *reinterpret_cast<const h16x8*>(Kh[buf] + (32 * kk + l31) * KH + 16 * s + 8 * lh);
+        kfl[kk][s] = *reinterpret_cast<const h16x8*>(Kl[buf] + (32 * kk + l31) * KH + 16 * s + 8 * lh);
+      }
+    // ---- S^T = K Q^T (rows = keys, cols = queries) ----
+    f32x16 sacc[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[h][kk][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          sacc[h][kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[kk][s], ql[h][s], sacc[h][kk], 0, 0, 0);
+          sacc[h][kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[kk][s], qh[h][s], sacc[h][kk], 0, 0, 0);
+          sacc[h][kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[kk][s], qh[h][s], sacc[h][kk], 0, 0, 0);
+        }
+      }
+    // V^T A-fragments (shared by both query blocks)
+    h16x8 vfh[2][2], vfl[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const _Float16* ph_ = Vth[buf] + l31 * VH + 32 * kk + 16 * s + 4 * lh;
+        const _Float16* pl_ = Vtl[buf] + l31 * VH + 32 * kk + 16 * s + 4 * lh;
+        const h16x4 a0 = *reinterpret_cast<const h16x4*>(ph_);
+        const h16x4 a1 = *reinterpret_cast<const h16x4*>(ph_ + 8);
+        const h16x4 b0 = *reinterpret_cast<const h16x4*>(pl_);
+        const h16x4 b1 = *reinterpret_cast<const h16x4*>(pl_ + 8);
+        vfh[kk][s] = (h16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        vfl[kk][s] = (h16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // ---- online softmax (lane = query; reg r of sub-tile kk <-> key
+      //      32 kk + (r&3) + 8 (r>>2) + 4 lh) ----
+      if (TAIL) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int j = kt + 32 * kk + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (j >= klen) sacc[h][kk][r] = -INFINITY;
+          }
+      }
+      float mx = fmaxf(sacc[h][0][0], sacc[h][1][0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[h][0][r], sacc[h][1][r]));
+      mx = half_swap_max(mx);
+      const float m_new = fmaxf(m_run[h], mx);
+      const float corr = __builtin_amdgcn_exp2f(m_run[h] - m_new);   // first tile: exp2(-inf) = 0
+      m_run[h] = m_new;
+      const f32x2 c2 = {corr, corr};
+      psum2[h] *= c2;
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        f32x2 t = {o[h][r], o[h][r + 1]};
+        t *= c2;
+        o[h][r] = t[0];
+        o[h][r + 1] = t[1];
+      }
+      // p' = 2^10 * exp2(s - m): the 2^10 keeps small probabilities inside fp16's
+      // normal range; the row sum accumulates the same scaled values, so it
+      // cancels in the final 1/l.
+      const float mshift = m_new - 10.0f;
+      const f32x2 ms2 = {mshift, mshift};
+      unsigned int ph_u[2][8], pl_u[2][8];
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 sv = {sacc[h][kk][r], sacc[h][kk][r + 1]};
+          const f32x2 dv = sv - ms2;                       // v_pk_add_f32
+          f32x2 pv;
+          pv[0] = __builtin_amdgcn_exp2f(dv[0]);
+          pv[1] = __builtin_amdgcn_exp2f(dv[1]);
+          psum2[h] += pv;                                  // v_pk_add_f32
+          const unsigned int hi_u =
+              __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(pv[0], pv[1]));
+          unsigned int lo_u;
+          asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+              "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+              : "=&v"(lo_u)
+              : "v"(hi_u), "v"(pv[0]), "v"(pv[1]));
+          ph_u[kk][r >> 1] = hi_u;
+          pl_u[kk][r >> 1] = lo_u;
+        }
+      // ---- O^T += V^T P^T ----
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const u32x4 pa = {ph_u[kk][4 * s], ph_u[kk][4 * s + 1], ph_u[kk][4 * s + 2], ph_u[kk][4 * s + 3]};
+          const u32x4 pb = {pl_u[kk][4 * s], pl_u[kk][4 * s + 1], pl_u[kk][4 * s + 2], pl_u[kk][4 * s + 3]};
+          const h16x8 pbh = __builtin_bit_cast(h16x8, pa), pbl = __builtin_bit_cast(h16x8, pb);
+          o[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[kk][s], pbl, o[h], 0, 0, 0);
+          o[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[kk][s], pbh, o[h], 0, 0, 0);
+          o[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[kk][s], pbh, o[h], 0, 0, 0);
+        }
     }
-    *reinterpret_cast<h16x4*>(Kh[buf] + sr * KH + sc4) = kh4;
-    *reinterpret_cast<h16x4*>(Kl[buf] + sr * KH + sc4) = kl4;
   };
 
   if (klen > 0) {
     fetch(0);
-    stash(0, 0);
+    stash(0);
   }
   __syncthreads();
 
-  int buf = 0;
-  for (int kt = 0; kt < klen; kt += KT, buf ^= 1) {
-    const bool more = kt + KT < klen;
-    if (more) fetch(kt + KT);
+  int buf = 0, kt = 0;
+  for (; kt + KT2 <= klen; kt += KT2, buf ^= 1) {
+    const bool more = kt + KT2 < klen;
+    if (more) fetch(kt + KT2);
     __builtin_amdgcn_sched_barrier(0);
-
-    // ---- S^T = K Q^T (rows = keys, cols = queries) ----
-    f32x16 sacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-    h16x8 kfh[2], kfl[2], vfh[2], vfl[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      kfh[s] = *reinterpret_cast<const h16x8*>(Kh[buf] + l31 * KH + 16 * s + 8 * lh);
-      kfl[s] = *reinterpret_cast<const h16x8*>(Kl[buf] + l31 * KH + 16 * s + 8 * lh);
-    }
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], ql[s], sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[s], qh[s], sacc, 0, 0, 0);
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], qh[s], sacc, 0, 0, 0);
-    }
-    // V^T A-fragments (issued early: their LDS latency hides under the softmax)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const _Float16* ph_ = Vth[buf] + l31 * VH + 16 * s + 4 * lh;
-      const _Float16* pl_ = Vtl[buf] + l31 * VH + 16 * s + 4 * lh;
-      const h16x4 a0 = *reinterpret_cast<const h16x4*>(ph_);
-      const h16x4 a1 = *reinterpret_cast<const h16x4*>(ph_ + 8);
-      const h16x4 b0 = *reinterpret_cast<const h16x4*>(pl_);
-      const h16x4 b1 = *reinterpret_cast<const h16x4*>(pl_ + 8);
-      vfh[s] = (h16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-      vfl[s] = (h16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-    }
-
-    // ---- online softmax (lane = query; reg r <-> key (r&3) + 8 (r>>2) + 4 lh) ----
-    if (kt + KT > klen) {             // wave-uniform: only the last tile has a tail
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int j = kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (j >= klen) sacc[r] = -INFINITY;
-      }
-    }
-    float mx = sacc[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    // the running maximum rarely moves after the first tiles: skip the rescale
-    // of the 16 output registers unless some lane of the wave needs it
-    if (__ballot(m_new != m_run) != 0ull) {
-      const float corr = __builtin_amdgcn_exp2f(m_run - m_new);
-      l_run *= corr;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[r] *= corr;
-      m_run = m_new;
-    }
-    // p' = 2^10 * exp2(s - m): the 2^10 keeps small probabilities inside fp16's
-    // normal range; l_run accumulates the same scaled values, so it cancels in
-    // the final 1/l.  hi by packed round-toward-zero conversion, lo = p' - hi.
-    const float mshift = m_run - 10.0f;
-    float psum = 0.f;
-    unsigned int ph_u[8], pl_u[8];
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      const float p0 = __builtin_amdgcn_exp2f(sacc[r] - mshift);
-      const float p1 = __builtin_amdgcn_exp2f(sacc[r + 1] - mshift);
-      psum += p0 + p1;
-      const h16x2 hi = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(p0, p1));
-      const h16x2 lo = __builtin_bit_cast(h16x2, __builtin_amdgcn_cvt_pkrtz(p0 - (float)hi[0], p1 - (float)hi[1]));
-      ph_u[r >> 1] = __builtin_bit_cast(unsigned int, hi);
-      pl_u[r >> 1] = __builtin_bit_cast(unsigned int, lo);
-    }
-    psum += __shfl_xor(psum, 32, 64);
-    l_run += psum;
-    h16x8 pbh[2], pbl[2];   // registers 8s..8s+7 = B fragment of k-step s
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const u32x4 a = {ph_u[4 * s2], ph_u[4 * s2 + 1], ph_u[4 * s2 + 2], ph_u[4 * s2 + 3]};
-      const u32x4 b = {pl_u[4 * s2], pl_u[4 * s2 + 1], pl_u[4 * s2 + 2], pl_u[4 * s2 + 3]};
-      pbh[s2] = __builtin_bit_cast(h16x8, a);
-      pbl[s2] = __builtin_bit_cast(h16x8, b);
-    }
-
-    // ---- O^T += V^T P^T ----
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbl[s], o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[s], pbh[s], o, 0, 0, 0);
-      o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbh[s], o, 0, 0, 0);
-    }
+    tile(kt, buf, std::false_type{});
     __builtin_amdgcn_sched_barrier(0);
-    if (more) stash(kt + KT, buf ^ 1);
+    if (more) stash(buf ^ 1);
     __syncthreads();
   }
+  if (kt < klen) tile(kt, buf, std::true_type{});
 
-  if (qok) {
-    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-    float* op = out + (size_t)(qbeg + qi) * o_stride + hoff;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4 w4;
-      w4.x = o[4 * g + 0] * inv;
-      w4.y = o[4 * g + 1] * inv;
-      w4.z = o[4 * g + 2] * inv;
-      w4.w = o[4 * g + 3] * inv;
-      *reinterpret_cast<float4*>(op + 8 * g + 4 * lh) = w4;
+  for (int h = 0; h < 2; ++h) {
+    float l_run = psum2[h][0] + psum2[h][1];
+    l_run += __shfl_xor(l_run, 32, 64);
+    const int qi = q0 + wave * QW2 + 32 * h + l31;
+    if (qi < qlen) {
+      const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+      float* op = out + (size_t)(qbeg + qi) * o_stride + hoff;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 w4;
+        w4.x = o[h][4 * g + 0] * inv;
+        w4.y = o[h][4 * g + 1] * inv;
+        w4.z = o[h][4 * g + 2] * inv;
+        w4.w = o[h][4 * g + 3] * inv;
+        *reinterpret_cast<float4*>(op + 8 * g + 4 * lh) = w4;
+      }
     }
   }
 }
@@ -430,24 +561,50 @@ static int g_attn_mode = 1;   // 1 = split-fp16 (default), 0 = exact f32 MFMA
 
 using namespace spr;
 
+static size_t attn_tp(int t, int nseg) { return align_up((size_t)t + 8 * (size_t)nseg + KT2, PT); }
+
+extern "C" size_t spr_attn_workspace_bytes(int t, int nseg, int nhead, int head_dim) {
+  if (t < 0 || nseg < 0 || nhead < 0 || head_dim < 0) return 0;
+  const size_t d = (size_t)nhead * head_dim;
+  return 4 * align_up((size_t)(t > 0 ? t : 1) * d * 2, 256) + 2 * align_up(d * attn_tp(t, nseg) * 2, 256);
+}
+
 extern "C" int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k, int k_stride,
                                    const float* v, int v_stride, const int* cu,
-                                   const int* kv_seg, int nseg, int max_len_host, int nhead,
-                                   int head_dim, float scale, float* out, int o_stride,
-                                   void* stream_) {
+                                   const int* kv_seg, int t, int nseg, int max_len_host, int nhead,
+                                   int head_dim, float scale, float* out, int o_stride, void* ws,
+                                   size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(head_dim == HD, "attention: head_dim must be %d (got %d)", HD, head_dim);
-  SPR_REQUIRE(nseg >= 1 && nhead >= 1 && max_len_host >= 1, "attention: bad sizes");
+  SPR_REQUIRE(t >= 1 && nseg >= 1 && nhead >= 1 && max_len_host >= 1, "attention: bad sizes");
   SPR_REQUIRE(q_stride % 4 == 0 && k_stride % 4 == 0 && v_stride % 4 == 0 && o_stride % 4 == 0,
               "attention: row strides must be multiples of 4 floats");
   SPR_REQUIRE((long)cdiv(max_len_host, QB) * nhead * nseg < (1l << 31), "attention: grid too large");
   dim3 grid(cdiv(max_len_host, QB) * nhead * nseg);
-  if (spr::g_attn_mode == 1)
-    hipLaunchKernelGGL(k_attn_h3, grid, dim3(256), 0, stream, q, q_stride, k, k_stride, v, v_stride, cu,
-                       kv_seg, nseg, nhead, scale, out, o_stride);
-  else
+  if (spr::g_attn_mode == 1) {
+    grid = dim3(cdiv(max_len_host, QB2) * nhead * nseg);
+    const int d_model = nhead * head_dim;
+    const size_t tp = attn_tp(t, nseg);
+    SPR_REQUIRE(tp < (1ul << 31), "attention: too many tokens");
+    SPR_REQUIRE(ws != nullptr && ws_bytes >= spr_attn_workspace_bytes(t, nseg, nhead, head_dim),
+                "attention: workspace too small (%zu bytes given)", ws_bytes);
+    Workspace w(ws, ws_bytes);
+    _Float16* qh = w.take<_Float16>((size_t)t * d_model);
+    _Float16* ql = w.take<_Float16>((size_t)t * d_model);
+    _Float16* kh = w.take<_Float16>((size_t)t * d_model);
+    _Float16* kl = w.take<_Float16>((size_t)t * d_model);
+    _Float16* vth = w.take<_Float16>((size_t)d_model * tp);
+    _Float16* vtl = w.take<_Float16>((size_t)d_model * tp);
+    SPR_REQUIRE(vtl != nullptr, "attention: workspace carve failed");
+    hipLaunchKernelGGL(k_attn_pack, dim3((unsigned)(tp / PT)), dim3(256), 0, stream, q, q_stride, k, k_stride,
+                       v, v_stride, cu, nseg, d_model, (int)tp, scale * 1.4426950408889634f, qh, ql, kh,
+                       kl, vth, vtl);
+    hipLaunchKernelGGL(k_attn_h3, grid, dim3(256), 0, stream, qh, ql, kh, kl, vth, vtl, d_model, (int)tp,
+                       cu, kv_seg, nseg, nhead, out, o_stride);
+  } else {
     hipLaunchKernelGGL(k_attn, grid, dim3(256), 0, stream, q, q_stride, k, k_stride, v, v_stride, cu,
                        kv_seg, nseg, nhead, scale, out, o_stride);
+  }
   SPR_LAUNCH_CHECK();
   return 0;
 }

@@ -360,12 +360,19 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
           const int p = 4 * j4 + r;
           typedef typename VecH<NTC>::type hv_t;
           hv_t hh, ll;
-#pragma unroll
-          for (int t = 0; t < NTC; ++t) {
-            const float v = acc1[t][r];
-            const _Float16 h = (_Float16)v;
-            hh[t] = h;
-            ll[t] = (_Float16)(v - (float)h);
+          if constexpr (NTC == 2) {
+            unsigned int hu, lu;
+            split_pk(acc1[0][r], acc1[1][r], hu, lu);
+            hh = __builtin_bit_cast(hv_t, hu);
+            ll = __builtin_bit_cast(hv_t, lu);
+          } else {
+            static_assert(NTC == 4, "NTC is 2 or 4");
+            typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+            unsigned int h0, l0, h1, l1;
+            split_pk(acc1[0][r], acc1[1][r], h0, l0);
+            split_pk(acc1[2][r], acc1[3][r], h1, l1);
+            hh = __builtin_bit_cast(hv_t, (u2_t){h0, h1});
+            ll = __builtin_bit_cast(hv_t, (u2_t){l0, l1});
           }
           if (p < kKP) {
             *reinterpret_cast<hv_t*>(wfh + ql * SH + p * CC + NTC * p16) = hh;

@@ -174,20 +174,25 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt(
 // normalised, O(10)); spr_set_gemm_mode(0) selects the exact-f32 kernel.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int HS = 40;                 // LDS row stride in halves (BK = 32 + 8 pad)
 
 template <int BM, int BN, int WM, int WN, int ACT, bool RES>
-__global__ __launch_bounds__(256) void k_gemm_nt_h3(
+__global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
     const float* __restrict__ X, int M, int K, const float* __restrict__ Wt, int N,
     const float* __restrict__ bias, const float* __restrict__ residual,
     float* __restrict__ out) {
-  static_assert(WM * WN == 4, "4 waves");
+  constexpr int NT = WM * WN * 64;      // threads (4 or 8 waves)
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);   // 32x32 sub-tiles per wave
   constexpr int A_F4 = BM * BK / 4, B_F4 = BN * BK / 4;
-  constexpr int A_PT = A_F4 / 256, B_PT = B_F4 / 256;
-  static_assert(A_F4 % 256 == 0 && B_F4 % 256 == 0, "slab must divide over 256 threads");
-  __shared__ __align__(16) _Float16 Ah[BM * HS], Al[BM * HS], Bh[BN * HS], Bl[BN * HS];
+  constexpr int A_PT = A_F4 / NT, B_PT = B_F4 / NT;
+  static_assert(A_F4 % NT == 0 && B_F4 % NT == 0, "slab must divide over the threads");
+  extern __shared__ __align__(16) unsigned char gemm_smem[];
+  _Float16* Ah = reinterpret_cast<_Float16*>(gemm_smem);
+  _Float16* Al = Ah + BM * HS;
+  _Float16* Bh = Al + BM * HS;
+  _Float16* Bl = Bh + BN * HS;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WN, wn = wave % WN;
   // 1-D grid, XCD-swizzled: the column tiles of one row panel share an L2
@@ -208,45 +213,42 @@ __global__ __launch_bounds__(256) void k_gemm_nt_h3(
   auto load_slab = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
-      const int f = tid + i * 256;
+      const int f = tid + i * NT;
       const int r = f / (BK / 4), c4 = f % (BK / 4);
       const float* p = X + (size_t)min(m0 + r, M - 1) * K + k0 + c4 * 4;
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[i]) : "v"(p));
     }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
-      const int f = tid + i * 256;
+      const int f = tid + i * NT;
       const int r = f / (BK / 4), c4 = f % (BK / 4);
       const float* p = Wt + (size_t)min(n0 + r, N - 1) * K + k0 + c4 * 4;
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[i]) : "v"(p));
     }
   };
-  auto split_store = [&](const f32x4& v, bool in, _Float16* hi, _Float16* lo) {
-    f16x4 h, l;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float x = in ? v[e] : 0.f;
-      const _Float16 xh = (_Float16)x;
-      h[e] = xh;
-      l[e] = (_Float16)(x - (float)xh);
-    }
-    *reinterpret_cast<f16x4*>(hi) = h;
-    *reinterpret_cast<f16x4*>(lo) = l;
+  // rows past M / N are clamped on the load side: they produce finite garbage
+  // in accumulator rows / columns that store_tile never writes
+  auto split_store = [&](const f32x4& v, _Float16* hi, _Float16* lo) {
+    unsigned int h0, h1, l0, l1;
+    split_pk(v[0], v[1], h0, l0);
+    split_pk(v[2], v[3], h1, l1);
+    *reinterpret_cast<u32x2*>(hi) = (u32x2){h0, h1};
+    *reinterpret_cast<u32x2*>(lo) = (u32x2){l0, l1};
   };
   auto store_slab = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
-      const int f = tid + i * 256;
+      const int f = tid + i * NT;
       const int r = f / (BK / 4), c4 = f % (BK / 4);
-      split_store(ra[i], m0 + r < M, Ah + r * HS + c4 * 4, Al + r * HS + c4 * 4);
+      split_store(ra[i], Ah + r * HS + c4 * 4, Al + r * HS + c4 * 4);
     }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
-      const int f = tid + i * 256;
+      const int f = tid + i * NT;
       const int r = f / (BK / 4), c4 = f % (BK / 4);
-      split_store(rb[i], n0 + r < N, Bh + r * HS + c4 * 4, Bl + r * HS + c4 * 4);
+      split_store(rb[i], Bh + r * HS + c4 * 4, Bl + r * HS + c4 * 4);
     }
   };
 
@@ -383,14 +385,26 @@ template <int ACT, bool RES>
 int launch_gemm(const float* x, int m, int k, const float* w, int n, const float* bias,
                 const float* residual, float* out, hipStream_t stream) {
   if (spr::g_gemm_mode == 1) {
-    // 128x64 tiles (2 accumulator pairs per wave) keep the kernel at 3 waves/SIMD;
-    // 128x128 (4 pairs, >256 registers) drops to 1 wave/SIMD and measured 1.4x slower
-    if (n > 32) {
+    // LDS bytes of a BM x BN tile's slab (hi + lo planes of both operands)
+    auto lds = [](int bm, int bn) { return (size_t)(bm + bn) * spr::HS * 2 * sizeof(_Float16); };
+    if (n >= 256 && m >= 256) {
+      // 256x256 tiles, 8 waves of 64x128: ~64 flop per operand byte fetched from
+      // L2 (the 128-wide tiles below need 2-4x the L2 traffic and are bound by it)
+      auto kern = spr::k_gemm_nt_h3<256, 256, 4, 2, ACT, RES>;
+      static bool attr_done = false;
+      if (!attr_done) {
+        SPR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)lds(256, 256)));
+        attr_done = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(cdiv(n, 256) * cdiv(m, 256)), dim3(512), lds(256, 256), stream, x, m, k,
+                         w, n, bias, residual, out);
+    } else if (n > 32) {
       hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 64, 4, 1, ACT, RES>), dim3(cdiv(n, 64) * cdiv(m, 128)),
-                         dim3(256), 0, stream, x, m, k, w, n, bias, residual, out);
+                         dim3(256), lds(128, 64), stream, x, m, k, w, n, bias, residual, out);
     } else {
       hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 32, 4, 1, ACT, RES>), dim3(cdiv(n, 32) * cdiv(m, 128)),
-                         dim3(256), 0, stream, x, m, k, w, n, bias, residual, out);
+                         dim3(256), lds(128, 32), stream, x, m, k, w, n, bias, residual, out);
     }
   } else if (n % 64 == 0) {
     hipLaunchKernelGGL((spr::k_gemm_nt<2, 2, ACT, RES>), dim3((n / 64) * cdiv(m, 64)), dim3(256), 0, stream,

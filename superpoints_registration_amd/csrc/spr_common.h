@@ -92,6 +92,20 @@ __device__ __forceinline__ int xcd_swizzle(int b, int nwg) {
   return base + idx;
 }
 
+// Split-fp16 operand: hi = fp16(x) (RNE, packed convert), lo = fp16(x - hi) with
+// the subtraction and the narrowing done by ONE mixed-precision FMA per
+// element (v_fma_mixlo/hi_f16 widen the fp16 operand inside the ALU).
+// hi_u / lo_u hold (a, b) as packed halves.
+typedef _Float16 spr_h16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pk(float a, float b, unsigned int& hi_u, unsigned int& lo_u) {
+  const spr_h16x2 hi = {(_Float16)a, (_Float16)b};
+  hi_u = __builtin_bit_cast(unsigned int, hi);
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(lo_u)
+      : "v"(hi_u), "v"(a), "v"(b));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -246,10 +246,12 @@ def attention(q, k, v, cu, kv_seg, max_len: int, nhead: int, out=None) -> torch.
     nseg = cu.numel() - 1
     if out is None:
         out = torch.empty((T, d), dtype=torch.float32, device=q.device)
-    _lib.check(_lib.lib().spr_attn_varlen_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v),
-                                              v.stride(0), _ptr(cu), _ptr(kv_seg), nseg, int(max_len),
-                                              nhead, hd, 1.0 / math.sqrt(hd), _ptr(out), out.stride(0),
-                                              _stream(q)), "spr_attn_varlen_fwd")
+    L = _lib.lib()
+    ws = _workspace(L.spr_attn_workspace_bytes(T, nseg, nhead, hd), q.device)
+    _lib.check(L.spr_attn_varlen_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0),
+                                     _ptr(cu), _ptr(kv_seg), T, nseg, int(max_len), nhead, hd,
+                                     1.0 / math.sqrt(hd), _ptr(out), out.stride(0), _ptr(ws), ws.numel(),
+                                     _stream(q)), "spr_attn_varlen_fwd")
     return out
 
 

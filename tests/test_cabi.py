@@ -41,7 +41,8 @@ def test_host_side_argument_validation_needs_no_gpu():
     L = _lib.lib()
     rc = L.spr_linear(None, 0, 32, None, 32, None, None, 0, None, None)
     assert rc != 0 and b"linear" in L.spr_last_error()
-    rc = L.spr_attn_varlen_fwd(None, 256, None, 256, None, 256, None, None, 2, 10, 8, 64, 0.1, None, 256, None)
+    rc = L.spr_attn_varlen_fwd(None, 256, None, 256, None, 256, None, None, 20, 2, 10, 8, 64, 0.1, None, 256,
+                               None, 0, None)
     assert rc != 0 and b"head_dim" in L.spr_last_error()
 
 
