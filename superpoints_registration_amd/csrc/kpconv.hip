@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "spr_common.h"
+#include <cstdlib>
 
 namespace spr {
 namespace {
@@ -135,27 +136,32 @@ __global__ __launch_bounds__(256) void k_kpconv_cin1(
 
 // ---------------------------------------------------------------------------
 // Weight preparation for phase 2 of the fused kernel: W [15*cin, cout] f32 ->
-// Wt_hi / Wt_lo [cout][15*cin] fp16 (w = hi + lo, lo = fp16(w - hi)); a lane
-// then reads 8 consecutive k of one output channel with one 16-byte load.
-__global__ void k_w_prep(const float* __restrict__ W, int kt, int cout, _Float16* __restrict__ Wh,
-                         _Float16* __restrict__ Wl) {
-  __shared__ float tile[32][33];
-  const int k0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 32 x 8
-  for (int r = ty; r < 32; r += 8) {
-    const int k = k0 + r, o = o0 + tx;
-    tile[r][tx] = (k < kt && o < cout) ? W[(size_t)k * cout + o] : 0.f;
-  }
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int o = o0 + r, k = k0 + tx;
-    if (o < cout && k < kt) {
-      const float w = tile[tx][r];
-      const _Float16 h = (_Float16)w;
-      Wh[(size_t)o * kt + k] = h;
-      Wl[(size_t)o * kt + k] = (_Float16)(w - (float)h);
-    }
-  }
+// hi / lo fp16 planes (w = hi + lo, lo = fp16(w - hi)) in FRAGMENT ORDER: the
+// B operand of one v_mfma_f32_16x16x32_f16 (16 output channels x 32 k) is 64
+// lanes x 8 halves = 1 KiB contiguous, so a wave's 16-byte-per-lane load
+// covers eight full 128-byte lines instead of sixteen 64-byte pieces of
+// sixteen different rows.
+//   index = (((chunk * (cout/16) + nt) * KS + ks) * 64 + lane) * 8 + e
+//   lane = (j4 << 4) | p16;  n = 16 nt + p16;  kk = 32 ks + 8 j4 + e (inside the
+//   chunk's [15 x cc] block): kernel point kk / cc, channel chunk * cc + kk % cc
+__global__ void k_w_prep(const float* __restrict__ W, int cin, int cout, int cc,
+                         _Float16* __restrict__ Wh, _Float16* __restrict__ Wl) {
+  const int total = kKP * cin * cout;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int KS = kKP * cc / 32, NT = cout / 16;
+  const int e = i & 7, lane = (i >> 3) & 63;
+  int r = i >> 9;
+  const int ks = r % KS;
+  r /= KS;
+  const int nt = r % NT, chunk = r / NT;
+  const int p16 = lane & 15, j4 = lane >> 4;
+  const int kk = 32 * ks + 8 * j4 + e;
+  const int p = kk / cc, c = chunk * cc + kk % cc;
+  const float w = W[((size_t)p * cin + c) * cout + 16 * nt + p16];
+  const _Float16 h = (_Float16)w;
+  Wh[i] = h;
+  Wl[i] = (_Float16)(w - (float)h);
 }
 
 __device__ __forceinline__ void wait_vm(int n) {   // n folds to a constant after unrolling
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
     for (int qi = 0; qi < QPW; ++qi) {
       const int* row = lidx + (wave * QPW + qi) * KP;
       int nb = nblk;
-      if (rows_sorted) {   // valid count = position of the first shadow entry
+      if (rows_sorted & 1) {   // valid count = position of the first shadow entry
         int v = 0;
         for (int k = lane; k < KP; k += 64) v += (row[k] >= 0 && row[k] < ns) ? 1 : 0;
         v += __shfl_xor(v, 1, 64);
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
     if (lane == 0) lnit[wave] = n_it;
   }
   __syncthreads();
-  const int n_items = lnit[wave];
+  const int n_items = (rows_sorted & 256) ? 0 : lnit[wave];   // TEMP ablation
   const int* my_items = litem + wave * QPW * nblk;
 
   // kernel point of this lane (lane 15 of each 16 is padding)
@@ -299,7 +305,6 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
   for (int m = 0; m < MTW; ++m)
 #pragma unroll
     for (int t = 0; t < NTW; ++t) acc2[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int ktot = kKP * cin;
 
   for (int c0 = 0; c0 < cin; c0 += CC) {
     // ------------------------------ phase 1 --------------------------------
@@ -411,15 +416,16 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
       static_assert(NBATCH % D == 0 && NBATCH >= 2 * D && (D - 1) * LPB <= 16, "ring shape");
       const _Float16* ah_row = wfh + (mt * 16 + p16) * SH + 8 * j4;
       const _Float16* al_row = wfl + (mt * 16 + p16) * SH + 8 * j4;
-      const size_t wofs = (size_t)((ng * NTW) * 16 + p16) * ktot + c0 + 8 * j4;
+      constexpr int KS = KW / 32;                                  // k-steps per channel chunk
+      // fragment-order planes (k_w_prep): 512 halves per (chunk, n-tile, k-step)
+      const size_t wofs = ((size_t)(c0 / CC) * (cout / 16) + ng * NTW) * KS * 512 + lane * 8;
       kh8 bh[D][NTW], bl[D][NTW];
       auto load_step = [&](int ks, kh8 (&dh)[NTW], kh8 (&dl)[NTW]) {
-        const int kk0 = 32 * (ks0 + ks);                            // wave-uniform, inside one kernel point
-        const size_t gk = wofs + (size_t)(kk0 / CC) * cin + (kk0 % CC);
+        const size_t gk = wofs + (size_t)(ks0 + ks) * 512;
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-          const _Float16* ph = Wh + gk + (size_t)t * 16 * ktot;
-          const _Float16* pl = Wl + gk + (size_t)t * 16 * ktot;
+          const _Float16* ph = Wh + gk + (size_t)t * KS * 512;
+          const _Float16* pl = Wl + gk + (size_t)t * KS * 512;
           asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dh[t]) : "v"(ph));
           asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dl[t]) : "v"(pl));
         }
@@ -437,6 +443,7 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
           }
         }
       };
+      if (rows_sorted & 512) goto skip2;   // TEMP ablation
       wait_vm(0);
 #pragma unroll
       for (int d = 0; d < D; ++d) load_step(d, bh[d], bl[d]);
@@ -456,6 +463,7 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
         __builtin_amdgcn_sched_barrier(0);
         mma_step(NBATCH - D + d, bh[d], bl[d]);
       }
+    skip2:;
     }
     __syncthreads();
   }
@@ -598,11 +606,12 @@ extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, in
 
   if (impl == 0 && n_kp == kKP && cin % 32 == 0 && cout % 32 == 0 && cout <= 256) {
     const int ktot = n_kp * cin;
-    hipLaunchKernelGGL(k_w_prep, dim3(cdiv(ktot, 32), cdiv(cout, 32)), dim3(256), 0, stream, weights,
-                       ktot, cout, wh, wl);
+    hipLaunchKernelGGL(k_w_prep, dim3(cdiv((long)ktot * cout, 256)), dim3(256), 0, stream, weights, cin, cout,
+                       cin % 64 == 0 ? 64 : 32, wh, wl);
 #define SPR_KP_ARGS                                                                         \
-  q_xyz, nq, s_xyz, ns, nbr, nbr_stride, kmax, rows_sorted, x, cin, wh, wl, cout,           \
+  q_xyz, nq, s_xyz, ns, nbr, nbr_stride, kmax, rows_sorted | kp_abl, x, cin, wh, wl, cout,           \
       kernel_points, inv_extent, flag, out, stream
+    static const int kp_abl = getenv("SPR_KP_ABL") ? atoi(getenv("SPR_KP_ABL")) << 8 : 0;
     if (cin % 64 == 0) {
       // TQ = 32 (MT = 2), 8 waves: 4 n-groups x 2 k-halves, every wave both m-tiles
       if (cout == 64) return launch_mfma<64, 32, 1, 8, 2>(SPR_KP_ARGS);
