@@ -30,15 +30,17 @@
 #include <vector>
 
 #include "spr_common.h"
-#include <cstdlib>
 
 namespace spr {
 namespace {
 
 constexpr int kKP = 15;  // kernel points handled by the MFMA path (padded to 16)
 
-__global__ void k_rowflag(const float* __restrict__ x, int ns, int cin,
-                          unsigned char* __restrict__ flag) {
+// Per support point: flag = (sum of its features > 0) (the reference's neighbour
+// count, kpconv_blocks.py:399-404) and one 16-byte record {x, y, z, flag} so
+// that the fused kernel fetches a neighbour's position and flag with ONE load.
+__global__ void k_rowflag(const float* __restrict__ x, const float* __restrict__ s_xyz, int ns,
+                          int cin, unsigned char* __restrict__ flag, float4* __restrict__ sxf) {
   // one wave per row
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
@@ -46,7 +48,12 @@ __global__ void k_rowflag(const float* __restrict__ x, int ns, int cin,
   float s = 0.f;
   for (int c = lane; c < cin; c += 64) s += x[(size_t)row * cin + c];
   s = wave_sum(s);
-  if (lane == 0) flag[row] = s > 0.f ? 1 : 0;
+  if (lane == 0) {
+    const int f = s > 0.f ? 1 : 0;
+    flag[row] = (unsigned char)f;
+    sxf[row] = make_float4(s_xyz[3 * (size_t)row], s_xyz[3 * (size_t)row + 1],
+                           s_xyz[3 * (size_t)row + 2], __int_as_float(f));
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -214,34 +221,34 @@ template <> struct VecH<4> { typedef _Float16 type __attribute__((ext_vector_typ
 template <int NTC>
 struct KpItem {
   int idx[4];
-  float sp[4][3];   // neighbour xyz, one dwordx3 per k-step
+  float4 sp[4];     // neighbour {x, y, z, flag bits}, one 16-byte load per k-step
   float b[4][NTC];
   float qx, qy, qz;
-  int fl[4];
 };
 
-template <int CC, int TQ, int NTW, int NW, int SK>
-__global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
+template <int CC, int TQ, int NTW, int NW, int SK, int P1W>
+__global__ __launch_bounds__(64 * P1W) void k_kpconv_mfma(
     const float* __restrict__ q_xyz, int nq, const float* __restrict__ s_xyz, int ns,
     const int* __restrict__ nbr, int nbr_stride, int kmax, int rows_sorted,
     const float* __restrict__ x, int cin, const _Float16* __restrict__ Wh,
     const _Float16* __restrict__ Wl, int cout, const float* __restrict__ kpts, float inv_extent,
-    const unsigned char* __restrict__ flag, float* __restrict__ out) {
+    const float4* __restrict__ sxf, float* __restrict__ out) {
   constexpr int NTC = CC / 16;
   constexpr int MT = TQ / 16;
   constexpr int KW = kKP * CC;       // phase-2 K per chunk
   constexpr int SH = KW + 16;        // LDS row stride in halves: conflict-free ds_read_b128
-  constexpr int QPW = TQ / NW;       // queries per wave in phase 1
-  constexpr int NTHR = 64 * NW;
+  constexpr int QPW = TQ / P1W;      // queries per wave in phase 1
+  constexpr int NTHR = 64 * P1W;
+  static_assert(P1W >= NW && TQ % P1W == 0, "phase-1 waves");
   extern __shared__ __align__(16) unsigned char lds_raw[];
   _Float16* wfh = (_Float16*)lds_raw;                 // [TQ][SH] hi
   _Float16* wfl = wfh + TQ * SH;                      // [TQ][SH] lo
   int* lcnt = (int*)(wfl + TQ * SH);                  // [TQ]
-  int* lnit = lcnt + TQ;                              // [NW] live items per wave
-  int* litem = lnit + NW;                             // [NW][QPW * nblk] (qi << 8) | (last << 7) | b
+  int* lnit = lcnt + TQ;                              // [P1W] live items per wave
+  int* litem = lnit + P1W;                            // [P1W][QPW * nblk] (qi << 8) | (last << 7) | b
   const int nblk = (kmax + 15) >> 4;                  // neighbour blocks per query
   const int KP = nblk * 16;
-  int* lidx = litem + NW * QPW * nblk;                // [TQ][KP] neighbour indices of the tile
+  int* lidx = litem + P1W * QPW * nblk;               // [TQ][KP] neighbour indices of the tile
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -262,15 +269,13 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
     for (int qi = 0; qi < QPW; ++qi) {
       const int* row = lidx + (wave * QPW + qi) * KP;
       int nb = nblk;
-      if (rows_sorted & 1) {   // valid count = position of the first shadow entry
-        int v = 0;
-        for (int k = lane; k < KP; k += 64) v += (row[k] >= 0 && row[k] < ns) ? 1 : 0;
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
+      if (rows_sorted) {   // valid count = position of the first shadow entry
+        int v = 0;   // one ballot per 64 slots instead of a shuffle tree
+        for (int k0 = 0; k0 < KP; k0 += 64) {
+          const int k = k0 + lane;
+          const bool ok = k < KP && row[min(k, KP - 1)] >= 0 && row[min(k, KP - 1)] < ns;
+          v += __popcll(__ballot(ok));
+        }
         nb = max(1, (v + 15) >> 4);
       }
       if (lane < nb) litem[wave * QPW * nblk + n_it + lane] = (qi << 8) | ((lane == nb - 1) ? 128 : 0) | lane;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
     if (lane == 0) lnit[wave] = n_it;
   }
   __syncthreads();
-  const int n_items = (rows_sorted & 256) ? 0 : lnit[wave];   // TEMP ablation
+  const int n_items = lnit[wave];
   const int* my_items = litem + wave * QPW * nblk;
 
   // kernel point of this lane (lane 15 of each 16 is padding)
@@ -328,14 +333,11 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
         I.idx[s] = id_;
         const bool ok = id_ >= 0 && id_ < ns;
         const size_t id = ok ? (size_t)id_ : 0;
-        I.sp[s][0] = s_xyz[3 * id];
-        I.sp[s][1] = s_xyz[3 * id + 1];
-        I.sp[s][2] = s_xyz[3 * id + 2];
+        I.sp[s] = sxf[id];
         typedef typename VecF<NTC>::type vec_t;
         const vec_t xv = *reinterpret_cast<const vec_t*>(x + id * cin + c0 + NTC * p16);
 #pragma unroll
         for (int t = 0; t < NTC; ++t) I.b[s][t] = xv[t];
-        I.fl[s] = (int)flag[id];
       }
     };
     // consume item `it`; flush the query's accumulators after its last block
@@ -345,16 +347,16 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const bool ok = I.idx[s] >= 0 && I.idx[s] < ns;
-        const float dx = (I.sp[s][0] - I.qx) - kx, dy = (I.sp[s][1] - I.qy) - ky,
-                    dz = (I.sp[s][2] - I.qz) - kz;
+        const float dx = (I.sp[s].x - I.qx) - kx, dy = (I.sp[s].y - I.qy) - ky,
+                    dz = (I.sp[s].z - I.qz) - kz;
         // v_sqrt_f32 (1 ulp) instead of the correctly-rounded expansion
         float w = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
         if (!ok || p16 >= kKP) w = 0.f;
-        cnt += (ok && c0 == 0 && p16 == 0) ? I.fl[s] : 0;
+        cnt += (ok && c0 == 0 && p16 == 0) ? __float_as_int(I.sp[s].w) : 0;
 #pragma unroll
         for (int t = 0; t < NTC; ++t) {
-          const float bv = ok ? I.b[s][t] : 0.f;
-          acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, bv, acc1[t], 0, 0, 0);
+          // a shadow slot gathered row 0 (finite) and has w = 0
+          acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, I.b[s][t], acc1[t], 0, 0, 0);
         }
       }
       if (code & 128) {   // last live block of the query
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
     }
     __syncthreads();
     // ------------------------------ phase 2 --------------------------------
-    {
+    if (wave < NW) {   // the first NW waves contract; extra phase-1 waves wait at the barrier
       constexpr int NBATCH = KW / 32 / SK;                          // 32-deep k-steps of this wave
       const int ks0 = kh * NBATCH;
       constexpr int LPB = 2 * NTW;                                  // 16-byte loads per k-step
@@ -443,7 +445,6 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
           }
         }
       };
-      if (rows_sorted & 512) goto skip2;   // TEMP ablation
       wait_vm(0);
 #pragma unroll
       for (int d = 0; d < D; ++d) load_step(d, bh[d], bl[d]);
@@ -463,15 +464,15 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
         __builtin_amdgcn_sched_barrier(0);
         mma_step(NBATCH - D + d, bh[d], bl[d]);
       }
-    skip2:;
     }
     __syncthreads();
   }
   // ------------------------------ epilogue ---------------------------------
+  if (SK == 1 && wave >= NW) return;
   if (SK == 2) {
     // sum the two k-halves through LDS (the wf tiles are dead after the last barrier)
     float* red = reinterpret_cast<float*>(lds_raw);            // [NG][MTW][NTW][4][64]
-    if (kh == 1) {
+    if (wave < NW && kh == 1) {
 #pragma unroll
       for (int m = 0; m < MTW; ++m)
 #pragma unroll
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(64 * NW) void k_kpconv_mfma(
             red[(((ng * MTW + m) * NTW + t) * 4 + r) * 64 + lane] = acc2[m][t][r];
     }
     __syncthreads();
-    if (kh == 1) return;
+    if (wave >= NW || kh == 1) return;
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
 #pragma unroll
@@ -535,17 +536,17 @@ struct ProfScope {
   }
 };
 
-template <int CC, int TQ, int NTW, int NW, int SK>
+template <int CC, int TQ, int NTW, int NW, int SK, int P1W = NW>
 int launch_mfma(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
                 int nbr_stride, int kmax, int rows_sorted, const float* x, int cin,
                 const _Float16* Wh, const _Float16* Wl, int cout, const float* kpts,
-                float inv_extent, const unsigned char* flag, float* out, hipStream_t stream) {
+                float inv_extent, const float4* sxf, float* out, hipStream_t stream) {
   constexpr int SH = kKP * CC + 16;
-  constexpr int QPW = TQ / NW;
+  constexpr int QPW = TQ / P1W;
   const int nblk = (kmax + 15) / 16;
-  const size_t lds = 2 * sizeof(_Float16) * (size_t)TQ * SH + sizeof(int) * (TQ + NW) +
-                     sizeof(int) * (size_t)NW * QPW * nblk + sizeof(int) * (size_t)TQ * nblk * 16;
-  auto kern = k_kpconv_mfma<CC, TQ, NTW, NW, SK>;
+  const size_t lds = 2 * sizeof(_Float16) * (size_t)TQ * SH + sizeof(int) * (TQ + P1W) +
+                     sizeof(int) * (size_t)P1W * QPW * nblk + sizeof(int) * (size_t)TQ * nblk * 16;
+  auto kern = k_kpconv_mfma<CC, TQ, NTW, NW, SK, P1W>;
   ProfScope prof(stream, cin, cout, nq);
   SPR_REQUIRE(lds <= 160 * 1024, "kpconv: neighbour rows too wide for the LDS tile (kmax=%d)", kmax);
   if (lds > 64 * 1024) {
@@ -556,9 +557,9 @@ int launch_mfma(const float* q_xyz, int nq, const float* s_xyz, int ns, const in
       raised = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(cdiv(nq, TQ)), dim3(64 * NW), lds, stream, q_xyz, nq, s_xyz, ns,
+  hipLaunchKernelGGL(kern, dim3(cdiv(nq, TQ)), dim3(64 * P1W), lds, stream, q_xyz, nq, s_xyz, ns,
                      nbr, nbr_stride, kmax, rows_sorted, x, cin, Wh, Wl, cout, kpts, inv_extent,
-                     flag, out);
+                     sxf, out);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -570,8 +571,10 @@ using namespace spr;
 
 extern "C" size_t spr_kpconv_workspace_bytes(int nq, int ns, int cin, int cout) {
   (void)nq;
-  // flag bytes + pre-split transposed weights (hi, lo fp16; up to 32 kernel points)
-  return align_up((size_t)(ns > 0 ? ns : 1), 256) + 2 * align_up((size_t)32 * cin * cout * 2, 256) + 256;
+  // flag bytes + {x,y,z,flag} support records + pre-split fragment-order weights (hi, lo fp16; up to
+  // 32 kernel points)
+  const size_t n = (size_t)(ns > 0 ? ns : 1);
+  return align_up(n, 256) + align_up(16 * n, 256) + 2 * align_up((size_t)32 * cin * cout * 2, 256) + 256;
 }
 
 extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, int ns,
@@ -587,7 +590,8 @@ extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, in
   SPR_REQUIRE(kp_extent > 0.f, "kpconv: KP_extent must be > 0");
   SPR_REQUIRE(ws_bytes >= spr_kpconv_workspace_bytes(nq, ns, cin, cout), "kpconv: workspace too small");
   unsigned char* flag = (unsigned char*)ws;
-  _Float16* wh = (_Float16*)((char*)ws + align_up((size_t)ns, 256));
+  float4* sxf = (float4*)((char*)ws + align_up((size_t)ns, 256));
+  _Float16* wh = (_Float16*)((char*)sxf + align_up((size_t)ns * 16, 256));
   _Float16* wl = (_Float16*)((char*)wh + align_up((size_t)32 * cin * cout * 2, 256));
   const float inv_extent = 1.0f / kp_extent;
 
@@ -600,8 +604,8 @@ extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, in
     return 0;
   }
 
-  hipLaunchKernelGGL(k_rowflag, dim3(cdiv((long)ns * 64, 256)), dim3(256), 0, stream, x, ns, cin,
-                     flag);
+  hipLaunchKernelGGL(k_rowflag, dim3(cdiv((long)ns * 64, 256)), dim3(256), 0, stream, x, s_xyz, ns, cin,
+                     flag, sxf);
   SPR_LAUNCH_CHECK();
 
   if (impl == 0 && n_kp == kKP && cin % 32 == 0 && cout % 32 == 0 && cout <= 256) {
@@ -609,9 +613,8 @@ extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, in
     hipLaunchKernelGGL(k_w_prep, dim3(cdiv((long)ktot * cout, 256)), dim3(256), 0, stream, weights, cin, cout,
                        cin % 64 == 0 ? 64 : 32, wh, wl);
 #define SPR_KP_ARGS                                                                         \
-  q_xyz, nq, s_xyz, ns, nbr, nbr_stride, kmax, rows_sorted | kp_abl, x, cin, wh, wl, cout,           \
-      kernel_points, inv_extent, flag, out, stream
-    static const int kp_abl = getenv("SPR_KP_ABL") ? atoi(getenv("SPR_KP_ABL")) << 8 : 0;
+  q_xyz, nq, s_xyz, ns, nbr, nbr_stride, kmax, rows_sorted, x, cin, wh, wl, cout,           \
+      kernel_points, inv_extent, sxf, out, stream
     if (cin % 64 == 0) {
       // TQ = 32 (MT = 2), 8 waves: 4 n-groups x 2 k-halves, every wave both m-tiles
       if (cout == 64) return launch_mfma<64, 32, 1, 8, 2>(SPR_KP_ARGS);
