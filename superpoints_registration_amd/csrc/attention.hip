@@ -237,7 +237,7 @@ __device__ __forceinline__ int vstart(const int* __restrict__ cu, int s) {
 __global__ __launch_bounds__(256) void k_attn_pack(
     const float* __restrict__ q, int q_stride, const float* __restrict__ k, int k_stride,
     const float* __restrict__ v, int v_stride, const int* __restrict__ cu, int nseg, int d_model,
-    int tp, float qscale, _Float16* __restrict__ qh, _Float16* __restrict__ ql,
+    int t_total, int tp, float qscale, _Float16* __restrict__ qh, _Float16* __restrict__ ql,
     _Float16* __restrict__ kh, _Float16* __restrict__ kl, _Float16* __restrict__ vth,
     _Float16* __restrict__ vtl) {
   __shared__ __align__(16) _Float16 Lh[128 * PS], Ll[128 * PS];
@@ -274,12 +274,15 @@ __global__ __launch_bounds__(256) void k_attn_pack(
       if (t >= 0) {
         split_pk(vq.x * qscale, vq.y * qscale, ha, la);
         split_pk(vq.z * qscale, vq.w * qscale, hb, lb);
-        *reinterpret_cast<u32x2*>(qh + (size_t)t * d_model + f) = (u32x2){ha, hb};
-        *reinterpret_cast<u32x2*>(ql + (size_t)t * d_model + f) = (u32x2){la, lb};
+        // Q / K planes are head-major [head][token][32]: a 64-key tile of one head
+        // is 4 KiB contiguous (full 128-byte lines for the attention kernel's loads)
+        const size_t hm = ((size_t)(f / HD) * t_total + t) * HD + f % HD;
+        *reinterpret_cast<u32x2*>(qh + hm) = (u32x2){ha, hb};
+        *reinterpret_cast<u32x2*>(ql + hm) = (u32x2){la, lb};
         split_pk(vk.x, vk.y, ha, la);
         split_pk(vk.z, vk.w, hb, lb);
-        *reinterpret_cast<u32x2*>(kh + (size_t)t * d_model + f) = (u32x2){ha, hb};
-        *reinterpret_cast<u32x2*>(kl + (size_t)t * d_model + f) = (u32x2){la, lb};
+        *reinterpret_cast<u32x2*>(kh + hm) = (u32x2){ha, hb};
+        *reinterpret_cast<u32x2*>(kl + hm) = (u32x2){la, lb};
       }
       split_pk(vv.x, vv.y, ha, la);
       split_pk(vv.z, vv.w, hb, lb);
@@ -319,7 +322,7 @@ __device__ __forceinline__ float half_swap_max(float x) {
 __global__ __launch_bounds__(256) void k_attn_h3(
     const _Float16* __restrict__ qh_g, const _Float16* __restrict__ ql_g,
     const _Float16* __restrict__ kh_g, const _Float16* __restrict__ kl_g,
-    const _Float16* __restrict__ vth_g, const _Float16* __restrict__ vtl_g, int d_model, int tp,
+    const _Float16* __restrict__ vth_g, const _Float16* __restrict__ vtl_g, int t_total, int tp,
     const int* __restrict__ cu, const int* __restrict__ kv_seg, int nseg, int nhead,
     float* __restrict__ out, int o_stride) {
   __shared__ __align__(16) _Float16 Kh[2][KT2 * KH], Kl[2][KT2 * KH];
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(256) void k_attn_h3(
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int qi = min(q0 + wave * QW2 + 32 * h + l31, qlen - 1);
-    const size_t row = (size_t)(qbeg + qi) * d_model + hoff + 8 * lh;
+    const size_t row = ((size_t)head * t_total + qbeg + qi) * HD + 8 * lh;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       qh[h][s] = *reinterpret_cast<const h16x8*>(qh_g + row + 16 * s);
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(256) void k_attn_h3(
   const int svr = tid >> 3, svc = (tid & 7) * 8;
   u32x4 rkh, rkl, rvh, rvl;
   auto fetch = [&](int kt) {
-    const size_t krow = (size_t)(kbeg + min(kt + skr, klen - 1)) * d_model + hoff + skc;
+    const size_t krow = ((size_t)head * t_total + kbeg + min(kt + skr, klen - 1)) * HD + skc;
     const size_t vrow = (size_t)(hoff + svr) * tp + vbeg + kt + svc;
     const _Float16 *a = kh_g + krow, *b = kl_g + krow, *c = vth_g + vrow, *d = vtl_g + vrow;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rkh) : "v"(a));
@@ -597,9 +600,9 @@ extern "C" int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k,
     _Float16* vtl = w.take<_Float16>((size_t)d_model * tp);
     SPR_REQUIRE(vtl != nullptr, "attention: workspace carve failed");
     hipLaunchKernelGGL(k_attn_pack, dim3((unsigned)(tp / PT)), dim3(256), 0, stream, q, q_stride, k, k_stride,
-                       v, v_stride, cu, nseg, d_model, (int)tp, scale * 1.4426950408889634f, qh, ql, kh,
-                       kl, vth, vtl);
-    hipLaunchKernelGGL(k_attn_h3, grid, dim3(256), 0, stream, qh, ql, kh, kl, vth, vtl, d_model, (int)tp,
+                       v, v_stride, cu, nseg, d_model, t, (int)tp, scale * 1.4426950408889634f, qh, ql,
+                       kh, kl, vth, vtl);
+    hipLaunchKernelGGL(k_attn_h3, grid, dim3(256), 0, stream, qh, ql, kh, kl, vth, vtl, t, (int)tp,
                        cu, kv_seg, nseg, nhead, out, o_stride);
   } else {
     hipLaunchKernelGGL(k_attn, grid, dim3(256), 0, stream, q, q_stride, k, k_stride, v, v_stride, cu,

@@ -321,20 +321,34 @@ __device__ __forceinline__ unsigned long long nbr_key(float d2, int id) {
   return ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)id;
 }
 
+// scratch-row capacity: twice the row width, at most 128 (LDS of k_sort_rows)
+static inline int nbr_row_cap(int limit) { return limit * 2 < 128 ? limit * 2 : 128; }
+
 __global__ __launch_bounds__(256) void k_scan_table(
     const float* __restrict__ q_xyz, const int* __restrict__ q_cu, int nq, int nb,
     const GridCloud* __restrict__ info, const int* __restrict__ start,
     const float4* __restrict__ rec, const int* __restrict__ err, float r2, float inv_cell,
-    int limit, unsigned long long* __restrict__ tmp_key, int* __restrict__ kept_out,
+    int cap, int self, unsigned long long* __restrict__ tmp_key, int* __restrict__ kept_out,
     int* max_count) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (*err) return;
   int total = 0;
-  if (i < nq) {
-    const int c = find_segment(q_cu, nb, i);
+  if (t < nq) {
+    const int c = find_segment(q_cu, nb, t);
     const GridCloud g = info[c];
-    const float qx = q_xyz[3 * (size_t)i + 0], qy = q_xyz[3 * (size_t)i + 1],
-                qz = q_xyz[3 * (size_t)i + 2];
+    // self search (queries == supports): walk the queries in CELL order -- thread t
+    // takes the point of record t -- so the lanes of a wave scan the same cells and
+    // their record streams hit the same cache lines; rows are independent, each is
+    // written at its own query index
+    int i = t;
+    float qx, qy, qz;
+    if (self) {
+      const float4 me = rec[t];
+      i = __float_as_int(me.w);
+      qx = me.x, qy = me.y, qz = me.z;
+    } else {
+      qx = q_xyz[3 * (size_t)t + 0], qy = q_xyz[3 * (size_t)t + 1], qz = q_xyz[3 * (size_t)t + 2];
+    }
     const int cx = cell_coord(qx, g.mn[0], inv_cell);
     const int cy = cell_coord(qy, g.mn[1], inv_cell);
     const int cz = cell_coord(qz, g.mn[2], inv_cell);
@@ -349,7 +363,10 @@ __global__ __launch_bounds__(256) void k_scan_table(
       rb[k] = start[L0];
       re[k] = in ? start[L1] : rb[k];
     }
-    unsigned long long* row = tmp_key + (size_t)i * limit;
+    // scratch row of `cap` >= limit entries: a query with more than `limit` (but at most
+    // cap) supports in range keeps them all and k_sort_rows cuts the row; the
+    // replace-worst path (a dependent rescan of the row) only runs beyond cap
+    unsigned long long* row = tmp_key + (size_t)i * cap;
     int kept = 0;
     unsigned long long worst = 0;   // largest key among the kept entries
     int w_pos = 0;
@@ -362,7 +379,7 @@ __global__ __launch_bounds__(256) void k_scan_table(
       if (!(d2 < r2)) return;  // strict, nanoflann.hpp:249
       total++;
       const unsigned long long key = nbr_key(d2, __float_as_int(s.w));
-      if (kept < limit) {
+      if (kept < cap) {
         row[kept] = key;
         if (kept == 0 || key > worst) {
           worst = key;
@@ -375,7 +392,7 @@ __global__ __launch_bounds__(256) void k_scan_table(
       row[w_pos] = key;
       __threadfence_block();   // our own store must be visible to the rescan below
       worst = key;
-      for (int k = 0; k < limit; ++k) {
+      for (int k = 0; k < cap; ++k) {
         const unsigned long long rk = row[k];
         if (rk > worst) {
           worst = rk;
@@ -420,14 +437,14 @@ template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_sort_rows(const unsigned long long* __restrict__ tmp_key,
                                                      const int* __restrict__ kept_in,
                                                      const int* __restrict__ err, int nq, int ns,
-                                                     int limit, int* __restrict__ out) {
+                                                     int limit, int cap, int* __restrict__ out) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned long long* l_key = (unsigned long long*)smem;
   const int t = threadIdx.x;
   const int i = blockIdx.x * BLOCK + t;
   if (*err || i >= nq) return;
   const int kept = kept_in[i];
-  const unsigned long long* src = tmp_key + (size_t)i * limit;
+  const unsigned long long* src = tmp_key + (size_t)i * cap;
   for (int k = 0; k < kept; ++k) l_key[k * BLOCK + t] = src[k];
   int* row = out + (size_t)i * limit;
   constexpr unsigned long long kInf = ~0ull;
@@ -444,10 +461,11 @@ __global__ __launch_bounds__(BLOCK) void k_sort_rows(const unsigned long long* _
       r2 += kb < k2 ? 1 : 0;
       r3 += kb < k3 ? 1 : 0;
     }
-    row[r0] = (int)(unsigned)k0;
-    if (a + 1 < kept) row[r1] = (int)(unsigned)k1;
-    if (a + 2 < kept) row[r2] = (int)(unsigned)k2;
-    if (a + 3 < kept) row[r3] = (int)(unsigned)k3;
+    // ranks are a permutation of 0..kept-1; the row keeps the `limit` nearest
+    if (r0 < limit) row[r0] = (int)(unsigned)k0;
+    if (a + 1 < kept && r1 < limit) row[r1] = (int)(unsigned)k1;
+    if (a + 2 < kept && r2 < limit) row[r2] = (int)(unsigned)k2;
+    if (a + 3 < kept && r3 < limit) row[r3] = (int)(unsigned)k3;
   }
   for (int k = kept; k < limit; ++k) row[k] = ns;
 }
@@ -498,7 +516,7 @@ extern "C" size_t spr_radius_neighbors_workspace_bytes(int nq, int ns, int nb) {
   b += align_up(4 * N, 256);              // cell_of
   b += scan_temp_bytes(cap + 1);
   const size_t Q = (size_t)(nq > 0 ? nq : 1);
-  b += align_up(8 * Q * 128, 256);        // unsorted (d2, id) key rows, limit <= 128
+  b += align_up(8 * Q * 128, 256);        // unsorted (d2, id) key rows, nbr_row_cap(limit) <= 128
   b += align_up(4 * Q, 256);              // kept counts
   return b;
 }
@@ -556,15 +574,17 @@ extern "C" int spr_radius_neighbors(const float* q_xyz, const int* q_cu, int nq,
                                           stream));
     hipLaunchKernelGGL(k_cell_scatter, dim3(cdiv(ns, TB)), dim3(TB), 0, stream, s_xyz, ns, err, cell_of,
                        start, cursor, rec);
-    unsigned long long* tmp_key = w.take<unsigned long long>((size_t)nq * limit);
+    const int rcap = nbr_row_cap(limit);
+    unsigned long long* tmp_key = w.take<unsigned long long>((size_t)nq * rcap);
     int* kept = w.take<int>((size_t)nq);
     SPR_REQUIRE(kept != nullptr, "radius_neighbors: workspace carve failed (rows)");
     hipLaunchKernelGGL(k_scan_table, dim3(cdiv(nq, 256)), dim3(256), 0, stream, q_xyz, q_cu, nq, nb, ginfo,
-                       start, rec, err, r2, inv_cell, limit, tmp_key, kept, max_count);
+                       start, rec, err, r2, inv_cell, rcap, (q_xyz == s_xyz && q_cu == s_cu && nq == ns) ? 1 : 0,
+                       tmp_key, kept, max_count);
     {
-      constexpr int BLOCK = 64;   // limit <= 128 -> at most 64 KB of LDS
-      hipLaunchKernelGGL(k_sort_rows<BLOCK>, dim3(cdiv(nq, BLOCK)), dim3(BLOCK), (size_t)limit * 8 * BLOCK,
-                         stream, tmp_key, kept, err, nq, ns, limit, out_idx);
+      constexpr int BLOCK = 64;   // cap <= 128 -> at most 64 KB of LDS
+      hipLaunchKernelGGL(k_sort_rows<BLOCK>, dim3(cdiv(nq, BLOCK)), dim3(BLOCK), (size_t)rcap * 8 * BLOCK,
+                         stream, tmp_key, kept, err, nq, ns, limit, rcap, out_idx);
     }
     hipLaunchKernelGGL(k_nbr_err2, dim3(1), dim3(1), 0, stream, err, max_count);
     SPR_LAUNCH_CHECK();
