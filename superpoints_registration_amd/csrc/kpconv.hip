@@ -95,49 +95,68 @@ __global__ void k_kpconv_simple(const float* __restrict__ q_xyz, int nq,
 
 // ---------------------------------------------------------------------------
 // Cin == 1 (first block: features are a column of ones, qk_regtr_full.py:157).
-// One thread per query accumulates the 15 influence sums; the 15 x Cout
-// weight matrix sits in LDS.
-template <int MAXKP>
+// A wave owns 16 queries.  Lane (q = lane & 15, g = lane >> 4) accumulates the
+// influence sums of kernel points g, g + 4, g + 8, g + 12 of query q -- which is
+// exactly the A-operand layout of v_mfma_f32_16x16x4_f32 (row = query, k = g) --
+// so the [16 q x 16 kp] x [16 kp x Cout] product that follows needs no
+// transposition, and its C layout (lane = channel) stores 64-byte row pieces.
 __global__ __launch_bounds__(256) void k_kpconv_cin1(
     const float* __restrict__ q_xyz, int nq, const float* __restrict__ s_xyz, int ns,
-    const int* __restrict__ nbr, int nbr_stride, int kmax, const float* __restrict__ x,
-    const float* __restrict__ W, int cout, const float* __restrict__ kpts, int n_kp,
-    float inv_extent, float* __restrict__ out) {
-  extern __shared__ float lw[];  // [n_kp * cout] + [n_kp*3]
-  float* lk = lw + n_kp * cout;
-  for (int i = threadIdx.x; i < n_kp * cout; i += blockDim.x) lw[i] = W[i];
-  for (int i = threadIdx.x; i < n_kp * 3; i += blockDim.x) lk[i] = kpts[i];
-  __syncthreads();
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= nq) return;
+    const int* __restrict__ nbr, int nbr_stride, int kmax, int rows_sorted,
+    const float* __restrict__ x, const float* __restrict__ W, int cout,
+    const float* __restrict__ kpts, int n_kp, float inv_extent, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qv = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  if (q0 >= nq) return;
+  const int n = min(q0 + qv, nq - 1);
   const float qx = q_xyz[3 * (size_t)n], qy = q_xyz[3 * (size_t)n + 1], qz = q_xyz[3 * (size_t)n + 2];
-  float wf[MAXKP];
+  float kx[4], ky[4], kz[4];
+  bool kok[4];
 #pragma unroll
-  for (int p = 0; p < MAXKP; ++p) wf[p] = 0.f;
+  for (int s = 0; s < 4; ++s) {
+    const int p = 4 * s + g;
+    kok[s] = p < n_kp;
+    kx[s] = kok[s] ? kpts[3 * p] : 0.f;
+    ky[s] = kok[s] ? kpts[3 * p + 1] : 0.f;
+    kz[s] = kok[s] ? kpts[3 * p + 2] : 0.f;
+  }
+  float wf[4] = {0.f, 0.f, 0.f, 0.f};
   int cnt = 0;
+  const int* row = nbr + (size_t)n * nbr_stride;
   for (int k = 0; k < kmax; ++k) {
-    const int idx = nbr[(size_t)n * nbr_stride + k];
-    if (idx < 0 || idx >= ns) continue;
-    const float xv = x[idx];
+    const int idx = row[k];
+    const bool ok = idx >= 0 && idx < ns;
+    if (rows_sorted && __ballot(ok) == 0ull) break;   // only trailing shadow entries left
+    const size_t id = ok ? (size_t)idx : 0;
+    const float xv = ok ? x[id] : 0.f;
     cnt += xv > 0.f ? 1 : 0;
-    const float rx = s_xyz[3 * (size_t)idx] - qx, ry = s_xyz[3 * (size_t)idx + 1] - qy,
-                rz = s_xyz[3 * (size_t)idx + 2] - qz;
+    const float rx = s_xyz[3 * id] - qx, ry = s_xyz[3 * id + 1] - qy, rz = s_xyz[3 * id + 2] - qz;
 #pragma unroll
-    for (int p = 0; p < MAXKP; ++p) {
-      if (p < n_kp) {
-        const float dx = rx - lk[3 * p], dy = ry - lk[3 * p + 1], dz = rz - lk[3 * p + 2];
-        const float w = fmaxf(0.f, 1.f - sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
-        wf[p] += w * xv;
-      }
+    for (int s = 0; s < 4; ++s) {
+      const float dx = rx - kx[s], dy = ry - ky[s], dz = rz - kz[s];
+      // v_sqrt_f32 (1 ulp), like the fused kernel
+      const float w = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
+      wf[s] += kok[s] ? w * xv : 0.f;
     }
   }
   const float inv = 1.f / (float)max(cnt, 1);
-  for (int o = 0; o < cout; ++o) {
-    float a = 0.f;
 #pragma unroll
-    for (int p = 0; p < MAXKP; ++p)
-      if (p < n_kp) a += wf[p] * lw[p * cout + o];
-    out[(size_t)n * cout + o] = a * inv;
+  for (int s = 0; s < 4; ++s) wf[s] *= inv;
+  for (int o0 = 0; o0 < cout; o0 += 16) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int p = 4 * s + g;
+      const float bv = (p < n_kp && o0 + qv < cout) ? W[(size_t)p * cout + o0 + qv] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], bv, acc, 0, 0, 0);
+    }
+    // C layout: row (query) = 4 g + r, col (channel) = qv
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qn = q0 + 4 * g + r;
+      if (qn < nq && o0 + qv < cout) out[(size_t)qn * cout + o0 + qv] = acc[r];
+    }
   }
 }
 
@@ -596,10 +615,8 @@ extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, in
   const float inv_extent = 1.0f / kp_extent;
 
   if (cin == 1 && impl == 0 && n_kp <= 16) {
-    const size_t lds = sizeof(float) * ((size_t)n_kp * cout + 3 * n_kp);
-    hipLaunchKernelGGL(k_kpconv_cin1<16>, dim3(cdiv(nq, 256)), dim3(256), lds, stream, q_xyz, nq,
-                       s_xyz, ns, nbr, nbr_stride, kmax, x, weights, cout, kernel_points, n_kp,
-                       inv_extent, out);
+    hipLaunchKernelGGL(k_kpconv_cin1, dim3(cdiv(nq, 64)), dim3(256), 0, stream, q_xyz, nq, s_xyz, ns, nbr,
+                       nbr_stride, kmax, rows_sorted, x, weights, cout, kernel_points, n_kp, inv_extent, out);
     SPR_LAUNCH_CHECK();
     return 0;
   }
