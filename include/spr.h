@@ -64,7 +64,7 @@ int spr_grid_subsample(const float* xyz, const int* cu, int n, int nb, float dl,
  * [:, :max_neighbors] slice of kpconv.py:258-262.
  * Rows: supports of the same cloud with d2 < r*r (float32, exact reference
  * arithmetic), ascending (d2, index), global indices, padded with ns.
- *   out_idx [nq, limit] i32; max_count [1] i32 device = untruncated max row
+ *   out_idx [nq, limit] i32, 1 <= limit <= 128; max_count [1] i32 device = untruncated max row
  *   count (the reference's row width); the caller may slice to
  *   min(max_count, limit).
  * algo 0: dense per-cloud cell table (fast; *max_count = -2 if the clouds'

@@ -11,12 +11,17 @@ units of 1024 B; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so reads a
 """
 import collections, csv, glob, json, os, shutil, sys
 
+
+def newest(pattern):
+    """gpurun merges into gpurun_out/ without deleting earlier runs: take the latest file."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 src = "gpurun_out/final"
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(f"{src}/bench.json", f"profiles/{tag}_bench.json")
 shutil.copy(f"{src}/bench_under_rocprof.json", f"profiles/{tag}_bench_under_rocprof.json")
-stats = glob.glob(f"{src}/stats/*/*kernel_stats.csv")[0]
+stats = newest(f"{src}/stats/*/*kernel_stats.csv")
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 
 
@@ -30,8 +35,8 @@ def per_kernel(path, counter):
     return {k: (agg[k] / len(n[k]), len(n[k])) for k in agg}
 
 
-fetch = per_kernel(glob.glob(f"{src}/pmc_fetch/*/*counter_collection.csv")[0], "FETCH_SIZE")
-write = per_kernel(glob.glob(f"{src}/pmc_write/*/*counter_collection.csv")[0], "WRITE_SIZE")
+fetch = per_kernel(newest(f"{src}/pmc_fetch/*/*counter_collection.csv"), "FETCH_SIZE")
+write = per_kernel(newest(f"{src}/pmc_write/*/*counter_collection.csv"), "WRITE_SIZE")
 bench = json.load(open(f"{src}/bench.json"))
 roof = bench["roofline"]
 lines = ["kernel | launches | FETCH_SIZE (KiB/launch, raw) | WRITE_SIZE (KiB/launch) | HBM bytes/launch = 2*FETCH+WRITE"]

@@ -123,7 +123,7 @@ def batch_grid_subsampling_kpconv(points, batches_len, features=None, labels=Non
 def batch_neighbors_kpconv(queries, supports, q_batches, s_batches, radius, max_neighbors):
     """Replaces cpp_neighbors.batch_query + the column slice (kpconv.py:247-262).
     Returns int32 [Nq, min(max_count, max_neighbors)], shadow index = Ns."""
-    limit = int(max_neighbors) if max_neighbors > 0 else 119
+    limit = int(max_neighbors) if max_neighbors > 0 else 128
     idx, _ = ops.radius_neighbors(queries, supports,
                                   ops.lengths_to_cu(q_batches, queries.device),
                                   ops.lengths_to_cu(s_batches, queries.device),
