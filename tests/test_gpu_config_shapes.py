@@ -1,0 +1,142 @@
+"""GPU: the other BASELINE.json configurations as parity cases (configs[2..4]).
+
+  configs[2]  3DMatch-shaped indoor pairs (~20 k pts, 0.025 m voxel), batch 8
+  configs[3]  KITTI-shaped outdoor pairs (~120 k pts, 0.3 m voxel)
+  configs[4]  ModelNet-shaped partial-overlap pairs (1 024 pts), batch 256
+
+At these sizes the full CPU oracle is too slow for a test, so index work is
+checked bit-exactly on SAMPLED query rows against a brute-force float32
+restatement of the reference rule (nanoflann.hpp:249,432-440: d2 = dx*dx +
+dy*dy + dz*dz in float32, strict d2 < r*r, same cloud only; rows ordered by
+(d2, index) -- the tie order documented in DESIGN.md section 3), subsampling
+against the C oracle, and the model output through size-independent
+properties (proper rotations, determinism)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import native
+from superpoints_registration_amd import get_config, ops, synthetic
+from superpoints_registration_amd.kpconv import Preprocessor
+from superpoints_registration_amd.regtr import RegTR
+
+pytestmark = pytest.mark.gpu
+
+
+def _brute_rows(q, s, q_cloud, s_cloud, rows, radius, limit):
+    """Expected neighbour rows (global support indices, padded with len(s)) of the sampled queries."""
+    ns = len(s)
+    r2 = np.float32(radius) * np.float32(radius)
+    out = np.full((len(rows), limit), ns, np.int64)
+    counts = np.zeros(len(rows), np.int64)
+    for o, i in enumerate(rows):
+        cand = np.nonzero(s_cloud == q_cloud[i])[0]
+        d = q[i][None, :].astype(np.float32) - s[cand].astype(np.float32)
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32)
+        d2 = (d2 + d[:, 2] * d[:, 2]).astype(np.float32)
+        keep = d2 < r2
+        cand, d2 = cand[keep], d2[keep]
+        order = np.lexsort((cand, d2))
+        counts[o] = len(cand)
+        k = min(limit, len(cand))
+        out[o, :k] = cand[order[:k]]
+    return out, counts
+
+
+def _cloud_ids(lens):
+    return np.repeat(np.arange(len(lens)), lens)
+
+
+def _check_pyramid(pts_list, cfg, device, n_sample, seed):
+    """Runs the Preprocessor and checks every level's matrices on sampled rows."""
+    rng = np.random.default_rng(seed)
+    meta = Preprocessor(cfg)([torch.from_numpy(p).to(device) for p in pts_list])
+    r = cfg.first_subsampling_dl * cfg.conv_radius
+    nlev = len(meta['points'])
+    for l in range(nlev):
+        pts = meta['points'][l].cpu().numpy()
+        lens = meta['stack_lengths'][l].cpu().numpy()
+        cid = _cloud_ids(lens)
+        limit = int(cfg.neighborhood_limits[l])
+        nb = meta['neighbors'][l].cpu().numpy()
+        rows = rng.choice(len(pts), size=min(n_sample, len(pts)), replace=False)
+        exp, cnt = _brute_rows(pts, pts, cid, cid, rows, r, limit)
+        w = nb.shape[1]
+        assert w <= limit
+        assert np.array_equal(nb[rows], exp[:, :w]), f"level {l} conv neighbours"
+        assert np.all(exp[:, w:] == len(pts)), f"level {l}: reference width would be larger"
+        if l + 1 < nlev:
+            sub = meta['points'][l + 1].cpu().numpy()
+            sub_lens = meta['stack_lengths'][l + 1].cpu().numpy()
+            # subsampling: bit-exact barycentres in the reference's order (C oracle)
+            ref, ref_lens = native.grid_subsample(pts, lens, 2 * r / cfg.conv_radius)
+            assert np.array_equal(sub_lens, ref_lens)
+            assert np.array_equal(sub.view(np.uint32), ref.view(np.uint32))
+            scid = _cloud_ids(sub_lens)
+            pool = meta['pools'][l].cpu().numpy()
+            rows = rng.choice(len(sub), size=min(n_sample, len(sub)), replace=False)
+            exp, _ = _brute_rows(sub, pts, scid, cid, rows, r, limit)
+            assert np.array_equal(pool[rows], exp[:, :pool.shape[1]]), f"level {l} pools"
+            up = meta['upsamples'][l].cpu().numpy()
+            rows = rng.choice(len(pts), size=min(n_sample, len(pts)), replace=False)
+            exp, _ = _brute_rows(pts, sub, cid, scid, rows, 2 * r, limit)
+            assert np.array_equal(up[rows], exp[:, :up.shape[1]]), f"level {l} upsamples"
+        r *= 2
+    return meta
+
+
+def _check_poses(out, npairs):
+    pose = out['pose'].float().cpu().numpy().reshape(-1, 3, 4)[-npairs:]
+    assert np.all(np.isfinite(pose))
+    R = pose[:, :, :3].astype(np.float64)
+    eye = np.einsum('bij,bkj->bik', R, R)
+    assert np.abs(eye - np.eye(3)).max() < 1e-4          # orthonormal
+    assert np.abs(np.linalg.det(R) - 1.0).max() < 1e-4   # proper rotation (se3_torch.py:150-157)
+
+
+def _model(tag, device):
+    cfg = get_config(tag)
+    model = RegTR(cfg)
+    synthetic.fill_parameters(model, 0)
+    return cfg, model.to(device).eval()
+
+
+def test_config2_3dmatch_shaped_batch8(device):
+    cfg, model = _model('3dmatch', device)
+    pairs = [synthetic.make_pair(20000 + 137 * i, seed=10 + i) for i in range(8)]   # ragged sizes
+    pts = [p[0] for p in pairs] + [p[1] for p in pairs]
+    _check_pyramid(pts, cfg, device, n_sample=96, seed=2)
+    batch = {"src_xyz": [torch.from_numpy(p[0]).to(device) for p in pairs],
+             "tgt_xyz": [torch.from_numpy(p[1]).to(device) for p in pairs]}
+    with torch.no_grad():
+        o1 = model(batch)
+        o2 = model(batch)
+    _check_poses(o1, 8)
+    assert torch.equal(o1['pose'], o2['pose'])
+
+
+def test_config3_kitti_shaped_120k(device):
+    cfg, model = _model('kitti', device)
+    # outdoor scale: the box is stretched so that the 0.3 m voxel grid keeps ~40 k points at level 1
+    pair = synthetic.make_pair(120000, seed=21, extent=60.0, jitter=0.03, trans=(1.5, -0.7, 0.1))
+    _check_pyramid([pair[0], pair[1]], cfg, device, n_sample=64, seed=3)
+    batch = {"src_xyz": [torch.from_numpy(pair[0]).to(device)], "tgt_xyz": [torch.from_numpy(pair[1]).to(device)]}
+    with torch.no_grad():
+        o1 = model(batch)
+        o2 = model(batch)
+    _check_poses(o1, 1)
+    assert torch.equal(o1['pose'], o2['pose'])
+
+
+def test_config4_modelnet_shaped_batch256(device):
+    cfg, model = _model('modelnet', device)
+    pairs = [synthetic.make_sphere_pair(1024, seed=100 + i) for i in range(256)]
+    pts = [p[0] for p in pairs] + [p[1] for p in pairs]
+    _check_pyramid(pts, cfg, device, n_sample=128, seed=4)
+    batch = {"src_xyz": [torch.from_numpy(p[0]).to(device) for p in pairs],
+             "tgt_xyz": [torch.from_numpy(p[1]).to(device) for p in pairs]}
+    with torch.no_grad():
+        o1 = model(batch)
+        o2 = model(batch)
+    _check_poses(o1, 256)
+    assert torch.equal(o1['pose'], o2['pose'])

@@ -106,3 +106,32 @@ def test_full_size_pairs_order_and_arithmetic_invariance(device):
         f_ref, f_ex = outs["ref"]["src_feat"][b][0], outs["exact"]["src_feat"][b][0]
         assert float((f_ref - f_ex).abs().max()) <= 2e-5 * float(f_ex.abs().max())
         assert outs["ref"]["src_feat"][b].shape[1] > 1000          # ~1.9 k superpoints per cloud
+
+
+def test_full_size_pair_against_the_cpu_oracle(device):
+    """BASELINE config 2 size, ONE pair (16 384 pts/cloud): the whole forward
+    against the CPU oracle (oracle/torch_oracle.py, pinned to the reference by
+    tests/test_oracle_torch.py).  Tolerances: pose 1e-4 Frobenius (north_star),
+    conditioned features 1e-4 of their scale (fp32 reduction-order noise through
+    8 KPConv blocks + 6 transformer layers), pyramid bit-exact."""
+    from oracle import torch_oracle
+    cfg = get_config("3dmatch")
+    src, tgt, _ = synthetic.make_pair(16384, seed=5)
+    model = RegTR(cfg)
+    synthetic.fill_parameters(model, seed=0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = torch_oracle.regtr_forward(cfg, sd, [src], [tgt])
+        model = model.to(device).eval()
+        batch = {"src_xyz": [torch.from_numpy(src).to(device)], "tgt_xyz": [torch.from_numpy(tgt).to(device)]}
+        out = model(batch)
+    meta = batch["kpconv_meta"]
+    for l, p in enumerate(ref["meta"]["points"]):
+        assert np.array_equal(meta["points"][l].cpu().numpy().view(np.uint32), np.asarray(p).view(np.uint32))
+    cs, ct = ref["cond"][0]
+    scale = max(float(cs.abs().max()), 1.0)
+    assert float((out["src_feat"][0][0].cpu() - cs).abs().max()) <= 1e-4 * scale
+    assert float((out["tgt_feat"][0][0].cpu() - ct).abs().max()) <= 1e-4 * scale
+    err = np.linalg.norm(out["pose"][0].cpu().numpy() - ref["pose"][0].numpy())
+    assert err < 1e-4, f"pose error {err:.2e}"
