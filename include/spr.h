@@ -176,6 +176,23 @@ int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k,
                         float* out, int o_stride, void* ws, size_t ws_bytes,
                         void* stream);
 
+/* In-projection + attention core in one call: replaces
+ * F.multi_head_attention_forward's packed in-projection (q, k from x_qk,
+ * v from x_v; in_proj_weight [3d, d], in_proj_bias [3d]) followed by the core
+ * above -- nn.MultiheadAttention as called at transformers.py:198-227 minus the
+ * out-projection.  In split-fp16 mode the projection GEMM writes the attention
+ * operand planes straight from its accumulators (no fp32 [t, 3d] round trip);
+ * in exact mode it equals spr_linear + spr_attn_varlen_fwd.  d_model = 256.
+ *   x_qk, x_v [t, d] contiguous (may be the same pointer); out [t, d].
+ */
+size_t spr_attn_inproj_workspace_bytes(int t, int nseg, int nhead, int head_dim);
+int spr_attn_inproj_varlen_fwd(const float* x_qk, const float* x_v, int t,
+                               const float* w_in, const float* b_in,
+                               const int* cu, const int* kv_seg, int nseg,
+                               int max_len_host, int nhead, int head_dim,
+                               float scale, float* out, int o_stride, void* ws,
+                               size_t ws_bytes, void* stream);
+
 /* Arithmetic of the attention core: 1 (default) = split-fp16 MFMA (operands
  * carried as fp16 hi + fp16 lo, fp32 accumulation and softmax; fp32-level
  * accuracy), 0 = exact f32 MFMA. */

@@ -19,6 +19,7 @@
 //   order permuted consistently on both operands -- no LDS round trip for P.
 //   K / V tiles of 32 keys are staged in LDS (row stride 33 / 32 words ->
 //   conflict-free fragment reads) and shared by the four waves.
+#include "attn_planes.h"
 #include "spr_common.h"
 #include <type_traits>
 
@@ -230,7 +231,24 @@ constexpr int PT = 64;   // token columns per pack workgroup
 constexpr int PS = 72;   // pack transposition row stride (halves)
 
 __device__ __forceinline__ int vstart(const int* __restrict__ cu, int s) {
-  return (cu[s] + 8 * s) & ~7;
+  return attn_vstart_of(cu[s], s);
+}
+
+// Zeroes the gap columns between segments and the tail of the transposed V planes
+// (written by k_attn_pack itself on the unfused path; needed when the in-projection
+// GEMM emits the planes).  One workgroup per plane row.
+__global__ __launch_bounds__(256) void k_attn_zero_gaps(const int* __restrict__ cu, int nseg, int tp,
+                                                         _Float16* __restrict__ vth,
+                                                         _Float16* __restrict__ vtl) {
+  const size_t row = (size_t)blockIdx.x * tp;
+  for (int s = 0; s < nseg; ++s) {
+    const int beg = vstart(cu, s) + cu[s + 1] - cu[s];
+    const int end = s + 1 < nseg ? vstart(cu, s + 1) : tp;
+    for (int c = beg + threadIdx.x; c < end; c += 256) {
+      vth[row + c] = (_Float16)0.f;
+      vtl[row + c] = (_Float16)0.f;
+    }
+  }
 }
 
 // One workgroup = PT token columns x all features.  tp = padded column count.
@@ -608,6 +626,76 @@ extern "C" int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k,
     hipLaunchKernelGGL(k_attn, grid, dim3(256), 0, stream, q, q_stride, k, k_stride, v, v_stride, cu,
                        kv_seg, nseg, nhead, scale, out, o_stride);
   }
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t spr_attn_inproj_workspace_bytes(int t, int nseg, int nhead, int head_dim) {
+  if (t < 0 || nseg < 0 || nhead < 0 || head_dim < 0) return 0;
+  // operand planes + (exact mode only) the fp32 [t, 3 d] projection
+  return spr_attn_workspace_bytes(t, nseg, nhead, head_dim) +
+         align_up((size_t)(t > 0 ? t : 1) * 3 * nhead * head_dim * sizeof(float), 256);
+}
+
+extern "C" int spr_attn_inproj_varlen_fwd(const float* x_qk, const float* x_v, int t, const float* w_in,
+                                          const float* b_in, const int* cu, const int* kv_seg, int nseg,
+                                          int max_len_host, int nhead, int head_dim, float scale, float* out,
+                                          int o_stride, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(head_dim == HD, "attention: head_dim must be %d (got %d)", HD, head_dim);
+  SPR_REQUIRE(nhead * head_dim == 256, "attention in-projection: d_model must be 256 (got %d)", nhead * head_dim);
+  SPR_REQUIRE(t >= 1 && nseg >= 1 && max_len_host >= 1, "attention: bad sizes");
+  SPR_REQUIRE(x_qk && x_v && w_in && b_in, "attention in-projection: null operand");
+  SPR_REQUIRE(ws != nullptr && ws_bytes >= spr_attn_inproj_workspace_bytes(t, nseg, nhead, head_dim),
+              "attention in-projection: workspace too small (%zu bytes given)", ws_bytes);
+  const int d = nhead * head_dim;
+  const size_t planes_bytes = spr_attn_workspace_bytes(t, nseg, nhead, head_dim);
+  if (spr::g_attn_mode != 1 || t < 256) {
+    // exact-f32 mode (and tiny inputs): plain projection into the workspace, then the
+    // unfused core -- same results as spr_linear + spr_attn_varlen_fwd
+    float* qkv = (float*)((char*)ws + planes_bytes);
+    if (x_v == x_qk) {
+      if (int rc = launch_linear_plain(x_qk, t, d, w_in, 3 * d, b_in, qkv, stream)) return rc;
+    } else {
+      // two projections, written side by side: [q | k] from x_qk, [v] from x_v
+      float* qk = qkv;
+      float* v = qkv + (size_t)t * 2 * d;
+      if (int rc = launch_linear_plain(x_qk, t, d, w_in, 2 * d, b_in, qk, stream)) return rc;
+      if (int rc = launch_linear_plain(x_v, t, d, w_in + (size_t)2 * d * d, d, b_in + 2 * d, v, stream)) return rc;
+      return spr_attn_varlen_fwd(qk, 2 * d, qk + d, 2 * d, v, d, cu, kv_seg, t, nseg, max_len_host, nhead,
+                                 head_dim, scale, out, o_stride, ws, planes_bytes, stream_);
+    }
+    return spr_attn_varlen_fwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, cu, kv_seg, t, nseg,
+                               max_len_host, nhead, head_dim, scale, out, o_stride, ws, planes_bytes, stream_);
+  }
+  SPR_REQUIRE((long)cdiv(max_len_host, QB2) * nhead * nseg < (1l << 31), "attention: grid too large");
+  const size_t tp = attn_tp(t, nseg);
+  SPR_REQUIRE(tp < (1ul << 31), "attention: too many tokens");
+  Workspace w(ws, ws_bytes);
+  AttnPlanes pl;
+  pl.qh = w.take<_Float16>((size_t)t * d);
+  pl.ql = w.take<_Float16>((size_t)t * d);
+  pl.kh = w.take<_Float16>((size_t)t * d);
+  pl.kl = w.take<_Float16>((size_t)t * d);
+  pl.vth = w.take<_Float16>((size_t)d * tp);
+  pl.vtl = w.take<_Float16>((size_t)d * tp);
+  SPR_REQUIRE(pl.vtl != nullptr, "attention: workspace carve failed");
+  pl.cu = cu;
+  pl.nseg = nseg;
+  pl.t_total = t;
+  pl.tp = (int)tp;
+  pl.qscale = scale * 1.4426950408889634f;
+  hipLaunchKernelGGL(k_attn_zero_gaps, dim3(d), dim3(256), 0, stream, cu, nseg, (int)tp, pl.vth, pl.vtl);
+  if (x_v == x_qk) {
+    if (int rc = launch_inproj_planes(x_qk, t, d, w_in, 3 * d, b_in, 0, pl, stream)) return rc;
+  } else {
+    if (int rc = launch_inproj_planes(x_qk, t, d, w_in, 2 * d, b_in, 0, pl, stream)) return rc;
+    if (int rc = launch_inproj_planes(x_v, t, d, w_in + (size_t)2 * d * d, d, b_in + 2 * d, 2 * d, pl, stream))
+      return rc;
+  }
+  dim3 grid(cdiv(max_len_host, QB2) * nhead * nseg);
+  hipLaunchKernelGGL(k_attn_h3, grid, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth, pl.vtl, t,
+                     (int)tp, cu, kv_seg, nseg, nhead, out, o_stride);
   SPR_LAUNCH_CHECK();
   return 0;
 }

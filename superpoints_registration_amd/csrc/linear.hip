@@ -14,6 +14,7 @@
 // wave, BMxBN workgroup tile staged through LDS with a row stride of 33 words
 // (conflict-free fragment reads); the next K-slab is prefetched into
 // registers while the current one feeds the MFMAs.
+#include "attn_planes.h"
 #include "spr_common.h"
 
 namespace spr {
@@ -174,15 +175,16 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt(
 // normalised, O(10)); spr_set_gemm_mode(0) selects the exact-f32 kernel.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int HS = 40;                 // LDS row stride in halves (BK = 32 + 8 pad)
 
-template <int BM, int BN, int WM, int WN, int ACT, bool RES>
+template <int BM, int BN, int WM, int WN, int ACT, bool RES, bool PLANES = false>
 __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
     const float* __restrict__ X, int M, int K, const float* __restrict__ Wt, int N,
     const float* __restrict__ bias, const float* __restrict__ residual,
-    float* __restrict__ out) {
+    float* __restrict__ out, AttnPlanes pl, int f0) {
   constexpr int NT = WM * WN * 64;      // threads (4 or 8 waves)
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);   // 32x32 sub-tiles per wave
   constexpr int A_F4 = BM * BK / 4, B_F4 = BN * BK / 4;
@@ -280,15 +282,77 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           // small terms first, then the dominant one
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          if (PLANES) {
+            // transposed product: lane = token (X row), registers = features (W rows)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (PLANES) {
+    // ---- attention operand planes (attn_planes.h) straight from the accumulators ----
+    // accumulator (i, j): lane column = token m0 + (wm TM + i) 32 + l31, register r = feature
+    // n0 + (wn TN + j) 32 + (r & 3) + 8 (r >> 2) + 4 lh of this launch (f0 + ... of the projection)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int tok = m0 + (wm * TM + i) * 32 + l31;
+      if (tok >= M) continue;
+      const int which = (f0 + n0) >> 8;                         // 0 Q, 1 K, 2 V (block uniform)
+      int vcol = 0;
+      if (which == 2) {
+        const int sg = find_segment(pl.cu, pl.nseg, tok);
+        vcol = attn_vstart_of(pl.cu[sg], sg) + tok - pl.cu[sg];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int fl = n0 + (wn * TN + j) * 32;                 // first feature of the sub-tile (launch local)
+        const int fg = (f0 + fl) & 255;                         // ... inside its Q / K / V block
+        if (which == 2) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            // registers r, r+1 = adjacent features (two plane rows), same token column
+            const int d = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float a = acc[i][j][r] + bias[fl + d], b = acc[i][j][r + 1] + bias[fl + d + 1];
+            unsigned int hu, lu;
+            split_pk(a, b, hu, lu);
+            const f16x2 hh = __builtin_bit_cast(f16x2, hu), ll = __builtin_bit_cast(f16x2, lu);
+            const size_t o = (size_t)(fg + d) * pl.tp + vcol;
+            pl.vth[o] = hh[0];
+            pl.vth[o + pl.tp] = hh[1];
+            pl.vtl[o] = ll[0];
+            pl.vtl[o + pl.tp] = ll[1];
+          }
+        } else {
+          _Float16* ph = which == 0 ? pl.qh : pl.kh;
+          _Float16* pw = which == 0 ? pl.ql : pl.kl;
+          const float sc = which == 0 ? pl.qscale : 1.0f;
+          const size_t row = ((size_t)(fg >> 5) * pl.t_total + tok) * 32;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int d0 = 8 * g + 4 * lh;                      // registers 4g..4g+3 = features d0..d0+3
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + bias[fl + d0 + e]) * sc;
+            unsigned int h0, h1, l0, l1;
+            split_pk(v[0], v[1], h0, l0);
+            split_pk(v[2], v[3], h1, l1);
+            *reinterpret_cast<u32x2*>(ph + row + d0) = (u32x2){h0, h1};
+            *reinterpret_cast<u32x2*>(pw + row + d0) = (u32x2){l0, l1};
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + l31;
@@ -398,13 +462,13 @@ int launch_gemm(const float* x, int m, int k, const float* w, int n, const float
         attr_done = true;
       }
       hipLaunchKernelGGL(kern, dim3(cdiv(n, 256) * cdiv(m, 256)), dim3(512), lds(256, 256), stream, x, m, k,
-                         w, n, bias, residual, out);
+                         w, n, bias, residual, out, spr::AttnPlanes(), 0);
     } else if (n > 32) {
       hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 64, 4, 1, ACT, RES>), dim3(cdiv(n, 64) * cdiv(m, 128)),
-                         dim3(256), lds(128, 64), stream, x, m, k, w, n, bias, residual, out);
+                         dim3(256), lds(128, 64), stream, x, m, k, w, n, bias, residual, out, spr::AttnPlanes(), 0);
     } else {
       hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 32, 4, 1, ACT, RES>), dim3(cdiv(n, 32) * cdiv(m, 128)),
-                         dim3(256), lds(128, 32), stream, x, m, k, w, n, bias, residual, out);
+                         dim3(256), lds(128, 32), stream, x, m, k, w, n, bias, residual, out, spr::AttnPlanes(), 0);
     }
   } else if (n % 64 == 0) {
     hipLaunchKernelGGL((spr::k_gemm_nt<2, 2, ACT, RES>), dim3((n / 64) * cdiv(m, 64)), dim3(256), 0, stream,
@@ -417,6 +481,28 @@ int launch_gemm(const float* x, int m, int k, const float* w, int n, const float
   return 0;
 }
 }  // namespace
+
+int spr::launch_inproj_planes(const float* x, int m, int k, const float* w, int n, const float* bias, int f0,
+                              const AttnPlanes& planes, hipStream_t stream) {
+  SPR_REQUIRE(n % 256 == 0 && f0 % 256 == 0 && k % BK == 0 && m >= 1 && bias != nullptr,
+              "in-projection planes: bad shape (m=%d k=%d n=%d)", m, k, n);
+  auto kern = spr::k_gemm_nt_h3<256, 256, 4, 2, SPR_ACT_NONE, false, true>;
+  const size_t lds = (size_t)(256 + 256) * spr::HS * 2 * sizeof(_Float16);
+  static bool attr_done = false;
+  if (!attr_done) {
+    SPR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(cdiv(n, 256) * cdiv(m, 256)), dim3(512), lds, stream, x, m, k, w, n, bias,
+                     (const float*)nullptr, (float*)nullptr, planes, f0);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+int spr::launch_linear_plain(const float* x, int m, int k, const float* w, int n, const float* bias, float* out,
+                             hipStream_t stream) {
+  return launch_gemm<SPR_ACT_NONE, false>(x, m, k, w, n, bias, nullptr, out, stream);
+}
 
 extern "C" int spr_linear(const float* x, int m, int k, const float* w, int n, const float* bias,
                           const float* residual, int act, float* out, void* stream_) {

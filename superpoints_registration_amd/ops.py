@@ -255,6 +255,28 @@ def attention(q, k, v, cu, kv_seg, max_len: int, nhead: int, out=None) -> torch.
     return out
 
 
+def attention_inproj(x_qk, x_v, w_in, b_in, cu, kv_seg, max_len: int, nhead: int) -> torch.Tensor:
+    """In-projection (packed [3d, d] weight, q/k from x_qk, v from x_v) + attention core."""
+    x_qk = _dev(x_qk, "x_qk", torch.float32)
+    x_v = x_qk if x_v is x_qk else _dev(x_v, "x_v", torch.float32)
+    w_in = _dev(w_in, "w_in", torch.float32)
+    b_in = _dev(b_in, "b_in", torch.float32)
+    T, d = x_qk.shape
+    assert x_v.shape == (T, d) and w_in.shape == (3 * d, d) and b_in.shape == (3 * d,)
+    hd = d // nhead
+    cu = _dev(cu, "cu", torch.int32)
+    kv_seg = _dev(kv_seg, "kv_seg", torch.int32)
+    nseg = cu.numel() - 1
+    out = torch.empty((T, d), dtype=torch.float32, device=x_qk.device)
+    L = _lib.lib()
+    ws = _workspace(L.spr_attn_inproj_workspace_bytes(T, nseg, nhead, hd), x_qk.device)
+    _lib.check(L.spr_attn_inproj_varlen_fwd(_ptr(x_qk), _ptr(x_v), T, _ptr(w_in), _ptr(b_in), _ptr(cu),
+                                            _ptr(kv_seg), nseg, int(max_len), nhead, hd, 1.0 / math.sqrt(hd),
+                                            _ptr(out), out.stride(0), _ptr(ws), ws.numel(), _stream(x_qk)),
+               "spr_attn_inproj_varlen_fwd")
+    return out
+
+
 def set_attn_mode(mode: int) -> None:
     """1 = split-fp16 MFMA (default), 0 = exact f32 MFMA."""
     _lib.check(_lib.lib().spr_set_attn_mode(int(mode)), "spr_set_attn_mode")

@@ -108,14 +108,18 @@ class TransformerCrossEncoderLayer(nn.Module):
     def _mha(self, mha: nn.MultiheadAttention, qk_in, v_in, cu, kv_seg, max_len, residual):
         d = self.d_model
         W, b = mha.in_proj_weight.detach(), mha.in_proj_bias.detach()
-        if v_in is qk_in:
-            qkv = ops.linear(qk_in, W, b)                      # [T, 3d]
-            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        if d == 256:
+            # in-projection GEMM writes the attention operand planes directly
+            o = ops.attention_inproj(qk_in, v_in, W, b, cu, kv_seg, max_len, self.nhead)
         else:
-            qk = ops.linear(qk_in, W[:2 * d], b[:2 * d])       # [T, 2d]
-            q, k = qk[:, :d], qk[:, d:]
-            v = ops.linear(v_in, W[2 * d:], b[2 * d:])
-        o = ops.attention(q, k, v, cu, kv_seg, max_len, self.nhead)
+            if v_in is qk_in:
+                qkv = ops.linear(qk_in, W, b)                      # [T, 3d]
+                q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+            else:
+                qk = ops.linear(qk_in, W[:2 * d], b[:2 * d])       # [T, 2d]
+                q, k = qk[:, :d], qk[:, d:]
+                v = ops.linear(v_in, W[2 * d:], b[2 * d:])
+            o = ops.attention(q, k, v, cu, kv_seg, max_len, self.nhead)
         return ops.linear(o, mha.out_proj.weight.detach(), mha.out_proj.bias.detach(),
                           residual=residual)
 

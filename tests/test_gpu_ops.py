@@ -134,6 +134,42 @@ def test_attention_core_vs_fp64(device, mode):
     ops.set_attn_mode(1)
 
 
+@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("shared", [True, False])
+def test_attention_with_fused_in_projection_vs_fp64(device, mode, shared):
+    """spr_attn_inproj_varlen_fwd = packed in-projection (F.multi_head_attention_forward) + core.
+    Ragged segments incl. lengths that are not multiples of 4/8 (plane alignment), a
+    segment shorter than a tile, > 256 tokens in total so that the fused GEMM path runs."""
+    ops.set_attn_mode(mode)
+    ops.set_gemm_mode(mode)
+    lens = [301, 70, 257, 33, 129, 1]
+    tot = sum(lens)
+    x_qk = synthetic.rand((tot, 256), 31, -1.5, 1.5)
+    x_v = x_qk if shared else synthetic.rand((tot, 256), 32, -1.5, 1.5)
+    w = synthetic.rand((768, 256), 33, -0.1, 0.1)
+    b = synthetic.rand((768,), 34, -0.2, 0.2)
+    cu = ops.lengths_to_cu(lens, device)
+    d_qk = x_qk.to(device)
+    d_v = d_qk if shared else x_v.to(device)
+    kv_seg = [1, 0, 3, 2, 5, 4]
+    seg = torch.tensor(kv_seg, dtype=torch.int32, device=device)
+    o = ops.attention_inproj(d_qk, d_v, w.to(device), b.to(device), cu, seg, max(lens), 8)
+    qk = x_qk.double() @ w[:512].double().t() + b[:512].double()
+    vv = x_v.double() @ w[512:].double().t() + b[512:].double()
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    ref = torch.zeros((tot, 256), dtype=torch.float64)
+    for s in range(len(lens)):
+        ks = kv_seg[s]
+        q = qk[offs[s]:offs[s + 1], :256].view(-1, 8, 32).transpose(0, 1)
+        k = qk[offs[ks]:offs[ks + 1], 256:].view(-1, 8, 32).transpose(0, 1)
+        v = vv[offs[ks]:offs[ks + 1]].view(-1, 8, 32).transpose(0, 1)
+        a = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(32), -1)
+        ref[offs[s]:offs[s + 1]] = (a @ v).transpose(0, 1).reshape(-1, 256)
+    _close(o.cpu().numpy(), ref.numpy(), 5e-6, f"fused in-projection attention mode={mode} shared={shared}")
+    ops.set_attn_mode(1)
+    ops.set_gemm_mode(1)
+
+
 def _layer(device, seed=21):
     layer = TransformerCrossEncoderLayer(256, 8, 1024, 0.0, 'relu', True, True, True, 'dot_prod')
     synthetic.fill_parameters(layer, seed=seed)
