@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs-per-step", type=int, default=16)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="concurrent group forwards per step, each on its own HIP stream (streams.py); 2 with "
+                         "--pairs-per-step 32 is the highest-throughput setting, but co-running kernels "
+                         "stretch each other, so the per-kernel roofline leg is only meaningful at 1")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--config", default="3dmatch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -136,8 +140,12 @@ def main():
     batch = {"src_xyz": [torch.from_numpy(p[0]).to(dev) for p in pairs],
              "tgt_xyz": [torch.from_numpy(p[1]).to(dev) for p in pairs]}
 
+    from superpoints_registration_amd.streams import StreamedForward
+    runner = StreamedForward(model, n_streams=max(1, args.streams), device=dev)
+
     def step():
-        return model(batch)   # RegTR.forward leaves the pyramid in batch['kpconv_meta']
+        with torch.no_grad():
+            return runner(batch)   # leaves the pyramid(s) in batch['kpconv_meta']
 
     for _ in range(max(args.warmup, 1)):
         out = step()
@@ -156,7 +164,8 @@ def main():
         nqs = (ctypes.c_int * cap)()
         ms = (ctypes.c_float * cap)()
         n = L.spr_prof_read(cap, codes, nqs, ms)
-        per_fwd = [r for r in kpconv_alg_bytes(batch['kpconv_meta'], model)
+        metas = batch['kpconv_meta'] if isinstance(batch['kpconv_meta'], list) else [batch['kpconv_meta']]
+        per_fwd = [r for meta in metas for r in kpconv_alg_bytes(meta, model)
                    if r['cin'] % 16 == 0]          # cin == 1 runs the small dedicated kernel
         # aggregate per kernel instantiation (cin, cout) == one rocprof kernel name
         agg = {}
@@ -221,10 +230,12 @@ def main():
         "config": {"workload": f"synthetic {args.points}-pt pairs, full KPConv backbone + superpoint attn "
                                f"+ {'Sinkhorn-' if cfg.use_sinkhorn else ''}SVD pose ({args.config} config, "
                                f"BASELINE configs[1])",
-                   "pairs_per_step_per_gpu": B, "points_per_cloud": args.points,
+                   "pairs_per_step_per_gpu": B, "streams_per_gpu": max(1, args.streams),
+                   "points_per_cloud": args.points,
                    "point_order": "canonical" if args.canonical_order else "reference",
                    "upsample_indices": not args.skip_upsamples,
-                   "parallelism": f"pairs sharded over {world} rank(s), no data-path collective"},
+                   "parallelism": f"pairs sharded over {world} rank(s), no data-path collective; per rank "
+                                  f"{max(1, args.streams)} concurrent forwards of {B // max(1, args.streams)} pairs"},
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -29,6 +29,8 @@
 // a 1-pass pre-kernel writes one flag byte per support point.
 #include <vector>
 
+#include <mutex>
+
 #include "spr_common.h"
 
 namespace spr {
@@ -532,6 +534,7 @@ struct ProfRec {
   int nq;
 };
 static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;   // launches may come from several host threads (one per stream)
 static bool g_prof_on = false;
 
 struct ProfScope {
@@ -551,6 +554,7 @@ struct ProfScope {
   ~ProfScope() {
     if (!on) return;
     (void)hipEventRecord(rec.end, stream);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back(rec);
   }
 };

@@ -135,3 +135,25 @@ def test_full_size_pair_against_the_cpu_oracle(device):
     assert float((out["tgt_feat"][0][0].cpu() - ct).abs().max()) <= 1e-4 * scale
     err = np.linalg.norm(out["pose"][0].cpu().numpy() - ref["pose"][0].numpy())
     assert err < 1e-4, f"pose error {err:.2e}"
+
+
+def test_streamed_forward_equals_group_forwards(device):
+    """streams.StreamedForward: a batch as two concurrent group forwards on two HIP
+    streams == the same groups run one after the other (bitwise), pair order kept."""
+    from superpoints_registration_amd.streams import StreamedForward, split_batch
+    cfg = get_config("3dmatch")
+    model = RegTR(cfg)
+    synthetic.fill_parameters(model, seed=0)
+    model = model.to(device).eval()
+    pairs = [synthetic.make_pair(3000 + 211 * i, seed=40 + i) for i in range(5)]
+    batch = {"src_xyz": [torch.from_numpy(p[0]).to(device) for p in pairs],
+             "tgt_xyz": [torch.from_numpy(p[1]).to(device) for p in pairs]}
+    with torch.no_grad():
+        ref = [model(sub) for sub in split_batch(batch, 2)]       # groups of 3 and 2 pairs
+        out = StreamedForward(model, n_streams=2, device=device)(batch)
+    torch.cuda.synchronize()
+    assert out["pose"].shape == (5, 3, 4)
+    assert torch.equal(out["pose"], torch.cat([r["pose"] for r in ref]))
+    flat = [f for r in ref for f in r["src_feat"]]
+    assert len(out["src_feat"]) == 5 and all(torch.equal(a, b) for a, b in zip(out["src_feat"], flat))
+    assert isinstance(batch["kpconv_meta"], list) and len(batch["kpconv_meta"]) == 2
