@@ -11,25 +11,24 @@
 //     :409-412  divide by max(1, #{k : sum_c x[idx[n,k],c] > 0})
 //
 // The reference materialises [N,K,15,3] and [N,K,Cin] temporaries and runs
-// two batched matmuls.  Here one fused kernel per call:
-//   phase 1 (per wave, per query): the influence x feature contraction is a
-//     16x(16*t)x4 exact-f32 MFMA (v_mfma_f32_16x16x4_f32): lane (p = l&15,
-//     j = l>>4) computes ONE influence weight w[p][neighbour 4s+j] -- that is
-//     exactly the A-operand layout -- and loads 16 consecutive channels of
-//     neighbour j as the B operand.  Neighbour rows are gathered straight
-//     from HBM/L2 (64-byte runs per 16 lanes), 4 k-steps (16 neighbours) of
-//     loads are issued before the first use.
-//   phase 2 (per workgroup): the [TQ x 15*CC] weighted-feature tile is
-//     transposed through LDS (row stride = 2 mod 32 words -> conflict free
-//     A-fragment reads) and contracted with W[15*Cin, Cout] by the same MFMA
-//     with queries on the M axis; W streams from L2.
-//   Channels are processed in chunks of CC <= 64 so the LDS tile stays at
-//   ~61 KB (2 workgroups per CU); phase-2 accumulators persist across chunks.
-// The neighbour-count normaliser needs sum_c x[i,c] > 0 per support point:
-// a 1-pass pre-kernel writes one flag byte per support point.
-#include <vector>
-
+// two batched matmuls.  Here one fused kernel per call (k_kpconv_mfma, details
+// at its definition):
+//   phase 1 (per wave, per query): the influence x feature contraction is an
+//     exact-f32 MFMA (v_mfma_f32_16x16x4_f32): lane (p = l&15, j = l>>4)
+//     computes ONE influence weight w[p][neighbour 4s+j] -- exactly the
+//     A-operand layout -- and loads a row slice of neighbour j as the B
+//     operand; neighbour indices are staged in LDS, positions + the
+//     neighbour-count flag come as one 16-byte record per support point;
+//   phase 2 (per workgroup): the [TQ x 15*CC] weighted-feature tile (split
+//     fp16 hi/lo in LDS) is contracted with W[15*Cin, Cout] by
+//     v_mfma_f32_16x16x32_f16; W streams from L2 in MFMA-fragment order.
+//   Channels are processed in chunks of CC <= 64 (one 123 KB LDS tile per
+//   workgroup); phase-2 accumulators persist across chunks.
+// Pre-kernels per call: k_rowflag (flag = sum_c x[i,c] > 0 and the packed
+// support records), k_w_prep (weights -> fragment-order hi/lo planes).
+// cin == 1 (the first block) has its own kernel, k_kpconv_cin1.
 #include <mutex>
+#include <vector>
 
 #include "spr_common.h"
 
@@ -218,13 +217,14 @@ template <> struct VecH<4> { typedef _Float16 type __attribute__((ext_vector_typ
 //   CC    channel chunk (32 or 64); NTC = CC/16 phase-1 n-tiles
 //   TQ    queries per workgroup (multiple of 16); MT = TQ/16 m-tiles
 //   NTW   phase-2 n-tiles (of 16 output channels) per wave
-//   NW    waves per workgroup (4 or 8)
-// Wave w: phase 1 -> queries [w*TQ/NW, (w+1)*TQ/NW); phase 2 -> m-tile (w % MT),
-// n-tiles [(w / MT) * NTW, +NTW).  Requires cout == 16 * NTW * (NW / MT).
+//   NW    phase-2 waves; SK = 1: wave -> (m-tile w % MT, n-group w / MT);
+//         SK = 2: wave -> (n-group, k-half), every wave all m-tiles, the two
+//         k-halves summed through LDS.  cout == 16 * NTW * (number of n-groups)
+//   P1W   waves of the workgroup (phase 1 uses all of them; P1W >= NW)
+// Wave w: phase 1 -> queries [w*TQ/P1W, (w+1)*TQ/P1W).
 // Phase 2 streams the whole [15*Cin, Cout] weight matrix from L2 once per
-// workgroup, and that stream is what bounds the kernel (measured: time is
-// proportional to Cout, independent of gather locality and of the MFMA type),
-// so TQ is as large as LDS allows: 32 queries x 64 channels = 125 KB.
+// workgroup (in fragment order: whole 128-byte lines per wave load), so TQ is
+// as large as LDS allows: 32 queries x 64 channels = 123 KB.
 //
 // Phase 1 (exact f32): "items" = (query, block of 16 neighbours); only LIVE
 // blocks are enumerated (rows are distance sorted with trailing shadow

@@ -9,11 +9,16 @@
 //   PositionEmbeddingCoordsSine.forward  transformer/position_embedding.py:29-50
 //
 // GEMM: out[M,N] = act(X[M,K] @ W[N,K]^T + bias + residual), both operands
-// K-contiguous ("NT").  Exact-f32 matrix cores (v_mfma_f32_32x32x2_f32: a
-// k-ordered fmaf chain, no reduced-precision path), one 32x32 accumulator per
-// wave, BMxBN workgroup tile staged through LDS with a row stride of 33 words
-// (conflict-free fragment reads); the next K-slab is prefetched into
-// registers while the current one feeds the MFMAs.
+// K-contiguous ("NT").  Two kernels, chosen by spr_set_gemm_mode:
+//   k_gemm_nt_h3 (default)  split-fp16 operands (fp32-level accuracy), three
+//     v_mfma_f32_32x32x16_f16 per k-step; 256x256 / 128x64 / 128x32 tiles; an
+//     optional epilogue writes the attention operand planes (attn_planes.h)
+//     instead of a row-major fp32 matrix;
+//   k_gemm_nt               exact-f32 matrix cores (v_mfma_f32_32x32x2_f32: a
+//     k-ordered fmaf chain), one 32x32 accumulator per wave, LDS row stride of
+//     33 words (conflict-free fragment reads).
+// In both the next K-slab is prefetched into registers (inline-asm loads +
+// explicit s_waitcnt) while the current one feeds the MFMAs.
 #include "attn_planes.h"
 #include "spr_common.h"
 

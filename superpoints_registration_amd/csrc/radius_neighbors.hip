@@ -20,6 +20,9 @@
 //      arithmetic (explicit _rn intrinsics, no FMA contraction); the `limit`
 //      nearest by (d2, index) are kept in an LDS-resident sorted list
 //      (slot-major layout -> conflict-free), rows are padded with ns.
+// That is algo 1 (no limit on the clouds' extent).  The default, algo 0, replaces
+// steps 3-4 by a dense per-cloud cell table (counting sort, no key search) and a
+// scan + sort kernel pair -- see "Fast path" below.  Both give identical rows.
 // Ties: the reference's std::sort leaves equal-d2 runs in kd-tree visit order;
 // this kernel orders them by index (documented; tests canonicalise tie runs).
 #include <cstring>
@@ -197,10 +200,13 @@ __global__ __launch_bounds__(BLOCK) void k_query(
 //   k_cell_count  one integer atomic per support point (spread over ~N cells)
 //   rocPRIM exclusive scan over the cell counts -> cell starts
 //   k_cell_scatter  counting-sort scatter of (xyz, index) records
-//   k_query_table one thread per query: the 9 (dz,dy) rows of the 3x3x3
-//                 neighbourhood are 9 contiguous record ranges whose bounds
-//                 are 18 independent loads; candidates stream as 16-byte
-//                 records, 4 in flight.
+//   k_scan_table  one thread per query, no LDS (full occupancy): the 9 (dz,dy)
+//                 rows of the 3x3x3 neighbourhood are 9 contiguous record
+//                 ranges whose bounds are 18 independent loads; candidates
+//                 stream as 16-byte records, 8 in flight; in-range ones are
+//                 appended as packed (d2, index) keys to a scratch row of
+//                 capacity 2*limit.  Self searches walk the queries in cell order.
+//   k_sort_rows   rank sort of each scratch row in LDS, cut to `limit`.
 // The order inside a cell depends on atomic arrival order, the OUTPUT does
 // not: rows are ordered by (d2, index) and the K-nearest cut uses the same
 // total order.
