@@ -248,6 +248,36 @@ int spr_sinkhorn_correspondences(const float* feat, int d, const float* xyz,
 int spr_gather_rows(const float* x, int n_src, int c, const int* idx, int n,
                     float* out, void* stream);
 
+/* ---- losses (forward) of RegTR.compute_loss -- SURVEY 8f row 1 --------------
+ * models/qk_regtr_full.py:313-368.  Deterministic reductions (fixed partition,
+ * float64 accumulation).  Scalars are written to device memory (out[0]).
+ *
+ * spr_overlap_pool: one level of compute_overlaps (backbone_kpconv/kpconv.py:
+ *   552-578): out[q] = clamp(mean over the valid pool entries of ov_prev, 0, 1).
+ * spr_bce_logits_mean: nn.BCEWithLogitsLoss(reduction='mean') (:90, :329).
+ * spr_infonce_pair: InfoNCELossFull.compute_infonce (models/losses/
+ *   feature_loss.py:268-296) for ONE pair; anchor_xyz are the source keypoints,
+ *   transformed by pose_gt [3,4] inside (se3_transform, :341-345).
+ * spr_transform_l1_pair: mean |T_gt x - T_pred x| over one pair's keypoints
+ *   (:349-355).   spr_sum_scaled: out[0] = scale * sum(values[0..n)).
+ * ws: spr_loss_workspace_bytes(max anchors, max positives, d) covers all four.
+ */
+size_t spr_loss_workspace_bytes(int n_max, int m_max, int d);
+int spr_overlap_pool(const float* ov_prev, int ns_prev, const int* pool,
+                     int pool_stride, int w, int nq, float* out, void* stream);
+int spr_bce_logits_mean(const float* x, const float* y, int n, float* out,
+                        void* ws, size_t ws_bytes, void* stream);
+int spr_infonce_pair(const float* anchor_feat, int n, const float* positive_feat,
+                     int m, int d, const float* anchor_xyz, const float* pose_gt,
+                     const float* positive_xyz, const float* W, float r_p,
+                     float r_n, float* out, void* ws, size_t ws_bytes,
+                     void* stream);
+int spr_transform_l1_pair(const float* pose_gt, const float* pose_pred,
+                          const float* xyz, int n, float* out, void* ws,
+                          size_t ws_bytes, void* stream);
+int spr_sum_scaled(const float* values, int n, float scale, float* out,
+                   void* stream);
+
 /* Per-launch timing of the fused KPConv kernel with HIP events recorded on the
  * launch stream (used by bench.py for the roofline figure; off by default).
  * spr_prof_enable(1) clears the log and starts recording, spr_prof_enable(0)

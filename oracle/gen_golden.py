@@ -222,6 +222,51 @@ def gen_regtr(cfg_tag, B):
           [tuple(meta['points'][l].shape) for l in range(L)], 'pose', out['pose'][0, :, 3].numpy())
 
 
+def loss_inputs(cfg_tag, B):
+    """Ground-truth side of compute_loss for the golden pairs (seeded, regenerated by the
+    tests): the pairs' synthetic pose and per-point overlap masks (a fixed pseudo-random
+    ~60 % pattern -- compute_loss only consumes them, qk_regtr_full.py:321-329)."""
+    pairs, sizes = pairs_for(cfg_tag, B)
+    if cfg_tag == '3dmatch':
+        full = [synthetic.make_pair(max(n, m), seed=40 + i, extent=0.45, jitter=0.002,
+                                    trans=(0.03, -0.02, 0.01)) for i, (n, m) in enumerate(sizes)]
+    elif cfg_tag == 'kitti':
+        full = [synthetic.make_pair(max(n, m), seed=50 + i, extent=6.0, jitter=0.02,
+                                    trans=(0.4, -0.2, 0.05)) for i, (n, m) in enumerate(sizes)]
+    else:
+        full = [synthetic.make_sphere_pair(1024, seed=60 + i, radius=0.2) for i in range(B)]
+    pose = np.stack([f[2] for f in full]).astype(np.float32)
+    rng = np.random.default_rng(777)
+    src_ov = [rng.random(n) < 0.6 for n, _ in sizes]
+    tgt_ov = [rng.random(m) < 0.6 for _, m in sizes]
+    return pose, src_ov, tgt_ov
+
+
+def gen_loss(cfg_tag, B=2):
+    """Reference RegTR.compute_loss (qk_regtr_full.py:313-368) on the golden pairs."""
+    model, cfg = ref_harness.make_model(f'qk_regtr_full_{cfg_tag}.yaml', seed=0)
+    synthetic.fill_parameters(model, seed=0)
+    pairs, sizes = pairs_for(cfg_tag, B)
+    src = [p[0][:n] for p, (n, m) in zip(pairs, sizes)]
+    tgt = [p[1][:m] for p, (n, m) in zip(pairs, sizes)]
+    pose, src_ov, tgt_ov = loss_inputs(cfg_tag, B)
+    batch = {'src_xyz': [torch.from_numpy(s) for s in src], 'tgt_xyz': [torch.from_numpy(t) for t in tgt],
+             'pose': torch.from_numpy(pose),
+             'src_overlap': [torch.from_numpy(o) for o in src_ov],
+             'tgt_overlap': [torch.from_numpy(o) for o in tgt_ov]}
+    with torch.no_grad():
+        out = model(batch)
+        losses = model.compute_loss(out, batch)
+    p = len(batch['kpconv_meta']['stack_lengths']) - 1
+    fx = {'B': np.int32(B), 'seed': np.int32(0),
+          'overlap_gt': batch['overlap_pyr'][f'pyr_{p}'].numpy().astype(np.float32)}
+    for k, v in losses.items():
+        fx[f'loss_{k}'] = np.float64(float(v))
+    path = os.path.join(OUT, f'loss_{cfg_tag}_b{B}.npz')
+    np.savez_compressed(path, **fx)
+    print(os.path.basename(path), {k: float(v) for k, v in losses.items()})
+
+
 def main():
     assert ref_harness.available(), "needs /root/reference (dev container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -235,6 +280,9 @@ def main():
         for tag in ('3dmatch', 'kitti', 'modelnet'):
             if tag in what:
                 gen_regtr(tag, 2)
+        for tag in ('3dmatch', 'kitti', 'modelnet'):
+            if f'loss_{tag}' in what or 'loss' in what:
+                gen_loss(tag, 2)
     finally:
         os.chdir(cwd)
 

@@ -47,6 +47,12 @@ SIGNATURES = {
     "spr_sinkhorn_workspace_bytes": (_sz, [_vp, _i]),
     "spr_sinkhorn_correspondences": (_i, [_vp, _i, _vp, _vp, _vp, _i, _f, _f, _i, _i, _vp, _vp, _vp,
                                           _sz, _vp]),
+    "spr_loss_workspace_bytes": (_sz, [_i, _i, _i]),
+    "spr_overlap_pool": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "spr_bce_logits_mean": (_i, [_vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "spr_infonce_pair": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _sz, _vp]),
+    "spr_transform_l1_pair": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "spr_sum_scaled": (_i, [_vp, _i, _f, _vp, _vp]),
     "spr_gather_rows": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     "spr_selftest": (_i, [_vp]),
     "spr_prof_enable": (_i, [_i]),

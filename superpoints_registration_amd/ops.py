@@ -336,6 +336,68 @@ def weighted_procrustes(a, b, w, pair_cu) -> torch.Tensor:
     return out
 
 
+# ---- losses (forward), SURVEY 8f row 1 -------------------------------------------
+def overlap_pool(ov_prev, pool_idx, ns_prev: int):
+    """One level of compute_overlaps (kpconv.py:552-578).  pool_idx int32 [Nq, W]."""
+    ov_prev = _dev(ov_prev, "ov_prev", torch.float32)
+    pool_idx = _dev(pool_idx, "pool_idx", torch.int32)
+    nq, w = pool_idx.shape
+    out = torch.empty((nq,), dtype=torch.float32, device=ov_prev.device)
+    _lib.check(_lib.lib().spr_overlap_pool(_ptr(ov_prev), int(ns_prev), _ptr(pool_idx), pool_idx.stride(0), w,
+                                           nq, _ptr(out), _stream(ov_prev)), "spr_overlap_pool")
+    return out
+
+
+def _loss_ws(n, m, d, device):
+    return _workspace(_lib.lib().spr_loss_workspace_bytes(int(n), int(m), int(d)), device)
+
+
+def bce_logits_mean(x, y):
+    x = _dev(x, "x", torch.float32)
+    y = _dev(y, "y", torch.float32)
+    assert x.shape == y.shape and x.dim() == 1
+    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    ws = _loss_ws(x.numel(), 1, 32, x.device)
+    _lib.check(_lib.lib().spr_bce_logits_mean(_ptr(x), _ptr(y), x.numel(), _ptr(out), _ptr(ws), ws.numel(),
+                                              _stream(x)), "spr_bce_logits_mean")
+    return out[0]
+
+
+def infonce_pair(anchor_feat, positive_feat, anchor_xyz, pose_gt, positive_xyz, W, r_p: float, r_n: float):
+    """InfoNCELossFull.compute_infonce for one pair; anchor_xyz is transformed by pose_gt [3,4] inside."""
+    a = _dev(anchor_feat, "anchor_feat", torch.float32)
+    p = _dev(positive_feat, "positive_feat", torch.float32)
+    n, d = a.shape
+    m = p.shape[0]
+    out = torch.empty((1,), dtype=torch.float32, device=a.device)
+    ws = _loss_ws(n, m, d, a.device)
+    _lib.check(_lib.lib().spr_infonce_pair(_ptr(a), n, _ptr(p), m, d, _ptr(_dev(anchor_xyz, "anchor_xyz", torch.float32)),
+                                           _ptr(_dev(pose_gt, "pose_gt", torch.float32)),
+                                           _ptr(_dev(positive_xyz, "positive_xyz", torch.float32)),
+                                           _ptr(_dev(W, "W", torch.float32)), float(r_p), float(r_n), _ptr(out),
+                                           _ptr(ws), ws.numel(), _stream(a)), "spr_infonce_pair")
+    return out[0]
+
+
+def transform_l1_pair(pose_gt, pose_pred, xyz):
+    xyz = _dev(xyz, "xyz", torch.float32)
+    out = torch.empty((1,), dtype=torch.float32, device=xyz.device)
+    ws = _loss_ws(xyz.shape[0], 1, 32, xyz.device)
+    _lib.check(_lib.lib().spr_transform_l1_pair(_ptr(_dev(pose_gt, "pose_gt", torch.float32)),
+                                                _ptr(_dev(pose_pred, "pose_pred", torch.float32)), _ptr(xyz),
+                                                xyz.shape[0], _ptr(out), _ptr(ws), ws.numel(), _stream(xyz)),
+               "spr_transform_l1_pair")
+    return out[0]
+
+
+def sum_scaled(values, scale: float = 1.0):
+    values = _dev(values, "values", torch.float32)
+    out = torch.empty((1,), dtype=torch.float32, device=values.device)
+    _lib.check(_lib.lib().spr_sum_scaled(_ptr(values), values.numel(), float(scale), _ptr(out), _stream(values)),
+               "spr_sum_scaled")
+    return out[0]
+
+
 def gather_rows(x, idx) -> torch.Tensor:
     x = _dev(x, "x", torch.float32)
     idx = _dev(idx, "idx", torch.int32)

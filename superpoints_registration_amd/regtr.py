@@ -154,6 +154,50 @@ class RegTR(nn.Module):
             'overlap_prob_list': vals, 'ind_list': inds,
         }
 
+    # ------------------------------------------------------------------ #
+    @torch.no_grad()
+    def compute_loss(self, pred, batch):
+        """Forward of RegTR.compute_loss (qk_regtr_full.py:313-368): overlap BCE on the
+        coarsest level of compute_overlaps, InfoNCE feature loss against the ground-truth
+        transformed keypoints, L1 transform loss; total = T + 0.1 feature + overlap.
+        batch needs 'pose' [B,3,4], 'src_overlap' / 'tgt_overlap' (per-point masks) and the
+        'kpconv_meta' a forward left there.  Values only: no autograd graph (backward is
+        the next row)."""
+        cfg = self.cfg
+        if cfg.get('feature_loss_type', 'infonce') != 'infonce':
+            raise NotImplementedError("only the InfoNCE feature loss is selected by the shipped configs")
+        if cfg.get('inlier_loss_on', False):
+            raise NotImplementedError("inlier_loss_on is off in every shipped config")
+        meta = batch['kpconv_meta']
+        device = meta['points'][0].device
+        B = len(batch['src_xyz'])
+        pose_gt = batch['pose'].to(device=device, dtype=torch.float32).contiguous()
+
+        # compute_overlaps (kpconv.py:552-578): average the per-point masks up the pyramid
+        ov = torch.cat([o.to(device) for o in list(batch['src_overlap']) + list(batch['tgt_overlap'])]).float()
+        pyr = {'pyr_0': ov}
+        for p in range(1, len(meta['points'])):
+            ov = ops.overlap_pool(ov, meta['_i32'][('pools', p - 1)], meta['points'][p - 1].shape[0])
+            pyr[f'pyr_{p}'] = ov
+        batch['overlap_pyr'] = pyr
+
+        # overlap loss: the (already sigmoided) predictions go through BCEWithLogits (:248, :329)
+        pred_ov = torch.cat([o[0, :, 0] for o in list(pred['src_overlap']) + list(pred['tgt_overlap'])])
+        losses = {'overlap': ops.bce_logits_mean(pred_ov.contiguous(), ov)}
+
+        W = self.feature_criterion.W.detach()
+        feat, t_l1 = [], []
+        for b in range(B):
+            for i in cfg.get('feature_loss_on', [0]):
+                feat.append(ops.infonce_pair(pred['src_feat'][b][i].contiguous(), pred['tgt_feat'][b][i].contiguous(),
+                                             pred['src_kp'][b].contiguous(), pose_gt[b], pred['tgt_kp'][b].contiguous(),
+                                             W, cfg.r_p, cfg.r_n))
+            t_l1.append(ops.transform_l1_pair(pose_gt[b], pred['pose'][b].contiguous(), pred['src_kp'][b].contiguous()))
+        losses['feature'] = ops.sum_scaled(torch.stack(feat), 1.0 / len(feat))      # mean over pairs (:314)
+        losses['T'] = ops.sum_scaled(torch.stack(t_l1), 1.0)                        # sum over pairs (:353)
+        losses['total'] = losses['T'] + 0.1 * losses['feature'] + losses['overlap']
+        return losses
+
     def _pose_from_matches(self, xyz_c, val, ind, cu, cu_host, B):
         """arg-max correspondences -> weighted Procrustes for all pairs in one
         launch.  For pair b the matched set lives on the tgt tokens when

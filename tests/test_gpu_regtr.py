@@ -157,3 +157,31 @@ def test_streamed_forward_equals_group_forwards(device):
     flat = [f for r in ref for f in r["src_feat"]]
     assert len(out["src_feat"]) == 5 and all(torch.equal(a, b) for a, b in zip(out["src_feat"], flat))
     assert isinstance(batch["kpconv_meta"], list) and len(batch["kpconv_meta"]) == 2
+
+
+@pytest.mark.parametrize("tag", ["3dmatch", "kitti", "modelnet"])
+def test_compute_loss_matches_reference(device, tag):
+    """RegTR.compute_loss (HIP) vs the reference's own compute_loss on the golden pairs
+    (oracle/gen_golden.py gen_loss): the coarsest ground-truth overlap level is exact up to
+    float summation order (1e-6), each loss term within 5e-5 relative (the terms are means
+    over thousands of fp32 values whose inputs already carry the 1e-4 feature tolerance)."""
+    from oracle.gen_golden import loss_inputs
+    g = load_golden(f"loss_{tag}_b2.npz")
+    B = int(g["B"])
+    pairs, sizes = pairs_for(tag, B)
+    pose, src_ov, tgt_ov = loss_inputs(tag, B)
+    model = RegTR(get_config(tag))
+    synthetic.fill_parameters(model, seed=int(g["seed"]))
+    model = model.to(device).eval()
+    batch = {"src_xyz": [torch.from_numpy(pairs[b][0][:sizes[b][0]]).to(device) for b in range(B)],
+             "tgt_xyz": [torch.from_numpy(pairs[b][1][:sizes[b][1]]).to(device) for b in range(B)],
+             "pose": torch.from_numpy(pose).to(device),
+             "src_overlap": [torch.from_numpy(o).to(device) for o in src_ov],
+             "tgt_overlap": [torch.from_numpy(o).to(device) for o in tgt_ov]}
+    pred = model(batch)
+    losses = model.compute_loss(pred, batch)
+    p = len(batch["kpconv_meta"]["points"]) - 1
+    assert np.allclose(batch["overlap_pyr"][f"pyr_{p}"].cpu().numpy(), g["overlap_gt"], atol=1e-6)
+    for k in ("overlap", "T", "feature", "total"):
+        ref = float(g[f"loss_{k}"])
+        assert abs(float(losses[k]) - ref) <= 5e-5 * max(1.0, abs(ref)), (k, float(losses[k]), ref)
