@@ -34,6 +34,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TFS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA
 
 
 def parse():
@@ -158,8 +159,9 @@ def main():
 
     # ---- roofline of the dominant kernel (rank 0) -----------------------------
     roofline = None
+    roofline_attn = None
     if rank == 0:
-        cap = 64 * max(args.steps, 1)
+        cap = 256 * max(args.steps, 1)
         codes = (ctypes.c_int * cap)()
         nqs = (ctypes.c_int * cap)()
         ms = (ctypes.c_float * cap)()
@@ -177,6 +179,27 @@ def main():
         for r in per_fwd:
             fwd_bytes[r['code']] = fwd_bytes.get(r['code'], 0) + r['bytes']
             fwd_launches[r['code']] = fwd_launches.get(r['code'], 0) + 1
+        # ---- second leg: the attention core (the largest single kernel by GPU time), MFMA roofline
+        attn_ms = [ms[i] for i in range(n) if codes[i] == -1]
+        roofline_attn = None
+        if attn_ms:
+            d_model = cfg.d_embed
+            flops_fwd = []          # per forward: self + cross call of every layer do the same work pattern
+            for meta in metas:
+                lens = [int(v) for v in meta['_lens_host'][-1]]
+                Bm = len(lens) // 2
+                self_f = sum(4.0 * d_model * L * L for L in lens)
+                cross_f = sum(4.0 * d_model * lens[b] * lens[Bm + b] * 2 for b in range(Bm))
+                flops_fwd.append((self_f, cross_f))
+            avg_flops = sum(sf + cf for sf, cf in flops_fwd) / (2.0 * len(flops_fwd))   # per call
+            avg_ms_attn = sum(attn_ms) / len(attn_ms)
+            tfs = avg_flops / (avg_ms_attn * 1e-3) / 1e12
+            roofline_attn = dict(bound="mfma", achieved=round(tfs, 2), peak=MFMA_F16_PEAK_TFS, unit="TFLOP/s",
+                                 frac=round(tfs / MFMA_F16_PEAK_TFS, 5), traffic=None,
+                                 kernel="k_attn_h3 (varlen attention core, split-fp16: 3 MFMA per product)",
+                                 avg_launch_ms=round(avg_ms_attn, 5), launches=len(attn_ms),
+                                 alg_flops_per_launch=int(avg_flops),
+                                 mfma_flops_executed_per_launch=int(3 * avg_flops))
         best = None
         for code, a in agg.items():
             if code not in fwd_bytes or a['count'] % fwd_launches[code] != 0:
@@ -237,6 +260,7 @@ def main():
                    "parallelism": f"pairs sharded over {world} rank(s), no data-path collective; per rank "
                                   f"{max(1, args.streams)} concurrent forwards of {B // max(1, args.streams)} pairs"},
         "roofline": roofline,
+        "roofline_attention": roofline_attn,
     }
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, args.points)

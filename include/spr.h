@@ -278,12 +278,14 @@ int spr_transform_l1_pair(const float* pose_gt, const float* pose_pred,
 int spr_sum_scaled(const float* values, int n, float scale, float* out,
                    void* stream);
 
-/* Per-launch timing of the fused KPConv kernel with HIP events recorded on the
- * launch stream (used by bench.py for the roofline figure; off by default).
+/* Per-launch timing of the fused KPConv kernel and of the attention core kernel
+ * with HIP events recorded on the launch stream (used by bench.py for the
+ * roofline figures; off by default).
  * spr_prof_enable(1) clears the log and starts recording, spr_prof_enable(0)
  * clears and stops.  spr_prof_read synchronises on the recorded events and
  * returns up to max_records entries (all arrays HOST memory):
- *   codes[i] = cin * 100000 + cout, nqs[i] = query count, ms[i] = duration. */
+ *   codes[i] = cin * 100000 + cout (KPConv) or -1 (attention core), nqs[i] =
+ *   query / token count, ms[i] = duration. */
 int spr_prof_enable(int on);
 int spr_prof_read(int max_records, int* codes_host, int* nqs_host, float* ms_host);
 

@@ -620,6 +620,7 @@ extern "C" int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k,
     hipLaunchKernelGGL(k_attn_pack, dim3((unsigned)(tp / PT)), dim3(256), 0, stream, q, q_stride, k, k_stride,
                        v, v_stride, cu, nseg, d_model, t, (int)tp, scale * 1.4426950408889634f, qh, ql,
                        kh, kl, vth, vtl);
+    ProfScope prof(stream, -1, t);
     hipLaunchKernelGGL(k_attn_h3, grid, dim3(256), 0, stream, qh, ql, kh, kl, vth, vtl, t, (int)tp,
                        cu, kv_seg, nseg, nhead, out, o_stride);
   } else {
@@ -694,6 +695,7 @@ extern "C" int spr_attn_inproj_varlen_fwd(const float* x_qk, const float* x_v, i
       return rc;
   }
   dim3 grid(cdiv(max_len_host, QB2) * nhead * nseg);
+  ProfScope prof(stream, -1, t);
   hipLaunchKernelGGL(k_attn_h3, grid, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth, pl.vtl, t,
                      (int)tp, cu, kv_seg, nseg, nhead, out, o_stride);
   SPR_LAUNCH_CHECK();

@@ -1,6 +1,7 @@
 // Error reporting, version and an on-device self test of the two f32 MFMA
 // fragment layouts every kernel in this library relies on.
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "spr_common.h"
@@ -14,6 +15,20 @@ void set_error(const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// ---- per-launch timing records (ProfScope, spr_common.h) ----------------------
+struct ProfRec {
+  hipEvent_t beg, end;
+  int code, n;
+};
+static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+bool prof_enabled() { return g_prof_on; }
+void prof_push(hipEvent_t beg, hipEvent_t end, int code, int n) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof.push_back(ProfRec{beg, end, code, n});
 }
 
 namespace {
@@ -41,6 +56,33 @@ __global__ void k_test_32x32x2(const float* A, const float* B, float* D) {
 }  // namespace spr
 
 using namespace spr;
+
+extern "C" int spr_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof) {
+    (void)hipEventDestroy(r.beg);
+    (void)hipEventDestroy(r.end);
+  }
+  g_prof.clear();
+  g_prof_on = on != 0;
+  return 0;
+}
+
+extern "C" int spr_prof_read(int max_records, int* codes, int* nqs, float* ms) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  int n = 0;
+  for (auto& r : g_prof) {
+    if (n >= max_records) break;
+    if (hipEventSynchronize(r.end) != hipSuccess) break;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.beg, r.end) != hipSuccess) break;
+    codes[n] = r.code;
+    nqs[n] = r.n;
+    ms[n] = t;
+    ++n;
+  }
+  return n;
+}
 
 extern "C" int spr_version(void) { return SPR_VERSION; }
 extern "C" const char* spr_last_error(void) { return g_err; }

@@ -27,9 +27,6 @@
 // Pre-kernels per call: k_rowflag (flag = sum_c x[i,c] > 0 and the packed
 // support records), k_w_prep (weights -> fragment-order hi/lo planes).
 // cin == 1 (the first block) has its own kernel, k_kpconv_cin1.
-#include <mutex>
-#include <vector>
-
 #include "spr_common.h"
 
 namespace spr {
@@ -527,38 +524,6 @@ __global__ __launch_bounds__(64 * P1W) void k_kpconv_mfma(
     }
 }
 
-// ---- optional per-launch HIP-event timing (bench.py roofline leg) ------------
-struct ProfRec {
-  hipEvent_t beg, end;
-  int code;  // cin * 100000 + cout
-  int nq;
-};
-static std::vector<ProfRec> g_prof;
-static std::mutex g_prof_mu;   // launches may come from several host threads (one per stream)
-static bool g_prof_on = false;
-
-struct ProfScope {
-  hipStream_t stream;
-  bool on;
-  ProfRec rec;
-  ProfScope(hipStream_t s, int cin, int cout, int nq) : stream(s), on(g_prof_on) {
-    if (!on) return;
-    rec.code = cin * 100000 + cout;
-    rec.nq = nq;
-    if (hipEventCreate(&rec.beg) != hipSuccess || hipEventCreate(&rec.end) != hipSuccess) {
-      on = false;
-      return;
-    }
-    (void)hipEventRecord(rec.beg, stream);
-  }
-  ~ProfScope() {
-    if (!on) return;
-    (void)hipEventRecord(rec.end, stream);
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof.push_back(rec);
-  }
-};
-
 template <int CC, int TQ, int NTW, int NW, int SK, int P1W = NW>
 int launch_mfma(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
                 int nbr_stride, int kmax, int rows_sorted, const float* x, int cin,
@@ -570,7 +535,7 @@ int launch_mfma(const float* q_xyz, int nq, const float* s_xyz, int ns, const in
   const size_t lds = 2 * sizeof(_Float16) * (size_t)TQ * SH + sizeof(int) * (TQ + P1W) +
                      sizeof(int) * (size_t)P1W * QPW * nblk + sizeof(int) * (size_t)TQ * nblk * 16;
   auto kern = k_kpconv_mfma<CC, TQ, NTW, NW, SK, P1W>;
-  ProfScope prof(stream, cin, cout, nq);
+  ProfScope prof(stream, cin * 100000 + cout, nq);
   SPR_REQUIRE(lds <= 160 * 1024, "kpconv: neighbour rows too wide for the LDS tile (kmax=%d)", kmax);
   if (lds > 64 * 1024) {
     static bool raised = false;  // per instantiation
@@ -656,30 +621,4 @@ extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, in
                      inv_extent, flag, out);
   SPR_LAUNCH_CHECK();
   return 0;
-}
-
-// ---- profiling control (see include/spr.h) -----------------------------------
-extern "C" int spr_prof_enable(int on) {
-  for (auto& r : g_prof) {
-    (void)hipEventDestroy(r.beg);
-    (void)hipEventDestroy(r.end);
-  }
-  g_prof.clear();
-  g_prof_on = on != 0;
-  return 0;
-}
-
-extern "C" int spr_prof_read(int max_records, int* codes, int* nqs, float* ms) {
-  int n = 0;
-  for (auto& r : g_prof) {
-    if (n >= max_records) break;
-    if (hipEventSynchronize(r.end) != hipSuccess) break;
-    float t = 0.f;
-    if (hipEventElapsedTime(&t, r.beg, r.end) != hipSuccess) break;
-    codes[n] = r.code;
-    nqs[n] = r.nq;
-    ms[n] = t;
-    ++n;
-  }
-  return n;
 }

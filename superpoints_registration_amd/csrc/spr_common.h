@@ -61,6 +61,32 @@ struct Workspace {
   }
 };
 
+// ---- optional per-launch HIP-event timing (bench.py roofline legs) ----------
+// code: fused KPConv = cin * 100000 + cout; attention core (k_attn_h3 / k_attn) = -1.
+// Records are appended under a mutex (launches may come from several host
+// threads, one per stream); see spr_prof_enable / spr_prof_read in include/spr.h.
+bool prof_enabled();
+void prof_push(hipEvent_t beg, hipEvent_t end, int code, int n);
+struct ProfScope {
+  hipStream_t stream;
+  bool on;
+  hipEvent_t beg, end;
+  int code, n;
+  ProfScope(hipStream_t s, int code_, int n_) : stream(s), on(prof_enabled()), code(code_), n(n_) {
+    if (!on) return;
+    if (hipEventCreate(&beg) != hipSuccess || hipEventCreate(&end) != hipSuccess) {
+      on = false;
+      return;
+    }
+    (void)hipEventRecord(beg, stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(end, stream);
+    prof_push(beg, end, code, n);
+  }
+};
+
 // ---- device helpers --------------------------------------------------------
 #ifdef __HIPCC__
 typedef float f32x4 __attribute__((ext_vector_type(4)));
