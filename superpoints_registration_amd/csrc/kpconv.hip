@@ -271,7 +271,20 @@ __global__ __launch_bounds__(64 * P1W) void k_kpconv_mfma(
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int p16 = lane & 15, j4 = lane >> 4;
-  const int q0 = blockIdx.x * TQ;
+
+  // kernel point of this lane (lane 15 of each 16 is padding)
+  float kx = 0.f, ky = 0.f, kz = 0.f;
+  if (p16 < kKP) {
+    kx = kpts[3 * p16];
+    ky = kpts[3 * p16 + 1];
+    kz = kpts[3 * p16 + 2];
+  }
+
+  // Persistent workgroup: tiles blockIdx.x, blockIdx.x + gridDim.x, ... (one LDS-sized
+  // workgroup per CU, so a launch per tile only added dispatch latency between tiles).
+  const int ntiles = (nq + TQ - 1) / TQ;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int q0 = tile * TQ;
 
   // Stage the tile's neighbour rows in LDS once (coalesced), padded with the
   // shadow index: the gather pipeline then depends on LDS reads only.
@@ -304,14 +317,6 @@ __global__ __launch_bounds__(64 * P1W) void k_kpconv_mfma(
   __syncthreads();
   const int n_items = lnit[wave];
   const int* my_items = litem + wave * QPW * nblk;
-
-  // kernel point of this lane (lane 15 of each 16 is padding)
-  float kx = 0.f, ky = 0.f, kz = 0.f;
-  if (p16 < kKP) {
-    kx = kpts[3 * p16];
-    ky = kpts[3 * p16 + 1];
-    kz = kpts[3 * p16 + 2];
-  }
 
   // phase-2 roles.  SK == 1: wave -> (m-tile wave % MT, n-group wave / MT), whole k range.
   // SK == 2: wave -> (n-group wave % NG, k-half wave / NG) and ALL m-tiles: every weight
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(64 * P1W) void k_kpconv_mfma(
     __syncthreads();
   }
   // ------------------------------ epilogue ---------------------------------
-  if (SK == 1 && wave >= NW) return;
+  const bool writer = (SK == 1) ? (wave < NW) : (wave < NW && kh == 0);
   if (SK == 2) {
     // sum the two k-halves through LDS (the wf tiles are dead after the last barrier)
     float* red = reinterpret_cast<float*>(lds_raw);            // [NG][MTW][NTW][4][64]
@@ -500,28 +505,33 @@ __global__ __launch_bounds__(64 * P1W) void k_kpconv_mfma(
             red[(((ng * MTW + m) * NTW + t) * 4 + r) * 64 + lane] = acc2[m][t][r];
     }
     __syncthreads();
-    if (wave >= NW || kh == 1) return;
+    if (writer) {
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc2[m][t][r] += red[(((ng * MTW + m) * NTW + t) * 4 + r) * 64 + lane];
+    }
+  }
+  if (writer) {
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
 #pragma unroll
-      for (int t = 0; t < NTW; ++t)
+      for (int r = 0; r < 4; ++r) {
+        const int ql = (mt + m) * 16 + 4 * j4 + r;
+        const int n = q0 + ql;
+        if (n < nq) {
+          const float inv = 1.f / (float)max(lcnt[ql], 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          acc2[m][t][r] += red[(((ng * MTW + m) * NTW + t) * 4 + r) * 64 + lane];
-  }
-#pragma unroll
-  for (int m = 0; m < MTW; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ql = (mt + m) * 16 + 4 * j4 + r;
-      const int n = q0 + ql;
-      if (n < nq) {
-        const float inv = 1.f / (float)max(lcnt[ql], 1);
-#pragma unroll
-        for (int t = 0; t < NTW; ++t)
-          out[(size_t)n * cout + (ng * NTW + t) * 16 + p16] = acc2[m][t][r] * inv;
+          for (int t = 0; t < NTW; ++t)
+            out[(size_t)n * cout + (ng * NTW + t) * 16 + p16] = acc2[m][t][r] * inv;
+        }
       }
-    }
+  }
+  __syncthreads();   // the next tile rewrites the LDS regions read above
+  }  // persistent tile loop
 }
 
 template <int CC, int TQ, int NTW, int NW, int SK, int P1W = NW>
@@ -545,7 +555,18 @@ int launch_mfma(const float* q_xyz, int nq, const float* s_xyz, int ns, const in
       raised = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(cdiv(nq, TQ)), dim3(64 * P1W), lds, stream, q_xyz, nq, s_xyz, ns,
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    SPR_HIP_CHECK(hipGetDevice(&dev));
+    SPR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;   // LDS-limited residency
+  const int ntiles = cdiv(nq, TQ);
+  const int grid = ntiles < n_cu * per_cu ? ntiles : n_cu * per_cu;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * P1W), lds, stream, q_xyz, nq, s_xyz, ns,
                      nbr, nbr_stride, kmax, rows_sorted, x, cin, Wh, Wl, cout, kpts, inv_extent,
                      sxf, out);
   SPR_LAUNCH_CHECK();
