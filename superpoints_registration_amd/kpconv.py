@@ -135,6 +135,33 @@ batch_grid_subsampling_kpconv_gpu = batch_grid_subsampling_kpconv  # kpconv.py:2
 batch_neighbors_kpconv_gpu = batch_neighbors_kpconv                # kpconv.py:265
 
 
+class _IndexList(list):
+    """List of per-level index matrices that holds the kernels' int32 tensors and converts
+    an entry to the public dtype (int64, like the reference's torch.long indices) the first
+    time it is READ.  The forward pass itself only uses the int32 views, so the three
+    [N, limit] int64 copies per level (hundreds of MB per step) are only made for callers
+    that actually look at them."""
+
+    def __init__(self, dtype):
+        super().__init__()
+        self._dtype = dtype
+
+    def _conv(self, i):
+        t = list.__getitem__(self, i)
+        if t.dtype != self._dtype:
+            t = t.to(self._dtype)
+            list.__setitem__(self, i, t)
+        return t
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._conv(j) for j in range(*i.indices(len(self)))]
+        return self._conv(i if i >= 0 else len(self) + i)
+
+    def __iter__(self):
+        return (self._conv(i) for i in range(len(self)))
+
+
 class Preprocessor(nn.Module):
     """Builds the KPConv pyramid metadata for a list of clouds.
 
@@ -167,7 +194,8 @@ class Preprocessor(nn.Module):
         points = torch.cat(pts, dim=0).to(torch.float32).contiguous()
         lens_host = [int(p.shape[0]) for p in pts]
 
-        meta = {k: [] for k in ('points', 'neighbors', 'pools', 'upsamples', 'stack_lengths')}
+        meta = {k: [] for k in ('points', 'stack_lengths')}
+        meta.update({k: _IndexList(self.index_dtype) for k in ('neighbors', 'pools', 'upsamples')})
         meta.update(_cu={}, _i32={}, _lens_host=[], _rows_sorted=True)
         placeholder = torch.zeros((0, 1), dtype=self.index_dtype, device=device)
 
@@ -176,7 +204,7 @@ class Preprocessor(nn.Module):
                 meta[key].append(placeholder)
                 return
             meta['_i32'][(key, level)] = idx
-            meta[key].append(idx if self.index_dtype == torch.int32 else idx.to(self.index_dtype))
+            meta[key].append(idx)                 # converted to index_dtype on first read
 
         for l, lv in enumerate(levels):
             cu = ops.lengths_to_cu(lens_host, device)
