@@ -50,6 +50,11 @@ def parse():
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--config", default="3dmatch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-mode", type=int, default=1, help="1 = range-scaled split-fp16 MFMA (default), 0 = exact f32")
+    ap.add_argument("--attn-mode", type=int, default=1,
+                    help="1 = split-fp16 (default), 0 = exact f32, 2 = single-pass fp16 operands")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the short exact-f32 and fp16-attention legs that follow the headline timing")
     ap.add_argument("--canonical-order", action="store_true",
                     help="ascending-voxel-key point order instead of the reference's hash-map order")
     ap.add_argument("--skip-upsamples", action="store_true",
@@ -107,8 +112,8 @@ def cpu_baseline(cfg, model_sd, n_points):
     dt = time.perf_counter() - t0
     if use_ref:
         native.grid_subsample, native.radius_neighbors = orig_sub, orig_nb
-    return dict(value=npairs / dt, unit="pairs/s", cores=threads, kind="port",
-                sample=f"{npairs} pairs x {n_points} pts/cloud, one forward each, {dt:.1f} s in total; torch part on "
+    return dict(value=npairs / dt, unit="pairs/s", cores=threads, kind="port", pairs_per_forward=1,
+                sample=f"{npairs} pairs x {n_points} pts/cloud, one forward each (B = 1), {dt:.1f} s in total; torch part on "
                        f"{threads} threads, native preprocessing single-threaded "
                        f"({'reference C++ via oracle/_ref' if use_ref else 'brute-force C port'})")
 
@@ -143,6 +148,8 @@ def main():
 
     from superpoints_registration_amd.streams import StreamedForward
     runner = StreamedForward(model, n_streams=max(1, args.streams), device=dev)
+    ops.set_gemm_mode(args.gemm_mode)
+    ops.set_attn_mode(args.attn_mode)
 
     def step():
         with torch.no_grad():
@@ -167,8 +174,7 @@ def main():
         ms = (ctypes.c_float * cap)()
         n = L.spr_prof_read(cap, codes, nqs, ms)
         metas = batch['kpconv_meta'] if isinstance(batch['kpconv_meta'], list) else [batch['kpconv_meta']]
-        per_fwd = [r for meta in metas for r in kpconv_alg_bytes(meta, model)
-                   if r['cin'] % 16 == 0]          # cin == 1 runs the small dedicated kernel
+        per_fwd = [r for meta in metas for r in kpconv_alg_bytes(meta, model)]   # incl. the cin == 1 kernel
         # aggregate per kernel instantiation (cin, cout) == one rocprof kernel name
         agg = {}
         for i in range(n):
@@ -196,10 +202,12 @@ def main():
             tfs = avg_flops / (avg_ms_attn * 1e-3) / 1e12
             roofline_attn = dict(bound="mfma", achieved=round(tfs, 2), peak=MFMA_F16_PEAK_TFS, unit="TFLOP/s",
                                  frac=round(tfs / MFMA_F16_PEAK_TFS, 5), traffic=None,
-                                 kernel="k_attn_h3 (varlen attention core, split-fp16: 3 MFMA per product)",
+                                 kernel={1: "k_attn_h3<true> (varlen attention core, split-fp16: 3 MFMA per product)",
+                                         2: "k_attn_h3<false> (varlen attention core, single-pass fp16 operands)",
+                                         0: "k_attn (exact f32 MFMA)"}[args.attn_mode],
                                  avg_launch_ms=round(avg_ms_attn, 5), launches=len(attn_ms),
                                  alg_flops_per_launch=int(avg_flops),
-                                 mfma_flops_executed_per_launch=int(3 * avg_flops))
+                                 mfma_flops_executed_per_launch=int({1: 3, 2: 1, 0: 1}[args.attn_mode] * avg_flops))
         best = None
         for code, a in agg.items():
             if code not in fwd_bytes or a['count'] % fwd_launches[code] != 0:
@@ -213,24 +221,56 @@ def main():
             avg_ms = best['total_ms'] / best['count']
             bytes_per_launch = best['total_bytes'] / best['count']
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic = None
+            # HBM traffic comes from separate rocprofv3 --pmc passes (scripts/measure_round.sh ->
+            # profiles/kpconv_traffic.json); it is reported only with its provenance and only while
+            # the kernel duration recorded with it agrees with this run's (else: stale -> null)
+            traffic, traffic_src = None, None
             tpath = os.path.join(REPO, "profiles", "kpconv_traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                    tj = json.load(open(tpath))
+                    ref_ms = tj.get("kernel_avg_ms")
+                    same_kernel = tj.get("code") == best['code']
+                    if same_kernel and ref_ms and abs(ref_ms - avg_ms) <= 0.15 * avg_ms:
+                        traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_src = dict(file="profiles/kpconv_traffic.json", tag=tj.get("tag"),
+                                       collected_utc=tj.get("collected_utc"), kernel_avg_ms_then=ref_ms,
+                                       stale=traffic is None)
                 except Exception:
-                    traffic = None
+                    traffic, traffic_src = None, None
             cin, cout = best['code'] // 100000, best['code'] % 100000
             roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                             kernel=f"k_kpconv_mfma (fused KPConv gather) cin={cin} cout={cout}",
                             avg_launch_ms=round(avg_ms, 5), launches=best['count'],
-                            alg_bytes_per_launch=int(bytes_per_launch),
+                            alg_bytes_per_launch=int(bytes_per_launch), traffic_source=traffic_src,
+                            pooled_all_variants=dict(
+                                gbs=round(sum(fwd_bytes[c] * (a['count'] // fwd_launches[c]) for c, a in agg.items()
+                                              if c in fwd_bytes) / (sum(a['ms'] for c, a in agg.items()
+                                                                        if c in fwd_bytes) * 1e-3) / 1e9, 1)),
                             all_kpconv_variants={f"{c // 100000}->{c % 100000}": dict(
                                 launches=a['count'], avg_ms=round(a['ms'] / a['count'], 5),
                                 gbs=round(fwd_bytes[c] / fwd_launches[c] / (a['ms'] / a['count'] * 1e-3) / 1e9, 1))
                                 for c, a in agg.items() if c in fwd_bytes})
     L.spr_prof_enable(0)
+
+    # ---- extra legs (N == 1): the same workload in exact-f32 arithmetic and with single-pass
+    # fp16 attention operands; short, after the headline timing, never part of `value`
+    extra = {}
+    if world == 1 and not args.no_extra_legs:
+        def leg(gm, am, steps):
+            ops.set_gemm_mode(gm)
+            ops.set_attn_mode(am)
+            step()
+            torch.cuda.synchronize()
+            t = sharding.timed_steps(step, steps, dist=None, sync=torch.cuda.synchronize, device=dev)
+            return dict(value=round(sharding.throughput(B, steps, 1, t), 3), unit="pairs/s",
+                        ms_per_step=round(1e3 * t / steps, 3), steps=steps, gemm_mode=gm, attn_mode=am)
+        n_leg = max(1, min(args.steps, 4))
+        extra["exact_f32"] = leg(0, 0, n_leg)
+        extra["fp16_attention"] = leg(args.gemm_mode, 2, n_leg)
+        ops.set_gemm_mode(args.gemm_mode)
+        ops.set_attn_mode(args.attn_mode)
 
     if rank != 0:
         if dist is not None:
@@ -248,7 +288,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": {(1, 1): "f32 (matrix products: range-scaled split-f16x2 MFMA, f32 accumulate)",
+                  (0, 0): "f32 (exact f32 MFMA)"}.get((args.gemm_mode, args.attn_mode),
+                                                      f"f32 storage/accumulate, gemm_mode={args.gemm_mode}, "
+                                                      f"attn_mode={args.attn_mode}"),
         "data": "synthetic",
         "config": {"workload": f"synthetic {args.points}-pt pairs, full KPConv backbone + superpoint attn "
                                f"+ {'Sinkhorn-' if cfg.use_sinkhorn else ''}SVD pose ({args.config} config, "
@@ -261,6 +304,8 @@ def main():
                                   f"{max(1, args.streams)} concurrent forwards of {B // max(1, args.streams)} pairs"},
         "roofline": roofline,
         "roofline_attention": roofline_attn,
+        "exact_f32": extra.get("exact_f32"),
+        "fp16_attention": extra.get("fp16_attention"),
     }
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, args.points)

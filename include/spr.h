@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPR_VERSION 1
+#define SPR_VERSION 2
 
 /* activation codes for spr_linear / spr_instnorm */
 #define SPR_ACT_NONE 0
@@ -126,16 +126,24 @@ int spr_maxpool_gather(const float* x, int ns, int c, const int* idx, int nq,
  * Replaces the nn.Linear calls on the path: UnaryBlock.mlp
  * (kpconv_blocks.py:549,:557), feat_proj / overlap_predictor
  * (qk_regtr_full.py:47,:85,:176,:248), MultiheadAttention in/out projections
- * and linear1/linear2 (transformer/transformers.py:96-104).  Exact-f32 MFMA.
- * bias, residual may be NULL.  k must be a multiple of 32 unless n == 1.
+ * and linear1/linear2 (transformer/transformers.py:96-104).
+ * bias, residual may be NULL.  k must be a multiple of 32 unless n <= 64.
+ * ws: spr_linear_workspace_bytes() bytes of device scratch (the operands'
+ * max-|x| partials; may be NULL in mode 0).
  */
+size_t spr_linear_workspace_bytes(void);
 int spr_linear(const float* x, int m, int k, const float* w, int n,
                const float* bias, const float* residual, int act, float* out,
-               void* stream);
+               void* ws, size_t ws_bytes, void* stream);
 /* Arithmetic of spr_linear (and of the correlation GEMMs inside the matching
- * head): 1 (default) = split-fp16 MFMA, x = fp16 hi + fp16 lo with fp32
- * accumulation -- fp32-level accuracy (~2^-22 relative per product) at ~5x the
- * exact-f32 MFMA rate, needs |x| < 65504;  0 = exact f32 MFMA. */
+ * head):
+ *   1 (default) = split-fp16 MFMA: each operand tensor is scaled by a power of
+ *     two derived from its measured max |x| (no overflow possible, whatever the
+ *     magnitudes), then carried as fp16 hi + fp16 lo; three MFMAs per product,
+ *     fp32 accumulation.  Elements within 2^-18 of their tensor's maximum keep 22
+ *     significand bits (~2^-22 relative per product); smaller ones keep an
+ *     absolute error of 2^-39 max|x|.  ~5x the exact-f32 MFMA rate.
+ *   0 = exact f32 MFMA (a k-ordered fmaf chain). */
 int spr_set_gemm_mode(int mode);
 
 /* ---- LayerNorm (+ positional embedding add) --------------------------------
@@ -193,9 +201,15 @@ int spr_attn_inproj_varlen_fwd(const float* x_qk, const float* x_v, int t,
                                float scale, float* out, int o_stride, void* ws,
                                size_t ws_bytes, void* stream);
 
-/* Arithmetic of the attention core: 1 (default) = split-fp16 MFMA (operands
- * carried as fp16 hi + fp16 lo, fp32 accumulation and softmax; fp32-level
- * accuracy), 0 = exact f32 MFMA. */
+/* Arithmetic of the attention core:
+ *   1 (default) = split-fp16 MFMA (Q, K, V and the probabilities carried as fp16
+ *     hi + lo; Q/K balanced and V scaled by powers of two derived from measured
+ *     or derived bounds, so no magnitude overflows fp16; fp32 accumulation and
+ *     softmax; fp32-level accuracy);
+ *   0 = exact f32 MFMA;
+ *   2 = single-pass fp16 MFMA (hi planes only: 11-bit operands, fp32 softmax and
+ *     accumulators; 1/3 of the matrix-core work -- the throughput mode BASELINE
+ *     configs[4] names; ~1e-3 relative on the attention output). */
 int spr_set_attn_mode(int mode);
 
 /* ---- a11: dual-softmax matching ---------------------------------------------

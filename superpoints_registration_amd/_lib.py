@@ -30,7 +30,8 @@ SIGNATURES = {
     "spr_instnorm_workspace_bytes": (_sz, [_i, _i, _i]),
     "spr_instnorm": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _f, _vp, _vp, _sz, _vp]),
     "spr_maxpool_gather": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
-    "spr_linear": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "spr_linear_workspace_bytes": (_sz, []),
+    "spr_linear": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "spr_set_gemm_mode": (_i, [_i]),
     "spr_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "spr_posemb_sine": (_i, [_vp, _i, _i, _f, _f, _vp, _vp]),

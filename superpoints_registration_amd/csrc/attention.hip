@@ -21,6 +21,7 @@
 //   conflict-free fragment reads) and shared by the four waves.
 #include "attn_planes.h"
 #include "spr_common.h"
+#include <atomic>
 #include <type_traits>
 
 namespace spr {
@@ -196,10 +197,19 @@ __global__ __launch_bounds__(256) void k_attn(
 
 // ---------------------------------------------------------------------------
 // Split-fp16 variant ("h3"): fp32-level accuracy, ~5x less matrix-core time.
-// Every operand x is carried as hi = fp16(x) and lo = fp16(x - hi);
-// a.b ~= ah.bh + ah.bl + al.bh in ONE fp32 accumulator (the matrix cores
-// honour fp16 subnormals, scripts/abl/denorm.hip, so lo needs no rescaling; its
-// absolute resolution is 2^-24).
+// Every operand x is carried as hi = fp16(x m) and lo = fp16(x m - hi) with a
+// per-tensor multiplier m (below); a.b ~= ah.bh + ah.bl + al.bh in ONE fp32
+// accumulator (the matrix cores honour fp16 subnormals, scripts/abl/denorm.hip).
+//
+// Range safety (k_plane_scales): K is multiplied by 2^ek and Q by
+// log2(e)/sqrt(d) 2^-ek with ek = half the exponent gap between the bounds of
+// |q| and |k| -- the scores are unchanged, both planes sit at sqrt(|q||k|) and
+// cannot overflow unless the scores themselves exceed 2^30; V is multiplied by
+// 2^ev (max |v| 2^ev in [2^14, 2^15)) and the output by 2^-ev.  The bounds are
+// measured (unfused entry: launch_absmax on q, k, v) or derived (fused entry:
+// max|x| * max row L1 norm of the projection block + max|bias|).
+// Mode 2 ("h1") runs the same kernel with the hi planes only: single-pass fp16
+// operands (11 significand bits), fp32 softmax and accumulators, 1/3 of the MFMAs.
 //
 // Two kernels:
 //   k_attn_pack  splits Q (pre-scaled by log2(e)/sqrt(d)), K and V ONCE per
@@ -255,9 +265,10 @@ __global__ __launch_bounds__(256) void k_attn_zero_gaps(const int* __restrict__ 
 __global__ __launch_bounds__(256) void k_attn_pack(
     const float* __restrict__ q, int q_stride, const float* __restrict__ k, int k_stride,
     const float* __restrict__ v, int v_stride, const int* __restrict__ cu, int nseg, int d_model,
-    int t_total, int tp, float qscale, _Float16* __restrict__ qh, _Float16* __restrict__ ql,
-    _Float16* __restrict__ kh, _Float16* __restrict__ kl, _Float16* __restrict__ vth,
-    _Float16* __restrict__ vtl) {
+    int t_total, int tp, const float* __restrict__ scales, _Float16* __restrict__ qh,
+    _Float16* __restrict__ ql, _Float16* __restrict__ kh, _Float16* __restrict__ kl,
+    _Float16* __restrict__ vth, _Float16* __restrict__ vtl) {
+  const float qmul = scales[0], kmul = scales[1], vmul = scales[2];
   __shared__ __align__(16) _Float16 Lh[128 * PS], Ll[128 * PS];
   __shared__ int tok[PT];
   const int tid = threadIdx.x;
@@ -290,20 +301,20 @@ __global__ __launch_bounds__(256) void k_attn_pack(
       }
       unsigned int ha, hb, la, lb;
       if (t >= 0) {
-        split_pk(vq.x * qscale, vq.y * qscale, ha, la);
-        split_pk(vq.z * qscale, vq.w * qscale, hb, lb);
+        split_pk_s(vq.x, vq.y, qmul, ha, la);
+        split_pk_s(vq.z, vq.w, qmul, hb, lb);
         // Q / K planes are head-major [head][token][32]: a 64-key tile of one head
         // is 4 KiB contiguous (full 128-byte lines for the attention kernel's loads)
         const size_t hm = ((size_t)(f / HD) * t_total + t) * HD + f % HD;
         *reinterpret_cast<u32x2*>(qh + hm) = (u32x2){ha, hb};
         *reinterpret_cast<u32x2*>(ql + hm) = (u32x2){la, lb};
-        split_pk(vk.x, vk.y, ha, la);
-        split_pk(vk.z, vk.w, hb, lb);
+        split_pk_s(vk.x, vk.y, kmul, ha, la);
+        split_pk_s(vk.z, vk.w, kmul, hb, lb);
         *reinterpret_cast<u32x2*>(kh + hm) = (u32x2){ha, hb};
         *reinterpret_cast<u32x2*>(kl + hm) = (u32x2){la, lb};
       }
-      split_pk(vv.x, vv.y, ha, la);
-      split_pk(vv.z, vv.w, hb, lb);
+      split_pk_s(vv.x, vv.y, vmul, ha, la);
+      split_pk_s(vv.z, vv.w, vmul, hb, lb);
       const h16x4 vh4 = __builtin_bit_cast(h16x4, (u32x2){ha, hb});
       const h16x4 vl4 = __builtin_bit_cast(h16x4, (u32x2){la, lb});
 #pragma unroll
@@ -337,12 +348,14 @@ __device__ __forceinline__ float half_swap_max(float x) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
+// H3 = true: split-fp16 (hi + lo planes, 3 MFMAs per product); false: hi planes only.
+template <bool H3>
 __global__ __launch_bounds__(256) void k_attn_h3(
     const _Float16* __restrict__ qh_g, const _Float16* __restrict__ ql_g,
     const _Float16* __restrict__ kh_g, const _Float16* __restrict__ kl_g,
     const _Float16* __restrict__ vth_g, const _Float16* __restrict__ vtl_g, int t_total, int tp,
     const int* __restrict__ cu, const int* __restrict__ kv_seg, int nseg, int nhead,
-    float* __restrict__ out, int o_stride) {
+    const float* __restrict__ scales, float* __restrict__ out, int o_stride) {
   __shared__ __align__(16) _Float16 Kh[2][KT2 * KH], Kl[2][KT2 * KH];
   __shared__ __align__(16) _Float16 Vth[2][HD * VH], Vtl[2][HD * VH];
   // 1-D grid: all query tiles of one (segment, head) -- which stream the same
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(256) void k_attn_h3(
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       qh[h][s] = *reinterpret_cast<const h16x8*>(qh_g + row + 16 * s);
-      ql[h][s] = *reinterpret_cast<const h16x8*>(ql_g + row + 16 * s);
+      if constexpr (H3) ql[h][s] = *reinterpret_cast<const h16x8*>(ql_g + row + 16 * s);
     }
   }
 
@@ -409,17 +422,17 @@ __global__ __launch_bounds__(256) void k_attn_h3(
     const size_t vrow = (size_t)(hoff + svr) * tp + vbeg + kt + svc;
     const _Float16 *a = kh_g + krow, *b = kl_g + krow, *c = vth_g + vrow, *d = vtl_g + vrow;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rkh) : "v"(a));
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rkl) : "v"(b));
+    if constexpr (H3) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rkl) : "v"(b));
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rvh) : "v"(c));
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rvl) : "v"(d));
+    if constexpr (H3) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rvl) : "v"(d));
   };
   auto stash = [&](int buf) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     *reinterpret_cast<u32x4*>(Kh[buf] + skr * KH + skc) = rkh;
-    *reinterpret_cast<u32x4*>(Kl[buf] + skr * KH + skc) = rkl;
+    if constexpr (H3) *reinterpret_cast<u32x4*>(Kl[buf] + skr * KH + skc) = rkl;
     *reinterpret_cast<u32x4*>(Vth[buf] + svr * VH + svc) = rvh;
-    *reinterpret_cast<u32x4*>(Vtl[buf] + svr * VH + svc) = rvl;
+    if constexpr (H3) *reinterpret_cast<u32x4*>(Vtl[buf] + svr * VH + svc) = rvl;
   };
 
   // One 64-key tile.  Branch-free inside (the online-softmax rescale is applied
@@ -434,7 +447,8 @@ __global__ __launch_bounds__(256) void k_attn_h3(
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         kfh[kk][s] = *reinterpret_cast<const h16x8*>(Kh[buf] + (32 * kk + l31) * KH + 16 * s + 8 * lh);
-        kfl[kk][s] = *reinterpret_cast<const h16x8*>(Kl[buf] + (32 * kk + l31) * KH + 16 * s + 8 * lh);
+        if constexpr (H3)
+          kfl[kk][s] = *reinterpret_cast<const h16x8*>(Kl[buf] + (32 * kk + l31) * KH + 16 * s + 8 * lh);
       }
     // ---- S^T = K Q^T (rows = keys, cols = queries) ----
     f32x16 sacc[2][2];
@@ -446,8 +460,10 @@ __global__ __launch_bounds__(256) void k_attn_h3(
         for (int r = 0; r < 16; ++r) sacc[h][kk][r] = 0.f;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          sacc[h][kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[kk][s], ql[h][s], sacc[h][kk], 0, 0, 0);
-          sacc[h][kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[kk][s], qh[h][s], sacc[h][kk], 0, 0, 0);
+          if constexpr (H3) {
+            sacc[h][kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[kk][s], ql[h][s], sacc[h][kk], 0, 0, 0);
+            sacc[h][kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[kk][s], qh[h][s], sacc[h][kk], 0, 0, 0);
+          }
           sacc[h][kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[kk][s], qh[h][s], sacc[h][kk], 0, 0, 0);
         }
       }
@@ -461,10 +477,12 @@ __global__ __launch_bounds__(256) void k_attn_h3(
         const _Float16* pl_ = Vtl[buf] + l31 * VH + 32 * kk + 16 * s + 4 * lh;
         const h16x4 a0 = *reinterpret_cast<const h16x4*>(ph_);
         const h16x4 a1 = *reinterpret_cast<const h16x4*>(ph_ + 8);
-        const h16x4 b0 = *reinterpret_cast<const h16x4*>(pl_);
-        const h16x4 b1 = *reinterpret_cast<const h16x4*>(pl_ + 8);
         vfh[kk][s] = (h16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        vfl[kk][s] = (h16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        if constexpr (H3) {
+          const h16x4 b0 = *reinterpret_cast<const h16x4*>(pl_);
+          const h16x4 b1 = *reinterpret_cast<const h16x4*>(pl_ + 8);
+          vfl[kk][s] = (h16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        }
       }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -513,13 +531,15 @@ __global__ __launch_bounds__(256) void k_attn_h3(
           psum2[h] += pv;                                  // v_pk_add_f32
           const unsigned int hi_u =
               __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(pv[0], pv[1]));
-          unsigned int lo_u;
-          asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
-              "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-              : "=&v"(lo_u)
-              : "v"(hi_u), "v"(pv[0]), "v"(pv[1]));
           ph_u[kk][r >> 1] = hi_u;
-          pl_u[kk][r >> 1] = lo_u;
+          if constexpr (H3) {
+            unsigned int lo_u;
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                : "=&v"(lo_u)
+                : "v"(hi_u), "v"(pv[0]), "v"(pv[1]));
+            pl_u[kk][r >> 1] = lo_u;
+          }
         }
       // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -527,10 +547,13 @@ __global__ __launch_bounds__(256) void k_attn_h3(
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const u32x4 pa = {ph_u[kk][4 * s], ph_u[kk][4 * s + 1], ph_u[kk][4 * s + 2], ph_u[kk][4 * s + 3]};
-          const u32x4 pb = {pl_u[kk][4 * s], pl_u[kk][4 * s + 1], pl_u[kk][4 * s + 2], pl_u[kk][4 * s + 3]};
-          const h16x8 pbh = __builtin_bit_cast(h16x8, pa), pbl = __builtin_bit_cast(h16x8, pb);
-          o[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[kk][s], pbl, o[h], 0, 0, 0);
-          o[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[kk][s], pbh, o[h], 0, 0, 0);
+          const h16x8 pbh = __builtin_bit_cast(h16x8, pa);
+          if constexpr (H3) {
+            const u32x4 pb = {pl_u[kk][4 * s], pl_u[kk][4 * s + 1], pl_u[kk][4 * s + 2], pl_u[kk][4 * s + 3]};
+            const h16x8 pbl = __builtin_bit_cast(h16x8, pb);
+            o[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[kk][s], pbl, o[h], 0, 0, 0);
+            o[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[kk][s], pbh, o[h], 0, 0, 0);
+          }
           o[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[kk][s], pbh, o[h], 0, 0, 0);
         }
     }
@@ -560,7 +583,7 @@ __global__ __launch_bounds__(256) void k_attn_h3(
     l_run += __shfl_xor(l_run, 32, 64);
     const int qi = q0 + wave * QW2 + 32 * h + l31;
     if (qi < qlen) {
-      const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+      const float inv = (l_run > 0.f ? 1.0f / l_run : 0.f) * scales[3];   // 2^-ev undoes the V multiplier
       float* op = out + (size_t)(qbeg + qi) * o_stride + hoff;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -575,7 +598,76 @@ __global__ __launch_bounds__(256) void k_attn_h3(
   }
 }
 
-static int g_attn_mode = 1;   // 1 = split-fp16 (default), 0 = exact f32 MFMA
+static std::atomic<int> g_attn_mode{1};   // 1 = split-fp16 (default), 0 = exact f32 MFMA, 2 = single-pass fp16
+
+// L1 norm of every row of w [rows, cols]: one wave per row.
+__global__ void k_row_l1(const float* __restrict__ w, int rows, int cols, float* __restrict__ out) {
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += fabsf(w[(size_t)row * cols + c]);
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+
+// Plane multipliers from bounds on |q|, |k|, |v| (one workgroup).
+//   rowl1 == nullptr: the bounds are the measured maxima (q_parts, k_parts, v_parts);
+//   else (fused in-projection, weights [3d, d], bias [3d]): bound of block b =
+//     max|x| * max_row L1(W_b) + max|bias_b|, x = x_qk for Q and K, x_v for V.
+__global__ __launch_bounds__(256) void k_plane_scales(const float* __restrict__ q_parts,
+                                                      const float* __restrict__ k_parts,
+                                                      const float* __restrict__ v_parts,
+                                                      const float* __restrict__ rowl1,
+                                                      const float* __restrict__ bias, int d, float qscale,
+                                                      float* __restrict__ scales) {
+  __shared__ float sh[17];
+  __shared__ float blk[6];
+  float qb = block_absmax(q_parts, sh);
+  float kb = block_absmax(k_parts, sh);
+  float vb = block_absmax(v_parts, sh);
+  if (rowl1 != nullptr) {
+    for (int b = 0; b < 3; ++b) {
+      float l1 = 0.f, bm = 0.f;
+      for (int i = threadIdx.x; i < d; i += 256) {
+        l1 = fmaxf(l1, rowl1[b * d + i]);
+        bm = fmaxf(bm, fabsf(bias[b * d + i]));
+      }
+      l1 = wave_max(l1);
+      bm = wave_max(bm);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) {
+        sh[threadIdx.x >> 6] = l1;
+        sh[4 + (threadIdx.x >> 6)] = bm;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        blk[2 * b] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+        blk[2 * b + 1] = fmaxf(fmaxf(sh[4], sh[5]), fmaxf(sh[6], sh[7]));
+      }
+    }
+    __syncthreads();
+    qb = qb * blk[0] + blk[1];
+    kb = kb * blk[2] + blk[3];
+    vb = vb * blk[4] + blk[5];
+  }
+  if (threadIdx.x == 0) {
+    // ek = half the exponent gap: K 2^ek and Q qscale 2^-ek both sit at sqrt(|q||k|)
+    const float qs = qb * qscale;
+    int ek = 0;
+    if (qs > 0.f && kb > 0.f && qs < 3.0e38f && kb < 3.0e38f) {
+      const int eq = (int)((__float_as_uint(qs) >> 23) & 0xff) - 127;
+      const int ekk = (int)((__float_as_uint(kb) >> 23) & 0xff) - 127;
+      ek = (eq - ekk) >> 1;
+      ek = max(-60, min(60, ek));
+    }
+    const int ev = pow2_exp_for(vb);
+    scales[0] = qscale * pow2f(-ek);
+    scales[1] = pow2f(ek);
+    scales[2] = pow2f(ev);
+    scales[3] = pow2f(-ev);
+  }
+}
 
 }  // namespace
 }  // namespace spr
@@ -583,12 +675,53 @@ static int g_attn_mode = 1;   // 1 = split-fp16 (default), 0 = exact f32 MFMA
 using namespace spr;
 
 static size_t attn_tp(int t, int nseg) { return align_up((size_t)t + 8 * (size_t)nseg + KT2, PT); }
+// small scratch behind the planes: 3 absmax partial arrays, 3*256 row norms, 4 scales
+static constexpr size_t kAttnSmall = 3 * 2048 + 4096 + 256;
 
 extern "C" size_t spr_attn_workspace_bytes(int t, int nseg, int nhead, int head_dim) {
   if (t < 0 || nseg < 0 || nhead < 0 || head_dim < 0) return 0;
   const size_t d = (size_t)nhead * head_dim;
-  return 4 * align_up((size_t)(t > 0 ? t : 1) * d * 2, 256) + 2 * align_up(d * attn_tp(t, nseg) * 2, 256);
+  return 4 * align_up((size_t)(t > 0 ? t : 1) * d * 2, 256) + 2 * align_up(d * attn_tp(t, nseg) * 2, 256) +
+         kAttnSmall;
 }
+
+namespace {
+struct AttnSmall {
+  float *p0, *p1, *p2, *rowl1, *scales;
+};
+// carves the operand planes and the small scratch out of ws
+int carve(void* ws, size_t ws_bytes, int t, int nseg, int d, size_t tp, AttnPlanes& pl, AttnSmall& sm) {
+  Workspace w(ws, ws_bytes);
+  pl.qh = w.take<_Float16>((size_t)t * d);
+  pl.ql = w.take<_Float16>((size_t)t * d);
+  pl.kh = w.take<_Float16>((size_t)t * d);
+  pl.kl = w.take<_Float16>((size_t)t * d);
+  pl.vth = w.take<_Float16>((size_t)d * tp);
+  pl.vtl = w.take<_Float16>((size_t)d * tp);
+  sm.p0 = w.take<float>(kAmaxParts);
+  sm.p1 = w.take<float>(kAmaxParts);
+  sm.p2 = w.take<float>(kAmaxParts);
+  sm.rowl1 = w.take<float>(1024);
+  sm.scales = w.take<float>(4);
+  SPR_REQUIRE(sm.scales != nullptr, "attention: workspace carve failed");
+  pl.scales = sm.scales;
+  return 0;
+}
+
+int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int* kv_seg, int nseg,
+                int max_len_host, int nhead, float* out, int o_stride, int mode, hipStream_t stream) {
+  dim3 grid(cdiv(max_len_host, QB2) * nhead * nseg);
+  ProfScope prof(stream, -1, t);
+  if (mode == 2)
+    hipLaunchKernelGGL(k_attn_h3<false>, grid, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth, pl.vtl,
+                       t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+  else
+    hipLaunchKernelGGL(k_attn_h3<true>, grid, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth, pl.vtl,
+                       t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
 
 extern "C" int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k, int k_stride,
                                    const float* v, int v_stride, const int* cu,
@@ -601,34 +734,32 @@ extern "C" int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k,
   SPR_REQUIRE(q_stride % 4 == 0 && k_stride % 4 == 0 && v_stride % 4 == 0 && o_stride % 4 == 0,
               "attention: row strides must be multiples of 4 floats");
   SPR_REQUIRE((long)cdiv(max_len_host, QB) * nhead * nseg < (1l << 31), "attention: grid too large");
-  dim3 grid(cdiv(max_len_host, QB) * nhead * nseg);
-  if (spr::g_attn_mode == 1) {
-    grid = dim3(cdiv(max_len_host, QB2) * nhead * nseg);
-    const int d_model = nhead * head_dim;
-    const size_t tp = attn_tp(t, nseg);
-    SPR_REQUIRE(tp < (1ul << 31), "attention: too many tokens");
-    SPR_REQUIRE(ws != nullptr && ws_bytes >= spr_attn_workspace_bytes(t, nseg, nhead, head_dim),
-                "attention: workspace too small (%zu bytes given)", ws_bytes);
-    Workspace w(ws, ws_bytes);
-    _Float16* qh = w.take<_Float16>((size_t)t * d_model);
-    _Float16* ql = w.take<_Float16>((size_t)t * d_model);
-    _Float16* kh = w.take<_Float16>((size_t)t * d_model);
-    _Float16* kl = w.take<_Float16>((size_t)t * d_model);
-    _Float16* vth = w.take<_Float16>((size_t)d_model * tp);
-    _Float16* vtl = w.take<_Float16>((size_t)d_model * tp);
-    SPR_REQUIRE(vtl != nullptr, "attention: workspace carve failed");
-    hipLaunchKernelGGL(k_attn_pack, dim3((unsigned)(tp / PT)), dim3(256), 0, stream, q, q_stride, k, k_stride,
-                       v, v_stride, cu, nseg, d_model, t, (int)tp, scale * 1.4426950408889634f, qh, ql,
-                       kh, kl, vth, vtl);
-    ProfScope prof(stream, -1, t);
-    hipLaunchKernelGGL(k_attn_h3, grid, dim3(256), 0, stream, qh, ql, kh, kl, vth, vtl, t, (int)tp,
-                       cu, kv_seg, nseg, nhead, out, o_stride);
-  } else {
+  const int mode = spr::g_attn_mode.load(std::memory_order_relaxed);
+  if (mode == 0) {
+    dim3 grid(cdiv(max_len_host, QB) * nhead * nseg);
     hipLaunchKernelGGL(k_attn, grid, dim3(256), 0, stream, q, q_stride, k, k_stride, v, v_stride, cu,
                        kv_seg, nseg, nhead, scale, out, o_stride);
+    SPR_LAUNCH_CHECK();
+    return 0;
   }
+  const int d_model = nhead * head_dim;
+  const size_t tp = attn_tp(t, nseg);
+  SPR_REQUIRE(tp < (1ul << 31), "attention: too many tokens");
+  SPR_REQUIRE(ws != nullptr && ws_bytes >= spr_attn_workspace_bytes(t, nseg, nhead, head_dim),
+              "attention: workspace too small (%zu bytes given)", ws_bytes);
+  AttnPlanes pl{};
+  AttnSmall sm{};
+  if (int rc = carve(ws, ws_bytes, t, nseg, d_model, tp, pl, sm)) return rc;
+  if (int rc = launch_absmax(q, t, d_model, q_stride, sm.p0, stream)) return rc;
+  if (int rc = launch_absmax(k, t, d_model, k_stride, sm.p1, stream)) return rc;
+  if (int rc = launch_absmax(v, t, d_model, v_stride, sm.p2, stream)) return rc;
+  hipLaunchKernelGGL(k_plane_scales, dim3(1), dim3(256), 0, stream, sm.p0, sm.p1, sm.p2, (const float*)nullptr,
+                     (const float*)nullptr, d_model, scale * 1.4426950408889634f, sm.scales);
+  hipLaunchKernelGGL(k_attn_pack, dim3((unsigned)(tp / PT)), dim3(256), 0, stream, q, q_stride, k, k_stride,
+                     v, v_stride, cu, nseg, d_model, t, (int)tp, sm.scales, pl.qh, pl.ql, pl.kh, pl.kl,
+                     pl.vth, pl.vtl);
   SPR_LAUNCH_CHECK();
-  return 0;
+  return launch_core(pl, t, tp, cu, kv_seg, nseg, max_len_host, nhead, out, o_stride, mode, stream);
 }
 
 extern "C" size_t spr_attn_inproj_workspace_bytes(int t, int nseg, int nhead, int head_dim) {
@@ -651,18 +782,37 @@ extern "C" int spr_attn_inproj_varlen_fwd(const float* x_qk, const float* x_v, i
               "attention in-projection: workspace too small (%zu bytes given)", ws_bytes);
   const int d = nhead * head_dim;
   const size_t planes_bytes = spr_attn_workspace_bytes(t, nseg, nhead, head_dim);
-  if (spr::g_attn_mode != 1 || t < 256) {
+  const int mode = spr::g_attn_mode.load(std::memory_order_relaxed);
+  const size_t tp = attn_tp(t, nseg);
+  SPR_REQUIRE(tp < (1ul << 31), "attention: too many tokens");
+  AttnPlanes pl{};
+  AttnSmall sm{};
+  if (int rc = carve(ws, planes_bytes, t, nseg, d, tp, pl, sm)) return rc;
+  const bool gemm_split = gemm_mode() == 1;
+  if (mode == 0 || t < 256 || !gemm_split) {
     // exact-f32 mode (and tiny inputs): plain projection into the workspace, then the
     // unfused core -- same results as spr_linear + spr_attn_varlen_fwd
     float* qkv = (float*)((char*)ws + planes_bytes);
+    const float *xp = nullptr, *xvp = nullptr, *wp = nullptr;
+    if (gemm_split) {   // operand ranges for the split-fp16 GEMM (sm.* is rewritten by the core afterwards)
+      if (int rc = launch_absmax(x_qk, t, d, d, sm.p0, stream)) return rc;
+      if (int rc = launch_absmax(w_in, 3 * d, d, d, sm.p1, stream)) return rc;
+      xp = xvp = sm.p0;
+      wp = sm.p1;
+      if (x_v != x_qk) {
+        if (int rc = launch_absmax(x_v, t, d, d, sm.p2, stream)) return rc;
+        xvp = sm.p2;
+      }
+    }
     if (x_v == x_qk) {
-      if (int rc = launch_linear_plain(x_qk, t, d, w_in, 3 * d, b_in, qkv, stream)) return rc;
+      if (int rc = launch_linear_ranged(x_qk, t, d, w_in, 3 * d, b_in, qkv, xp, wp, stream)) return rc;
     } else {
       // two projections, written side by side: [q | k] from x_qk, [v] from x_v
       float* qk = qkv;
       float* v = qkv + (size_t)t * 2 * d;
-      if (int rc = launch_linear_plain(x_qk, t, d, w_in, 2 * d, b_in, qk, stream)) return rc;
-      if (int rc = launch_linear_plain(x_v, t, d, w_in + (size_t)2 * d * d, d, b_in + 2 * d, v, stream)) return rc;
+      if (int rc = launch_linear_ranged(x_qk, t, d, w_in, 2 * d, b_in, qk, xp, wp, stream)) return rc;
+      if (int rc = launch_linear_ranged(x_v, t, d, w_in + (size_t)2 * d * d, d, b_in + 2 * d, v, xvp, wp, stream))
+        return rc;
       return spr_attn_varlen_fwd(qk, 2 * d, qk + d, 2 * d, v, d, cu, kv_seg, t, nseg, max_len_host, nhead,
                                  head_dim, scale, out, o_stride, ws, planes_bytes, stream_);
     }
@@ -670,40 +820,37 @@ extern "C" int spr_attn_inproj_varlen_fwd(const float* x_qk, const float* x_v, i
                                max_len_host, nhead, head_dim, scale, out, o_stride, ws, planes_bytes, stream_);
   }
   SPR_REQUIRE((long)cdiv(max_len_host, QB2) * nhead * nseg < (1l << 31), "attention: grid too large");
-  const size_t tp = attn_tp(t, nseg);
-  SPR_REQUIRE(tp < (1ul << 31), "attention: too many tokens");
-  Workspace w(ws, ws_bytes);
-  AttnPlanes pl;
-  pl.qh = w.take<_Float16>((size_t)t * d);
-  pl.ql = w.take<_Float16>((size_t)t * d);
-  pl.kh = w.take<_Float16>((size_t)t * d);
-  pl.kl = w.take<_Float16>((size_t)t * d);
-  pl.vth = w.take<_Float16>((size_t)d * tp);
-  pl.vtl = w.take<_Float16>((size_t)d * tp);
-  SPR_REQUIRE(pl.vtl != nullptr, "attention: workspace carve failed");
   pl.cu = cu;
   pl.nseg = nseg;
   pl.t_total = t;
   pl.tp = (int)tp;
-  pl.qscale = scale * 1.4426950408889634f;
+  // operand ranges: max|x| (inputs), max|w| (the projection's own operand scale) and the plane
+  // multipliers from the bounds max|x| * max row-L1(W block) + max|bias block|
+  if (int rc = launch_absmax(x_qk, t, d, d, sm.p0, stream)) return rc;
+  const float* xvp = sm.p0;
+  if (x_v != x_qk) {
+    if (int rc = launch_absmax(x_v, t, d, d, sm.p2, stream)) return rc;
+    xvp = sm.p2;
+  }
+  if (int rc = launch_absmax(w_in, 3 * d, d, d, sm.p1, stream)) return rc;
+  hipLaunchKernelGGL(k_row_l1, dim3(cdiv((long)3 * d * 64, 256)), dim3(256), 0, stream, w_in, 3 * d, d, sm.rowl1);
+  hipLaunchKernelGGL(k_plane_scales, dim3(1), dim3(256), 0, stream, sm.p0, sm.p0, xvp, sm.rowl1, b_in, d,
+                     scale * 1.4426950408889634f, sm.scales);
   hipLaunchKernelGGL(k_attn_zero_gaps, dim3(d), dim3(256), 0, stream, cu, nseg, (int)tp, pl.vth, pl.vtl);
   if (x_v == x_qk) {
-    if (int rc = launch_inproj_planes(x_qk, t, d, w_in, 3 * d, b_in, 0, pl, stream)) return rc;
+    if (int rc = launch_inproj_planes(x_qk, t, d, w_in, 3 * d, b_in, 0, pl, sm.p0, sm.p1, stream)) return rc;
   } else {
-    if (int rc = launch_inproj_planes(x_qk, t, d, w_in, 2 * d, b_in, 0, pl, stream)) return rc;
-    if (int rc = launch_inproj_planes(x_v, t, d, w_in + (size_t)2 * d * d, d, b_in + 2 * d, 2 * d, pl, stream))
+    if (int rc = launch_inproj_planes(x_qk, t, d, w_in, 2 * d, b_in, 0, pl, sm.p0, sm.p1, stream)) return rc;
+    if (int rc = launch_inproj_planes(x_v, t, d, w_in + (size_t)2 * d * d, d, b_in + 2 * d, 2 * d, pl, xvp, sm.p1,
+                                      stream))
       return rc;
   }
-  dim3 grid(cdiv(max_len_host, QB2) * nhead * nseg);
-  ProfScope prof(stream, -1, t);
-  hipLaunchKernelGGL(k_attn_h3, grid, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth, pl.vtl, t,
-                     (int)tp, cu, kv_seg, nseg, nhead, out, o_stride);
-  SPR_LAUNCH_CHECK();
-  return 0;
+  return launch_core(pl, t, tp, cu, kv_seg, nseg, max_len_host, nhead, out, o_stride, mode, stream);
 }
 
 extern "C" int spr_set_attn_mode(int mode) {
-  SPR_REQUIRE(mode == 0 || mode == 1, "attention mode must be 0 (exact f32 MFMA) or 1 (split-fp16)");
-  spr::g_attn_mode = mode;
+  SPR_REQUIRE(mode >= 0 && mode <= 2,
+              "attention mode must be 0 (exact f32 MFMA), 1 (split-fp16) or 2 (single-pass fp16)");
+  spr::g_attn_mode.store(mode);
   return 0;
 }

@@ -14,17 +14,23 @@ struct AttnPlanes {
   _Float16 *vth, *vtl;           // [nhead*32][tp] transposed
   const int* cu;                 // [nseg + 1]
   int nseg, t_total, tp;
-  float qscale;
+  // device [4]: multipliers applied when the planes are written -- [0] Q: log2(e)/sqrt(d) * 2^-ek,
+  // [1] K: 2^ek, [2] V: 2^ev -- and [3] = 2^-ev, applied to the attention output
+  // (k_plane_scales, attention.hip)
+  const float* scales;
 };
 
 // Split-fp16 GEMM  planes <- x [m, k] . w [n, k]^T + bias  for the n output
 // features [f0, f0 + n) of the packed in-projection (0..255 = Q, 256..511 = K,
 // 512..767 = V; d_model = 256, head_dim = 32).  n and f0 are multiples of 256.
+// a_parts / w_parts: absmax partials of x and w (launch_absmax).
 int launch_inproj_planes(const float* x, int m, int k, const float* w, int n, const float* bias, int f0,
-                         const AttnPlanes& planes, hipStream_t stream);
+                         const AttnPlanes& planes, const float* a_parts, const float* w_parts,
+                         hipStream_t stream);
 
-// Exact-f32 / generic GEMM used by the mode-0 fallback of the fused entry point.
-int launch_linear_plain(const float* x, int m, int k, const float* w, int n, const float* bias, float* out,
-                        hipStream_t stream);
+// Plain GEMM out = x w^T + bias with pre-measured operand ranges (nullptr in exact-f32 mode).
+int launch_linear_ranged(const float* x, int m, int k, const float* w, int n, const float* bias, float* out,
+                         const float* a_parts, const float* w_parts, hipStream_t stream);
+int gemm_mode();   // 1 = split-fp16, 0 = exact f32
 
 }  // namespace spr

@@ -1,7 +1,10 @@
 // Error reporting, version and an on-device self test of the two f32 MFMA
 // fragment layouts every kernel in this library relies on.
+#include <atomic>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "spr_common.h"
@@ -24,14 +27,60 @@ struct ProfRec {
 };
 static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mu;
-static bool g_prof_on = false;
-bool prof_enabled() { return g_prof_on; }
+static std::atomic<bool> g_prof_on{false};
+bool prof_enabled() { return g_prof_on.load(std::memory_order_relaxed); }
 void prof_push(hipEvent_t beg, hipEvent_t end, int code, int n) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof.push_back(ProfRec{beg, end, code, n});
 }
 
 namespace {
+// max |x| of a [rows, cols] view (row stride `stride` floats) as kAmaxParts
+// per-block partials.  Fixed grid of kAmaxParts blocks: every slot is written.
+// cols4 = cols / 4 when the view is float4-addressable (cols, stride % 4 == 0 and
+// 16-byte aligned base), else 0 -> scalar path.
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, long rows, int cols,
+                                                long stride, int cols4, float* __restrict__ parts) {
+  __shared__ float sh[4];
+  float m = 0.f;
+  const long nthr = (long)gridDim.x * 256, t0 = (long)blockIdx.x * 256 + threadIdx.x;
+  if (cols4 > 0) {
+    const long total = rows * cols4;
+    if (stride == cols) {
+      const float4* p = reinterpret_cast<const float4*>(x);
+      long i = t0;
+      for (; i + 3 * nthr < total; i += 4 * nthr) {   // four 16-byte loads in flight
+        const float4 a = p[i], b = p[i + nthr], c = p[i + 2 * nthr], d = p[i + 3 * nthr];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))));
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w))));
+      }
+      for (; i < total; i += nthr) {
+        const float4 a = p[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+      }
+    } else {
+      for (long i = t0; i < total; i += nthr) {
+        const long r = i / cols4;
+        const int c = (int)(i - r * cols4);
+        const float4 a = *reinterpret_cast<const float4*>(x + r * stride + 4 * c);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+      }
+    }
+  } else {
+    const long total = rows * cols;
+    for (long i = t0; i < total; i += nthr) {
+      const long r = i / cols;
+      m = fmaxf(m, fabsf(x[r * stride + (i - r * cols)]));
+    }
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
 // D[16x16] = A[16x4] B[4x16] with A[l&15][l>>4], B[l>>4][l&15];
 // D: col = l&15, row = 4*(l>>4) + r
 __global__ void k_test_16x16x4(const float* A, const float* B, float* D) {
@@ -56,6 +105,49 @@ __global__ void k_test_32x32x2(const float* A, const float* B, float* D) {
 }  // namespace spr
 
 using namespace spr;
+
+namespace {
+std::mutex g_dev_mu;
+std::map<std::pair<int, const void*>, int> g_lds_attr;   // (device, kernel) -> bytes granted
+std::map<int, int> g_cu_count;                            // device -> CUs
+}  // namespace
+
+int spr::ensure_dyn_lds(const void* kernel, int bytes) {
+  if (bytes <= 64 * 1024) return 0;
+  int dev = 0;
+  SPR_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  auto key = std::make_pair(dev, kernel);
+  auto it = g_lds_attr.find(key);
+  if (it != g_lds_attr.end() && it->second >= bytes) return 0;
+  SPR_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  g_lds_attr[key] = bytes;
+  return 0;
+}
+
+int spr::device_cu_count() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  auto it = g_cu_count.find(dev);
+  if (it != g_cu_count.end()) return it->second;
+  hipDeviceProp_t prop;
+  int n = 256;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    n = prop.multiProcessorCount;
+  g_cu_count[dev] = n;
+  return n;
+}
+
+int spr::launch_absmax(const float* x, long rows, int cols, long stride, float* parts, hipStream_t stream) {
+  SPR_REQUIRE(x != nullptr && parts != nullptr && rows >= 0 && cols >= 1 && stride >= cols,
+              "absmax: bad arguments (rows=%ld cols=%d stride=%ld)", rows, cols, stride);
+  const bool v4 = cols % 4 == 0 && stride % 4 == 0 && ((uintptr_t)x & 15) == 0;
+  hipLaunchKernelGGL(k_absmax, dim3(kAmaxParts), dim3(256), 0, stream, x, rows, cols, stride,
+                     v4 ? cols / 4 : 0, parts);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int spr_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);

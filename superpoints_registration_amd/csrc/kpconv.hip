@@ -168,8 +168,13 @@ __global__ __launch_bounds__(256) void k_kpconv_cin1(
 //   index = (((chunk * (cout/16) + nt) * KS + ks) * 64 + lane) * 8 + e
 //   lane = (j4 << 4) | p16;  n = 16 nt + p16;  kk = 32 ks + 8 j4 + e (inside the
 //   chunk's [15 x cc] block): kernel point kk / cc, channel chunk * cc + kk % cc
-__global__ void k_w_prep(const float* __restrict__ W, int cin, int cout, int cc,
-                         _Float16* __restrict__ Wh, _Float16* __restrict__ Wl) {
+// The weights are multiplied by the power of two that brings max |w| into [2^14, 2^15)
+// (w_parts: launch_absmax partials) before the split -- see split_pk_s, spr_common.h.
+__global__ __launch_bounds__(256) void k_w_prep(const float* __restrict__ W, int cin, int cout, int cc,
+                                                const float* __restrict__ w_parts,
+                                                _Float16* __restrict__ Wh, _Float16* __restrict__ Wl) {
+  __shared__ float sh[17];
+  const float sb = pow2f(pow2_exp_for(block_absmax(w_parts, sh)));
   const int total = kKP * cin * cout;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -182,7 +187,7 @@ __global__ void k_w_prep(const float* __restrict__ W, int cin, int cout, int cc,
   const int p16 = lane & 15, j4 = lane >> 4;
   const int kk = 32 * ks + 8 * j4 + e;
   const int p = kk / cc, c = chunk * cc + kk % cc;
-  const float w = W[((size_t)p * cin + c) * cout + 16 * nt + p16];
+  const float w = W[((size_t)p * cin + c) * cout + 16 * nt + p16] * sb;
   const _Float16 h = (_Float16)w;
   Wh[i] = h;
   Wl[i] = (_Float16)(w - (float)h);
@@ -250,7 +255,8 @@ __global__ __launch_bounds__(64 * P1W) void k_kpconv_mfma(
     const int* __restrict__ nbr, int nbr_stride, int kmax, int rows_sorted,
     const float* __restrict__ x, int cin, const _Float16* __restrict__ Wh,
     const _Float16* __restrict__ Wl, int cout, const float* __restrict__ kpts, float inv_extent,
-    const float4* __restrict__ sxf, float* __restrict__ out) {
+    const float4* __restrict__ sxf, const float* __restrict__ x_parts,
+    const float* __restrict__ w_parts, float* __restrict__ out) {
   constexpr int NTC = CC / 16;
   constexpr int MT = TQ / 16;
   constexpr int KW = kKP * CC;       // phase-2 K per chunk
@@ -278,6 +284,19 @@ __global__ __launch_bounds__(64 * P1W) void k_kpconv_mfma(
     kx = kpts[3 * p16];
     ky = kpts[3 * p16 + 1];
     kz = kpts[3 * p16 + 2];
+  }
+
+  // Phase-2 operand scales (powers of two, split_pk_s): weighted features are bounded by
+  // (valid neighbours) * max|x| <= kmax * max|x| (influences lie in [0, 1]); the weights were
+  // scaled by k_w_prep from the same partials.
+  float sa, unscale;
+  {
+    float* shf = reinterpret_cast<float*>(lds_raw);
+    const int ka = pow2_exp_for(block_absmax(x_parts, shf) * (float)kmax);
+    const int kb = pow2_exp_for(block_absmax(w_parts, shf));
+    __syncthreads();
+    sa = pow2f(ka);
+    unscale = pow2f(-ka - kb);
   }
 
   // Persistent workgroup: tiles blockIdx.x, blockIdx.x + gridDim.x, ... (one LDS-sized
@@ -392,15 +411,15 @@ __global__ __launch_bounds__(64 * P1W) void k_kpconv_mfma(
           hv_t hh, ll;
           if constexpr (NTC == 2) {
             unsigned int hu, lu;
-            split_pk(acc1[0][r], acc1[1][r], hu, lu);
+            split_pk_s(acc1[0][r], acc1[1][r], sa, hu, lu);
             hh = __builtin_bit_cast(hv_t, hu);
             ll = __builtin_bit_cast(hv_t, lu);
           } else {
             static_assert(NTC == 4, "NTC is 2 or 4");
             typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
             unsigned int h0, l0, h1, l1;
-            split_pk(acc1[0][r], acc1[1][r], h0, l0);
-            split_pk(acc1[2][r], acc1[3][r], h1, l1);
+            split_pk_s(acc1[0][r], acc1[1][r], sa, h0, l0);
+            split_pk_s(acc1[2][r], acc1[3][r], sa, h1, l1);
             hh = __builtin_bit_cast(hv_t, (u2_t){h0, h1});
             ll = __builtin_bit_cast(hv_t, (u2_t){l0, l1});
           }
@@ -523,7 +542,7 @@ __global__ __launch_bounds__(64 * P1W) void k_kpconv_mfma(
         const int ql = (mt + m) * 16 + 4 * j4 + r;
         const int n = q0 + ql;
         if (n < nq) {
-          const float inv = 1.f / (float)max(lcnt[ql], 1);
+          const float inv = unscale / (float)max(lcnt[ql], 1);   // unscale: exact power of two
 #pragma unroll
           for (int t = 0; t < NTW; ++t)
             out[(size_t)n * cout + (ng * NTW + t) * 16 + p16] = acc2[m][t][r] * inv;
@@ -538,7 +557,8 @@ template <int CC, int TQ, int NTW, int NW, int SK, int P1W = NW>
 int launch_mfma(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
                 int nbr_stride, int kmax, int rows_sorted, const float* x, int cin,
                 const _Float16* Wh, const _Float16* Wl, int cout, const float* kpts,
-                float inv_extent, const float4* sxf, float* out, hipStream_t stream) {
+                float inv_extent, const float4* sxf, const float* x_parts, const float* w_parts, float* out,
+                hipStream_t stream) {
   constexpr int SH = kKP * CC + 16;
   constexpr int QPW = TQ / P1W;
   const int nblk = (kmax + 15) / 16;
@@ -547,28 +567,15 @@ int launch_mfma(const float* q_xyz, int nq, const float* s_xyz, int ns, const in
   auto kern = k_kpconv_mfma<CC, TQ, NTW, NW, SK, P1W>;
   ProfScope prof(stream, cin * 100000 + cout, nq);
   SPR_REQUIRE(lds <= 160 * 1024, "kpconv: neighbour rows too wide for the LDS tile (kmax=%d)", kmax);
-  if (lds > 64 * 1024) {
-    static bool raised = false;  // per instantiation
-    if (!raised) {
-      SPR_HIP_CHECK(hipFuncSetAttribute((const void*)kern,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      raised = true;
-    }
-  }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    SPR_HIP_CHECK(hipGetDevice(&dev));
-    SPR_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  if (lds > 64 * 1024)
+    if (int rc = ensure_dyn_lds((const void*)kern, 160 * 1024)) return rc;
+  const int n_cu = device_cu_count();
   const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;   // LDS-limited residency
   const int ntiles = cdiv(nq, TQ);
   const int grid = ntiles < n_cu * per_cu ? ntiles : n_cu * per_cu;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * P1W), lds, stream, q_xyz, nq, s_xyz, ns,
                      nbr, nbr_stride, kmax, rows_sorted, x, cin, Wh, Wl, cout, kpts, inv_extent,
-                     sxf, out);
+                     sxf, x_parts, w_parts, out);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -583,7 +590,8 @@ extern "C" size_t spr_kpconv_workspace_bytes(int nq, int ns, int cin, int cout) 
   // flag bytes + {x,y,z,flag} support records + pre-split fragment-order weights (hi, lo fp16; up to
   // 32 kernel points)
   const size_t n = (size_t)(ns > 0 ? ns : 1);
-  return align_up(n, 256) + align_up(16 * n, 256) + 2 * align_up((size_t)32 * cin * cout * 2, 256) + 256;
+  return align_up(n, 256) + align_up(16 * n, 256) + 2 * align_up((size_t)32 * cin * cout * 2, 256) +
+         2 * align_up(kAmaxParts * sizeof(float), 256) + 256;
 }
 
 extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, int ns,
@@ -602,9 +610,12 @@ extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, in
   float4* sxf = (float4*)((char*)ws + align_up((size_t)ns, 256));
   _Float16* wh = (_Float16*)((char*)sxf + align_up((size_t)ns * 16, 256));
   _Float16* wl = (_Float16*)((char*)wh + align_up((size_t)32 * cin * cout * 2, 256));
+  float* x_parts = (float*)((char*)wl + align_up((size_t)32 * cin * cout * 2, 256));
+  float* w_parts = x_parts + align_up(kAmaxParts * sizeof(float), 256) / sizeof(float);
   const float inv_extent = 1.0f / kp_extent;
 
   if (cin == 1 && impl == 0 && n_kp <= 16) {
+    ProfScope prof(stream, cin * 100000 + cout, nq);
     hipLaunchKernelGGL(k_kpconv_cin1, dim3(cdiv(nq, 64)), dim3(256), 0, stream, q_xyz, nq, s_xyz, ns, nbr,
                        nbr_stride, kmax, rows_sorted, x, weights, cout, kernel_points, n_kp, inv_extent, out);
     SPR_LAUNCH_CHECK();
@@ -617,11 +628,13 @@ extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, in
 
   if (impl == 0 && n_kp == kKP && cin % 32 == 0 && cout % 32 == 0 && cout <= 256) {
     const int ktot = n_kp * cin;
+    if (int rc = launch_absmax(x, ns, cin, cin, x_parts, stream)) return rc;
+    if (int rc = launch_absmax(weights, ktot, cout, cout, w_parts, stream)) return rc;
     hipLaunchKernelGGL(k_w_prep, dim3(cdiv((long)ktot * cout, 256)), dim3(256), 0, stream, weights, cin, cout,
-                       cin % 64 == 0 ? 64 : 32, wh, wl);
+                       cin % 64 == 0 ? 64 : 32, w_parts, wh, wl);
 #define SPR_KP_ARGS                                                                         \
   q_xyz, nq, s_xyz, ns, nbr, nbr_stride, kmax, rows_sorted, x, cin, wh, wl, cout,           \
-      kernel_points, inv_extent, sxf, out, stream
+      kernel_points, inv_extent, sxf, x_parts, w_parts, out, stream
     if (cin % 64 == 0) {
       // TQ = 32 (MT = 2), 8 waves: 4 n-groups x 2 k-halves, every wave both m-tiles
       if (cout == 64) return launch_mfma<64, 32, 1, 8, 2>(SPR_KP_ARGS);

@@ -19,6 +19,8 @@
 //     33 words (conflict-free fragment reads).
 // In both the next K-slab is prefetched into registers (inline-asm loads +
 // explicit s_waitcnt) while the current one feeds the MFMAs.
+#include <atomic>
+
 #include "attn_planes.h"
 #include "spr_common.h"
 
@@ -35,7 +37,7 @@ constexpr int LDSK = BK + 1;
 template <int ACT, bool RES>
 __device__ __forceinline__ void store_tile(const f32x16& acc, int row0, int col, int M, int N,
                                            float bv, const float* __restrict__ residual,
-                                           float* __restrict__ out, int lh) {
+                                           float* __restrict__ out, int lh, float unscale = 1.0f) {
   if (col >= N) return;
   float res[16];
   if (RES) {
@@ -48,7 +50,7 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, int row0, int col,
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    float v = acc[r] + bv;
+    float v = acc[r] * unscale + bv;   // unscale: exact power of two (1 in the exact-f32 kernel)
     if (RES) v += res[r];
     if (ACT == SPR_ACT_RELU) v = fmaxf(v, 0.f);
     if (ACT == SPR_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
@@ -164,20 +166,22 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt(
 }
 
 // ---------------------------------------------------------------------------
-// Split-fp16 GEMM ("h3"): fp32 accuracy at ~5x the exact-f32 MFMA rate.
-//   x = hi + lo,  hi = fp16(x),  lo = fp16(x - hi)
-//   a.b ~= ah.bh + ah.bl + al.bh                   (al.bl ~ 2^-22 |a.b| dropped)
-// (the matrix cores honour fp16 subnormals on both operands -- measured with
-// scripts/abl/denorm.hip -- so lo needs no rescaling and all three products
-// share ONE fp32 accumulator; lo's absolute resolution is 2^-24)
-// hi and lo together carry 22 significand bits, so the operand representation
-// error is ~2^-23 relative -- the same order as one fp32 rounding; products
-// are exact in the MFMA and accumulate in fp32.  Three v_mfma_f32_32x32x16_f16
-// per 16-deep k-step (32 cycles each) replace eight v_mfma_f32_32x32x2_f32
-// (64 cycles each).  Operands are split on the fly while a K-slab is staged
-// into LDS (fp16 rows of 32+8 halves: 80-byte stride -> conflict-free
-// ds_read_b128 fragment reads).  Requires |x| < 65504 (activations here are
-// normalised, O(10)); spr_set_gemm_mode(0) selects the exact-f32 kernel.
+// Split-fp16 GEMM ("h3"): fp32-level accuracy at ~5x the exact-f32 MFMA rate.
+//   x' = x s_x (s_x = per-tensor power of two, max |x'| in [2^14, 2^15))
+//   x' = hi + lo,  hi = fp16(x'),  lo = fp16(x' - hi)
+//   a.b ~= (ah.bh + ah.bl + al.bh) / (s_a s_b)        (al.bl ~ 2^-22 |a.b| dropped)
+// The matrix cores honour fp16 subnormals on both operands (measured with
+// scripts/abl/denorm.hip), so all three products share ONE fp32 accumulator.
+// Range safety (spr_common.h, split_pk_s): max |x| of each operand comes from a
+// pre-pass (launch_absmax -> 512 partials, reduced in this kernel's prologue), so
+// no operand can overflow fp16 and every element within 2^-18 of its tensor's
+// maximum keeps 22 significand bits; smaller ones keep an absolute error of
+// 2^-39 max|x|.  Products are exact in the MFMA and accumulate in fp32.  Three
+// v_mfma_f32_32x32x16_f16 per 16-deep k-step (32 cycles each) replace eight
+// v_mfma_f32_32x32x2_f32 (64 cycles each).  Operands are scaled + split on the
+// fly while a K-slab is staged into LDS (fp16 rows of 32+8 halves: 80-byte stride
+// -> conflict-free ds_read_b128 fragment reads).  spr_set_gemm_mode(0) selects the
+// exact-f32 kernel.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -189,7 +193,8 @@ template <int BM, int BN, int WM, int WN, int ACT, bool RES, bool PLANES = false
 __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
     const float* __restrict__ X, int M, int K, const float* __restrict__ Wt, int N,
     const float* __restrict__ bias, const float* __restrict__ residual,
-    float* __restrict__ out, AttnPlanes pl, int f0) {
+    float* __restrict__ out, AttnPlanes pl, int f0, const float* __restrict__ a_parts,
+    const float* __restrict__ w_parts) {
   constexpr int NT = WM * WN * 64;      // threads (4 or 8 waves)
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);   // 32x32 sub-tiles per wave
   constexpr int A_F4 = BM * BK / 4, B_F4 = BN * BK / 4;
@@ -207,6 +212,18 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
   const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
   const int m0 = (lid / gx) * BM, n0 = (lid % gx) * BN;
   const int l31 = lane & 31, lh = lane >> 5;
+
+  // per-tensor power-of-two operand scales from the absmax partials
+  float sa, sb, unscale;
+  {
+    float* shf = reinterpret_cast<float*>(gemm_smem);
+    const int ka = pow2_exp_for(block_absmax(a_parts, shf));
+    const int kb = pow2_exp_for(block_absmax(w_parts, shf));
+    __syncthreads();   // shf aliases the operand tiles
+    sa = pow2f(ka);
+    sb = pow2f(kb);
+    unscale = pow2f(-ka - kb);
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -235,10 +252,10 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
   };
   // rows past M / N are clamped on the load side: they produce finite garbage
   // in accumulator rows / columns that store_tile never writes
-  auto split_store = [&](const f32x4& v, _Float16* hi, _Float16* lo) {
+  auto split_store = [&](const f32x4& v, float sc, _Float16* hi, _Float16* lo) {
     unsigned int h0, h1, l0, l1;
-    split_pk(v[0], v[1], h0, l0);
-    split_pk(v[2], v[3], h1, l1);
+    split_pk_s(v[0], v[1], sc, h0, l0);
+    split_pk_s(v[2], v[3], sc, h1, l1);
     *reinterpret_cast<u32x2*>(hi) = (u32x2){h0, h1};
     *reinterpret_cast<u32x2*>(lo) = (u32x2){l0, l1};
   };
@@ -249,13 +266,13 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
     for (int i = 0; i < A_PT; ++i) {
       const int f = tid + i * NT;
       const int r = f / (BK / 4), c4 = f % (BK / 4);
-      split_store(ra[i], Ah + r * HS + c4 * 4, Al + r * HS + c4 * 4);
+      split_store(ra[i], sa, Ah + r * HS + c4 * 4, Al + r * HS + c4 * 4);
     }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
       const int f = tid + i * NT;
       const int r = f / (BK / 4), c4 = f % (BK / 4);
-      split_store(rb[i], Bh + r * HS + c4 * 4, Bl + r * HS + c4 * 4);
+      split_store(rb[i], sb, Bh + r * HS + c4 * 4, Bl + r * HS + c4 * 4);
     }
   };
 
@@ -312,6 +329,9 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
       const int tok = m0 + (wm * TM + i) * 32 + l31;
       if (tok >= M) continue;
       const int which = (f0 + n0) >> 8;                         // 0 Q, 1 K, 2 V (block uniform)
+      // plane multiplier (power of two; Q additionally log2(e)/sqrt(d)) -- attention.hip,
+      // k_plane_scales: keeps every plane inside fp16's range whatever the magnitudes
+      const float pmul = pl.scales[which];
       int vcol = 0;
       if (which == 2) {
         const int sg = find_segment(pl.cu, pl.nseg, tok);
@@ -326,9 +346,10 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
           for (int r = 0; r < 16; r += 2) {
             // registers r, r+1 = adjacent features (two plane rows), same token column
             const int d = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float a = acc[i][j][r] + bias[fl + d], b = acc[i][j][r + 1] + bias[fl + d + 1];
+            const float a = acc[i][j][r] * unscale + bias[fl + d];
+            const float b = acc[i][j][r + 1] * unscale + bias[fl + d + 1];
             unsigned int hu, lu;
-            split_pk(a, b, hu, lu);
+            split_pk_s(a, b, pmul, hu, lu);
             const f16x2 hh = __builtin_bit_cast(f16x2, hu), ll = __builtin_bit_cast(f16x2, lu);
             const size_t o = (size_t)(fg + d) * pl.tp + vcol;
             pl.vth[o] = hh[0];
@@ -339,17 +360,16 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
         } else {
           _Float16* ph = which == 0 ? pl.qh : pl.kh;
           _Float16* pw = which == 0 ? pl.ql : pl.kl;
-          const float sc = which == 0 ? pl.qscale : 1.0f;
           const size_t row = ((size_t)(fg >> 5) * pl.t_total + tok) * 32;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int d0 = 8 * g + 4 * lh;                      // registers 4g..4g+3 = features d0..d0+3
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (acc[i][j][4 * g + e] + bias[fl + d0 + e]) * sc;
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * unscale + bias[fl + d0 + e];
             unsigned int h0, h1, l0, l1;
-            split_pk(v[0], v[1], h0, l0);
-            split_pk(v[2], v[3], h1, l1);
+            split_pk_s(v[0], v[1], pmul, h0, l0);
+            split_pk_s(v[2], v[3], pmul, h1, l1);
             *reinterpret_cast<u32x2*>(ph + row + d0) = (u32x2){h0, h1};
             *reinterpret_cast<u32x2*>(pw + row + d0) = (u32x2){l0, l1};
           }
@@ -364,11 +384,11 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
     const float bv = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
-      store_tile<ACT, RES>(acc[i][j], m0 + (wm * TM + i) * 32, col, M, N, bv, residual, out, lh);
+      store_tile<ACT, RES>(acc[i][j], m0 + (wm * TM + i) * 32, col, M, N, bv, residual, out, lh, unscale);
   }
 }
 
-static int g_gemm_mode = 1;   // 1 = split-fp16 (default), 0 = exact f32 MFMA
+static std::atomic<int> g_gemm_mode{1};   // 1 = split-fp16 (default), 0 = exact f32 MFMA
 
 // N small (overlap_predictor, N = 1): one wave per (row, n).
 __global__ void k_gemv_rows(const float* __restrict__ X, int M, int K, const float* __restrict__ Wt,
@@ -452,28 +472,27 @@ using namespace spr;
 namespace {
 template <int ACT, bool RES>
 int launch_gemm(const float* x, int m, int k, const float* w, int n, const float* bias,
-                const float* residual, float* out, hipStream_t stream) {
-  if (spr::g_gemm_mode == 1) {
+                const float* residual, float* out, const float* a_parts, const float* w_parts,
+                hipStream_t stream) {
+  if (spr::g_gemm_mode.load(std::memory_order_relaxed) == 1) {
+    SPR_REQUIRE(a_parts != nullptr && w_parts != nullptr, "linear: split-fp16 mode needs the absmax partials");
     // LDS bytes of a BM x BN tile's slab (hi + lo planes of both operands)
     auto lds = [](int bm, int bn) { return (size_t)(bm + bn) * spr::HS * 2 * sizeof(_Float16); };
     if (n >= 256 && m >= 256) {
       // 256x256 tiles, 8 waves of 64x128: ~64 flop per operand byte fetched from
       // L2 (the 128-wide tiles below need 2-4x the L2 traffic and are bound by it)
       auto kern = spr::k_gemm_nt_h3<256, 256, 4, 2, ACT, RES>;
-      static bool attr_done = false;
-      if (!attr_done) {
-        SPR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)lds(256, 256)));
-        attr_done = true;
-      }
+      if (int rc = ensure_dyn_lds((const void*)kern, (int)lds(256, 256))) return rc;
       hipLaunchKernelGGL(kern, dim3(cdiv(n, 256) * cdiv(m, 256)), dim3(512), lds(256, 256), stream, x, m, k,
-                         w, n, bias, residual, out, spr::AttnPlanes(), 0);
+                         w, n, bias, residual, out, spr::AttnPlanes(), 0, a_parts, w_parts);
     } else if (n > 32) {
       hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 64, 4, 1, ACT, RES>), dim3(cdiv(n, 64) * cdiv(m, 128)),
-                         dim3(256), lds(128, 64), stream, x, m, k, w, n, bias, residual, out, spr::AttnPlanes(), 0);
+                         dim3(256), lds(128, 64), stream, x, m, k, w, n, bias, residual, out, spr::AttnPlanes(), 0,
+                         a_parts, w_parts);
     } else {
       hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 32, 4, 1, ACT, RES>), dim3(cdiv(n, 32) * cdiv(m, 128)),
-                         dim3(256), lds(128, 32), stream, x, m, k, w, n, bias, residual, out, spr::AttnPlanes(), 0);
+                         dim3(256), lds(128, 32), stream, x, m, k, w, n, bias, residual, out, spr::AttnPlanes(), 0,
+                         a_parts, w_parts);
     }
   } else if (n % 64 == 0) {
     hipLaunchKernelGGL((spr::k_gemm_nt<2, 2, ACT, RES>), dim3((n / 64) * cdiv(m, 64)), dim3(256), 0, stream,
@@ -487,30 +506,36 @@ int launch_gemm(const float* x, int m, int k, const float* w, int n, const float
 }
 }  // namespace
 
+int spr::gemm_mode() { return spr::g_gemm_mode.load(std::memory_order_relaxed); }
+
 int spr::launch_inproj_planes(const float* x, int m, int k, const float* w, int n, const float* bias, int f0,
-                              const AttnPlanes& planes, hipStream_t stream) {
+                              const AttnPlanes& planes, const float* a_parts, const float* w_parts,
+                              hipStream_t stream) {
   SPR_REQUIRE(n % 256 == 0 && f0 % 256 == 0 && k % BK == 0 && m >= 1 && bias != nullptr,
               "in-projection planes: bad shape (m=%d k=%d n=%d)", m, k, n);
+  SPR_REQUIRE(a_parts && w_parts && planes.scales, "in-projection planes: missing scale inputs");
   auto kern = spr::k_gemm_nt_h3<256, 256, 4, 2, SPR_ACT_NONE, false, true>;
   const size_t lds = (size_t)(256 + 256) * spr::HS * 2 * sizeof(_Float16);
-  static bool attr_done = false;
-  if (!attr_done) {
-    SPR_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
+  if (int rc = ensure_dyn_lds((const void*)kern, (int)lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(cdiv(n, 256) * cdiv(m, 256)), dim3(512), lds, stream, x, m, k, w, n, bias,
-                     (const float*)nullptr, (float*)nullptr, planes, f0);
+                     (const float*)nullptr, (float*)nullptr, planes, f0, a_parts, w_parts);
   SPR_LAUNCH_CHECK();
   return 0;
 }
 
-int spr::launch_linear_plain(const float* x, int m, int k, const float* w, int n, const float* bias, float* out,
-                             hipStream_t stream) {
-  return launch_gemm<SPR_ACT_NONE, false>(x, m, k, w, n, bias, nullptr, out, stream);
+// GEMM with the operand ranges already measured (a_parts / w_parts: kAmaxParts partial
+// maxima each, see launch_absmax); used by the matching head and the mode-0 fallbacks
+// (which pass nullptr).
+int spr::launch_linear_ranged(const float* x, int m, int k, const float* w, int n, const float* bias,
+                              float* out, const float* a_parts, const float* w_parts, hipStream_t stream) {
+  return launch_gemm<SPR_ACT_NONE, false>(x, m, k, w, n, bias, nullptr, out, a_parts, w_parts, stream);
 }
 
+extern "C" size_t spr_linear_workspace_bytes(void) { return 2 * align_up(kAmaxParts * sizeof(float), 256); }
+
 extern "C" int spr_linear(const float* x, int m, int k, const float* w, int n, const float* bias,
-                          const float* residual, int act, float* out, void* stream_) {
+                          const float* residual, int act, float* out, void* ws, size_t ws_bytes,
+                          void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(m > 0 && k > 0 && n > 0, "linear: bad sizes m=%d k=%d n=%d", m, k, n);
   SPR_REQUIRE(act >= 0 && act <= 2, "linear: unknown activation %d", act);
@@ -522,20 +547,32 @@ extern "C" int spr_linear(const float* x, int m, int k, const float* w, int n, c
     SPR_LAUNCH_CHECK();
     return 0;
   }
+  const float *a_parts = nullptr, *w_parts = nullptr;
+  if (spr::gemm_mode() == 1) {
+    SPR_REQUIRE(ws != nullptr && ws_bytes >= spr_linear_workspace_bytes(),
+                "linear: workspace too small (%zu bytes given, spr_linear_workspace_bytes() needed)", ws_bytes);
+    Workspace wk(ws, ws_bytes);
+    float* ap = wk.take<float>(kAmaxParts);
+    float* wp = wk.take<float>(kAmaxParts);
+    if (int rc = launch_absmax(x, m, k, k, ap, stream)) return rc;
+    if (int rc = launch_absmax(w, n, k, k, wp, stream)) return rc;
+    a_parts = ap;
+    w_parts = wp;
+  }
   const bool res = residual != nullptr;
   switch (act * 2 + (res ? 1 : 0)) {
-    case 0: return launch_gemm<SPR_ACT_NONE, false>(x, m, k, w, n, bias, residual, out, stream);
-    case 1: return launch_gemm<SPR_ACT_NONE, true>(x, m, k, w, n, bias, residual, out, stream);
-    case 2: return launch_gemm<SPR_ACT_RELU, false>(x, m, k, w, n, bias, residual, out, stream);
-    case 3: return launch_gemm<SPR_ACT_RELU, true>(x, m, k, w, n, bias, residual, out, stream);
-    case 4: return launch_gemm<SPR_ACT_SIGMOID, false>(x, m, k, w, n, bias, residual, out, stream);
-    default: return launch_gemm<SPR_ACT_SIGMOID, true>(x, m, k, w, n, bias, residual, out, stream);
+    case 0: return launch_gemm<SPR_ACT_NONE, false>(x, m, k, w, n, bias, residual, out, a_parts, w_parts, stream);
+    case 1: return launch_gemm<SPR_ACT_NONE, true>(x, m, k, w, n, bias, residual, out, a_parts, w_parts, stream);
+    case 2: return launch_gemm<SPR_ACT_RELU, false>(x, m, k, w, n, bias, residual, out, a_parts, w_parts, stream);
+    case 3: return launch_gemm<SPR_ACT_RELU, true>(x, m, k, w, n, bias, residual, out, a_parts, w_parts, stream);
+    case 4: return launch_gemm<SPR_ACT_SIGMOID, false>(x, m, k, w, n, bias, residual, out, a_parts, w_parts, stream);
+    default: return launch_gemm<SPR_ACT_SIGMOID, true>(x, m, k, w, n, bias, residual, out, a_parts, w_parts, stream);
   }
 }
 
 extern "C" int spr_set_gemm_mode(int mode) {
   SPR_REQUIRE(mode == 0 || mode == 1, "gemm mode must be 0 (exact f32 MFMA) or 1 (split-fp16)");
-  spr::g_gemm_mode = mode;
+  spr::g_gemm_mode.store(mode);
   return 0;
 }
 

@@ -216,7 +216,8 @@ extern "C" size_t spr_loss_workspace_bytes(int n_max, int m_max, int d) {
   if (n_max < 0 || m_max < 0 || d < 0) return 0;
   const size_t n = (size_t)(n_max > 0 ? n_max : 1), m = (size_t)(m_max > 0 ? m_max : 1);
   return align_up(n * m * 4, 256) + align_up(n * d * 4, 256) + align_up((size_t)d * d * 4, 256) +
-         align_up(n * 12, 256) + 2 * align_up(n * 4, 256) + 2 * align_up((size_t)cdiv(n, RB) * 8, 256) + 1024;
+         align_up(n * 12, 256) + 2 * align_up(n * 4, 256) + 2 * align_up((size_t)cdiv(n, RB) * 8, 256) +
+         2 * spr_linear_workspace_bytes() + 1024;
 }
 
 extern "C" int spr_bce_logits_mean(const float* x, const float* y, int n, float* out, void* ws,
@@ -249,12 +250,15 @@ extern "C" int spr_infonce_pair(const float* anchor_feat, int n, const float* po
   const int nb = cdiv(n, RB);
   double* pa = w.take<double>(nb);
   double* pb = w.take<double>(nb);
-  SPR_REQUIRE(pb != nullptr, "infonce: workspace carve failed");
+  const size_t lws = spr_linear_workspace_bytes();
+  char* lw1 = w.take<char>(lws);
+  char* lw2 = w.take<char>(lws);
+  SPR_REQUIRE(pb != nullptr && lw2 != nullptr, "infonce: workspace carve failed");
   hipLaunchKernelGGL(k_wsym, dim3(cdiv(d * d, 256)), dim3(256), 0, stream, W, d, wsym);
   hipLaunchKernelGGL(k_transform, dim3(cdiv(n, 256)), dim3(256), 0, stream, pose_gt, anchor_xyz, n, axyz);
   // logits = (A W_sym) B^T : W_sym is symmetric, so the NT GEMM applies it as is
-  if (int rc = spr_linear(anchor_feat, n, d, wsym, d, nullptr, nullptr, SPR_ACT_NONE, t, stream_)) return rc;
-  if (int rc = spr_linear(t, n, d, positive_feat, m, nullptr, nullptr, SPR_ACT_NONE, logits, stream_)) return rc;
+  if (int rc = spr_linear(anchor_feat, n, d, wsym, d, nullptr, nullptr, SPR_ACT_NONE, t, lw1, lws, stream_)) return rc;
+  if (int rc = spr_linear(t, n, d, positive_feat, m, nullptr, nullptr, SPR_ACT_NONE, logits, lw2, lws, stream_)) return rc;
   hipLaunchKernelGGL(k_infonce_rows, dim3(cdiv((long)n * 64, 256)), dim3(256), 0, stream, logits, n, m, axyz,
                      positive_xyz, r_p, r_n, rl, rm);
   hipLaunchKernelGGL(k_pair_partial, dim3(nb), dim3(RB), 0, stream, rl, rm, n, pa, pb);

@@ -12,7 +12,8 @@
 //
 // The reference loops over pairs in Python, materialises softmax copies of the
 // N x M matrix and calls LAPACK through torch.svd (plus a device->host sync in
-// an assert, se3_torch.py:132).  Here: one exact-f32 MFMA GEMM per pair writes
+// an assert, se3_torch.py:132).  Here: one GEMM per pair (spr_linear's arithmetic:
+// range-scaled split-fp16 MFMA by default, exact f32 in gemm mode 0) writes
 // the score matrix once into scratch; row / column log-sum-exp passes stream
 // it (wave per row, 64 columns x 4 row-lanes per workgroup for columns); the
 // slack Sinkhorn is carried as two potential vectors
@@ -23,6 +24,7 @@
 // no host round trip anywhere.
 #include <vector>
 
+#include "attn_planes.h"
 #include "spr_common.h"
 
 namespace spr {
@@ -411,7 +413,7 @@ size_t match_ws_bytes(const int* cu_host, int npairs) {
     off = (off + 63) / 64 * 64;
   }
   return align_up((size_t)off * 4, 256) + align_up(sizeof(PairDesc) * npairs, 256) +
-         4 * align_up((size_t)tmax * 4, 256) + 1024;
+         4 * align_up((size_t)tmax * 4, 256) + align_up(kAmaxParts * sizeof(float), 256) + 1024;
 }
 
 }  // namespace
@@ -457,10 +459,18 @@ int correlate(const float* feat, int d, const int* cu_dev, const int* cu_host, i
   hipLaunchKernelGGL(k_build_pairs, dim3(1), dim3(64), 0, stream, cu_dev, npairs, pd);
   *max_n = 0;
   *max_m = 0;
+  // one range measurement of the whole feature tensor serves both operands of every pair
+  const float* parts = nullptr;
+  if (gemm_mode() == 1) {
+    float* pp = w.take<float>(kAmaxParts);
+    SPR_REQUIRE(pp != nullptr, "match: workspace carve failed");
+    if (int rc = launch_absmax(feat, cu_host[2 * npairs], d, d, pp, stream)) return rc;
+    parts = pp;
+  }
   for (int b = 0; b < npairs; ++b) {
     SPR_REQUIRE(h[b].n > 0 && h[b].m > 0, "match: empty cloud in pair %d", b);
-    if (spr_linear(feat + (size_t)h[b].src_beg * d, h[b].n, d, feat + (size_t)h[b].tgt_beg * d,
-                   h[b].m, nullptr, nullptr, SPR_ACT_NONE, mat + h[b].off, stream))
+    if (launch_linear_ranged(feat + (size_t)h[b].src_beg * d, h[b].n, d, feat + (size_t)h[b].tgt_beg * d,
+                             h[b].m, nullptr, mat + h[b].off, parts, parts, stream))
       return 1;
     *max_n = h[b].n > *max_n ? h[b].n : *max_n;
     *max_m = h[b].m > *max_m ? h[b].m : *max_m;

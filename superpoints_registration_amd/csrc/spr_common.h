@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
+#include <cstring>
 
 #include "../../include/spr.h"
 
@@ -87,6 +88,15 @@ struct ProfScope {
   }
 };
 
+// Per-device one-time kernel attribute (dynamic LDS above 64 KB) and CU count; keyed by the
+// current device, mutex protected (launches come from several host threads).  core.hip.
+int ensure_dyn_lds(const void* kernel, int bytes);
+int device_cu_count();
+
+// max |x| over a [rows, cols] view with row stride `stride` (floats) -> parts[kAmaxParts]
+// (device); see block_absmax.  Defined in core.hip.
+int launch_absmax(const float* x, long rows, int cols, long stride, float* parts, hipStream_t stream);
+
 // ---- device helpers --------------------------------------------------------
 #ifdef __HIPCC__
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -121,7 +131,9 @@ __device__ __forceinline__ int xcd_swizzle(int b, int nwg) {
 // Split-fp16 operand: hi = fp16(x) (RNE, packed convert), lo = fp16(x - hi) with
 // the subtraction and the narrowing done by ONE mixed-precision FMA per
 // element (v_fma_mixlo/hi_f16 widen the fp16 operand inside the ALU).
-// hi_u / lo_u hold (a, b) as packed halves.
+// hi_u / lo_u hold (a, b) as packed halves.  UNSCALED form: only for operands
+// whose magnitude is known to sit in fp16's comfortable range (softmax
+// probabilities); everything else goes through split_pk_s.
 typedef _Float16 spr_h16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split_pk(float a, float b, unsigned int& hi_u, unsigned int& lo_u) {
   const spr_h16x2 hi = {(_Float16)a, (_Float16)b};
@@ -130,6 +142,78 @@ __device__ __forceinline__ void split_pk(float a, float b, unsigned int& hi_u, u
       "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
       : "=&v"(lo_u)
       : "v"(hi_u), "v"(a), "v"(b));
+}
+
+// Range-safe split: the operand is first multiplied by a power of two s (exact)
+// chosen per TENSOR so that max |x| s lies in [2^14, 2^15) (pow2_scale_for):
+//   hi = fp16(x s),  lo = fp16(x s - hi)      (one v_fma_mix*_f16 each)
+// Every element with |x| >= 2^-18 max|x| then has a normal lo (22 significand
+// bits together with hi); smaller elements keep an ABSOLUTE error <= 2^-25 in
+// scaled units = 2^-39 max|x| -- far below one fp32 ulp of the tensor's large
+// entries.  No overflow is possible (max |x s| < 2^15 < 65504).  The product of
+// two scaled operands is unscaled in the epilogue by the exact factor
+// 1 / (s_a s_b).
+__device__ __forceinline__ void split_pk_s(float a, float b, float s, unsigned int& hi_u,
+                                           unsigned int& lo_u) {
+  asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
+      : "=&v"(hi_u)
+      : "v"(a), "v"(b), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %2, %4, -%1 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %3, %4, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(lo_u)
+      : "v"(hi_u), "v"(a), "v"(b), "v"(s));
+}
+
+// Exponent k of the power-of-two scale 2^k that brings `amax` into [2^14, 2^15);
+// clamped to [-60, 60] (so that 2^-(ka+kb) stays a normal float); 0 for a zero,
+// negative or non-finite bound.
+__host__ __device__ __forceinline__ int pow2_exp_for(float amax) {
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 0;
+  unsigned int u;
+#ifdef __HIP_DEVICE_COMPILE__
+  u = __float_as_uint(amax);
+#else
+  memcpy(&u, &amax, 4);
+#endif
+  const int e = (int)((u >> 23) & 0xff) - 127;   // floor(log2 amax) (denormals: -127)
+  int k = 14 - e;
+  if (k > 60) k = 60;
+  if (k < -60) k = -60;
+  return k;
+}
+__host__ __device__ __forceinline__ float pow2f(int k) {   // 2^k, |k| <= 126
+  const unsigned int u = (unsigned int)(127 + k) << 23;
+  float f;
+#ifdef __HIP_DEVICE_COMPILE__
+  f = __uint_as_float(u);
+#else
+  memcpy(&f, &u, 4);
+#endif
+  return f;
+}
+
+// ---- per-tensor max |x| as kAmaxParts per-block partials ---------------------
+// launch_absmax writes exactly kAmaxParts floats (unused blocks write 0); the
+// consumer kernel reduces them in its prologue with block_absmax -- no atomics,
+// no memset, no host round trip.
+constexpr int kAmaxParts = 512;
+// Reduces parts[0..kAmaxParts) over the workgroup; `sh` = 17 floats of LDS.
+// Contains two __syncthreads().  Result returned to every thread.
+__device__ __forceinline__ float block_absmax(const float* __restrict__ parts, float* sh) {
+  float m = 0.f;
+  for (int i = threadIdx.x; i < kAmaxParts; i += blockDim.x) m = fmaxf(m, parts[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = sh[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = fmaxf(t, sh[w]);
+    sh[16] = t;
+  }
+  __syncthreads();
+  return sh[16];
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

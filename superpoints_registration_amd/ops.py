@@ -198,8 +198,10 @@ def linear(x, weight, bias=None, residual=None, act: int = ACT_NONE) -> torch.Te
         residual = _dev(residual, "residual", torch.float32)
         assert residual.shape == (m, n)
     out = torch.empty((m, n), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().spr_linear(_ptr(x), m, k, _ptr(weight), n, _ptr(bias), _ptr(residual),
-                                     int(act), _ptr(out), _stream(x)), "spr_linear")
+    L = _lib.lib()
+    ws = _workspace(L.spr_linear_workspace_bytes(), x.device)
+    _lib.check(L.spr_linear(_ptr(x), m, k, _ptr(weight), n, _ptr(bias), _ptr(residual),
+                            int(act), _ptr(out), _ptr(ws), ws.numel(), _stream(x)), "spr_linear")
     return out
 
 
@@ -278,7 +280,7 @@ def attention_inproj(x_qk, x_v, w_in, b_in, cu, kv_seg, max_len: int, nhead: int
 
 
 def set_attn_mode(mode: int) -> None:
-    """1 = split-fp16 MFMA (default), 0 = exact f32 MFMA."""
+    """1 = split-fp16 MFMA (default), 0 = exact f32 MFMA, 2 = single-pass fp16 MFMA."""
     _lib.check(_lib.lib().spr_set_attn_mode(int(mode)), "spr_set_attn_mode")
 
 

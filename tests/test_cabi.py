@@ -32,14 +32,14 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_version_and_error_channel():
     L = _lib.lib()
-    assert L.spr_version() == 1
+    assert L.spr_version() == 2
     assert isinstance(L.spr_last_error(), bytes)
 
 
 def test_host_side_argument_validation_needs_no_gpu():
     # bad arguments are rejected on the host before any HIP call
     L = _lib.lib()
-    rc = L.spr_linear(None, 0, 32, None, 32, None, None, 0, None, None)
+    rc = L.spr_linear(None, 0, 32, None, 32, None, None, 0, None, None, 0, None)
     assert rc != 0 and b"linear" in L.spr_last_error()
     rc = L.spr_attn_varlen_fwd(None, 256, None, 256, None, 256, None, None, 20, 2, 10, 8, 64, 0.1, None, 256,
                                None, 0, None)

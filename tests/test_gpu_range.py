@@ -1,0 +1,238 @@
+"""GPU: range robustness of the default (split-fp16) arithmetic.
+
+Every matrix product of the library runs, by default, on fp16 hi/lo operand pairs
+(three MFMAs per product, fp32 accumulation).  fp16 has a 5-bit exponent, so the
+operands are brought into range by per-tensor powers of two derived from measured
+(or, for the fused in-projection, derived) magnitude bounds -- spr_common.h
+split_pk_s, linear.hip, attention.hip k_plane_scales, kpconv.hip.  These tests
+check fp32-level accuracy against float64 at operand magnitudes from 1e-5 to 1e3
+(and mixed magnitudes inside one tensor), where an unscaled fp16 split would lose
+its low half or overflow.
+
+Criteria (written next to each check):
+  * GEMM-shaped ops: per ELEMENT, |err_ij| <= (2^-21 + sqrt(K) 2^-24) sum_k |a_ik b_jk|
+    (the forward error bound of an fp32 dot product with 2^-22 operand error), and
+    the legacy max-norm criterion 2e-6 max(1, K/256) max|ref|;
+  * attention: 3e-6 max|ref|, or 4x the error of a plain fp32 evaluation when the
+    scores are so large that fp32 itself is ill-conditioned.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import torch_oracle as O
+from oracle.gen_golden import ops_inputs
+from superpoints_registration_amd import get_config, ops, synthetic
+from superpoints_registration_amd.regtr import RegTR
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _check_gemm(got, a64, b64, what, k):
+    """got ~ a64 @ b64^T.  Per-element bound relative to sum_k |a||b| + max-norm bound."""
+    ref = a64 @ b64.t()
+    mag = a64.abs() @ b64.abs().t()
+    err = (torch.as_tensor(got, dtype=torch.float64) - ref).abs()
+    coef = 2.0 ** -21 + math.sqrt(k) * 2.0 ** -24
+    worst = float((err / (mag + 1e-300)).max())
+    assert worst <= coef, f"{what}: per-element error {worst:.3e} of sum|a||b| exceeds {coef:.3e}"
+    scale = float(ref.abs().max())
+    assert float(err.max()) <= 2e-6 * max(1, k // 256) * scale, \
+        f"{what}: max err {float(err.max()):.3e} vs scale {scale:.3e}"
+    assert torch.isfinite(torch.as_tensor(got)).all(), what
+
+
+MAGS = [(1e-5, 1e-5), (1e-5, 1e3), (1e-3, 2e-3), (1.0, 2e-4), (3.0, 0.2), (1e3, 1e-5), (1e3, 1e3), (6e4, 1.0)]
+
+
+@pytest.mark.parametrize("m,k,n", [(700, 256, 256), (300, 1024, 128), (257, 64, 32), (515, 256, 768)])
+@pytest.mark.parametrize("mx,mw", MAGS)
+def test_linear_every_magnitude(device, m, k, n, mx, mw):
+    ops.set_gemm_mode(1)
+    x = synthetic.rand((m, k), 11) * mx
+    w = synthetic.rand((n, k), 12) * mw
+    y = ops.linear(x.to(device), w.to(device)).cpu()
+    _check_gemm(y, x.double(), w.double(), f"linear {m}x{k}x{n} |x|~{mx:g} |w|~{mw:g}", k)
+
+
+def test_linear_mixed_magnitudes_inside_one_tensor(device):
+    """Rows of x spanning 4 decades, rows of w spanning 3: the per-tensor scale must not
+    destroy the small rows (their absolute error floor is 2^-39 of the tensor maximum)."""
+    ops.set_gemm_mode(1)
+    m, k, n = 640, 256, 256
+    x = synthetic.rand((m, k), 13) * torch.logspace(0, -4, m).unsqueeze(1) * 50.0
+    w = synthetic.rand((n, k), 14) * torch.logspace(0, -3, n).unsqueeze(1) * 0.01
+    y = ops.linear(x.to(device), w.to(device)).cpu()
+    ref = x.double() @ w.double().t()
+    mag = x.double().abs() @ w.double().abs().t()
+    err = (y.double() - ref).abs()
+    assert float((err / mag).max()) <= 2.0 ** -21 + 16 * 2.0 ** -24
+
+
+def test_linear_bias_residual_activation_small_weights(device):
+    ops.set_gemm_mode(1)
+    m, k, n = 900, 256, 1024
+    x, w = synthetic.rand((m, k), 15, -3, 3), synthetic.rand((n, k), 16) * 2e-3
+    b, r = synthetic.rand((n,), 17) * 1e-3, synthetic.rand((m, n), 18) * 1e-3
+    y = ops.linear(x.to(device), w.to(device), b.to(device), r.to(device), ops.ACT_RELU).cpu()
+    ref = torch.relu(x.double() @ w.double().t() + b.double() + r.double())
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+def _attn_ref(q, k, v, lens, kv_seg, dtype):
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    out = torch.zeros((sum(lens), 256), dtype=dtype)
+    for s in range(len(lens)):
+        ks = kv_seg[s]
+        qq = q[offs[s]:offs[s + 1]].to(dtype).view(-1, 8, 32).transpose(0, 1)
+        kk = k[offs[ks]:offs[ks + 1]].to(dtype).view(-1, 8, 32).transpose(0, 1)
+        vv = v[offs[ks]:offs[ks + 1]].to(dtype).view(-1, 8, 32).transpose(0, 1)
+        a = torch.softmax(qq @ kk.transpose(1, 2) / math.sqrt(32), -1)
+        out[offs[s]:offs[s + 1]] = (a @ vv).transpose(0, 1).reshape(-1, 256)
+    return out
+
+
+@pytest.mark.parametrize("mq,mk,mv", [(1e-5, 1e-5, 1e-5), (1e-3, 1e3, 1e-5), (2.0, 2.0, 1e3), (1e3, 1e-3, 2e-4),
+                                      (30.0, 30.0, 1.0), (1e-2, 1e-2, 6e4)])
+def test_attention_core_every_magnitude(device, mq, mk, mv):
+    ops.set_attn_mode(1)
+    lens = [170, 33, 129, 1]
+    kv_seg = [2, 3, 0, 1]
+    tot = sum(lens)
+    q = synthetic.rand((tot, 256), 21) * mq
+    k = synthetic.rand((tot, 256), 22) * mk
+    v = synthetic.rand((tot, 256), 23) * mv
+    cu = ops.lengths_to_cu(lens, device)
+    seg = torch.tensor(kv_seg, dtype=torch.int32, device=device)
+    o = ops.attention(q.to(device), k.to(device), v.to(device), cu, seg, max(lens), 8).cpu()
+    ref = _attn_ref(q, k, v, lens, kv_seg, torch.float64)
+    ref32 = _attn_ref(q, k, v, lens, kv_seg, torch.float32).double()
+    scale = float(ref.abs().max())
+    err = float((o.double() - ref).abs().max())
+    err32 = float((ref32 - ref).abs().max())
+    assert torch.isfinite(o).all()
+    assert err <= max(3e-6 * scale, 4 * err32), f"attention |q|~{mq:g} |k|~{mk:g} |v|~{mv:g}: {err:.3e} (fp32 {err32:.3e}, scale {scale:.3e})"
+
+
+@pytest.mark.parametrize("mx,mw,mb", [(1.5, 0.1, 0.2), (1.5, 1e-3, 1e-3), (1e-3, 1e-2, 1e-6), (200.0, 1e-3, 1e-2),
+                                      (1e-4, 30.0, 1e-3)])
+@pytest.mark.parametrize("shared", [True, False])
+def test_attention_fused_inprojection_every_magnitude(device, mx, mw, mb, shared):
+    ops.set_attn_mode(1)
+    ops.set_gemm_mode(1)
+    lens = [301, 70, 257, 33, 129, 1]
+    kv_seg = [1, 0, 3, 2, 5, 4]
+    tot = sum(lens)
+    x_qk = synthetic.rand((tot, 256), 31) * mx
+    x_v = x_qk if shared else synthetic.rand((tot, 256), 32) * mx
+    w = synthetic.rand((768, 256), 33) * mw
+    b = synthetic.rand((768,), 34) * mb
+    cu = ops.lengths_to_cu(lens, device)
+    seg = torch.tensor(kv_seg, dtype=torch.int32, device=device)
+    d_qk = x_qk.to(device)
+    d_v = d_qk if shared else x_v.to(device)
+    o = ops.attention_inproj(d_qk, d_v, w.to(device), b.to(device), cu, seg, max(lens), 8).cpu()
+
+    def proj(dt):
+        qk = x_qk.to(dt) @ w[:512].to(dt).t() + b[:512].to(dt)
+        vv = x_v.to(dt) @ w[512:].to(dt).t() + b[512:].to(dt)
+        return _attn_ref(qk[:, :256], qk[:, 256:], vv, lens, kv_seg, dt)
+    ref, ref32 = proj(torch.float64), proj(torch.float32).double()
+    scale = float(ref.abs().max())
+    err = float((o.double() - ref).abs().max())
+    err32 = float((ref32 - ref).abs().max())
+    assert torch.isfinite(o).all()
+    assert err <= max(5e-6 * scale, 4 * err32), f"fused attention |x|~{mx:g} |w|~{mw:g}: {err:.3e} (fp32 {err32:.3e}, scale {scale:.3e})"
+
+
+@pytest.mark.parametrize("tag", ["c32", "c64", "c128"])
+@pytest.mark.parametrize("mx,mw", [(1e-5, 1e-5), (1.0, 2e-3), (1e3, 1e3), (1e-3, 50.0)])
+def test_kpconv_phase2_every_magnitude(device, tag, mx, mw):
+    """KPConv: features of magnitude mx (kept non-negative so that the reference's neighbour
+    count, #{sum_c x > 0}, is the same for every scale), weights of magnitude mw; float64
+    restatement of kpconv_blocks.py:309-412 as the reference."""
+    gold, inp = load_golden("ops.npz"), ops_inputs()
+    pts = T(inp["kp.pts"])
+    nb = T(gold["kp.nb"].astype(np.int64))
+    x = inp[f"kp.{tag}.x"].abs() * mx
+    w = inp[f"kp.{tag}.w"] / inp[f"kp.{tag}.w"].abs().max() * mw
+    kp = T(gold[f"kp.{tag}.kpts"])
+    y = ops.kpconv(pts.to(device), pts.to(device), nb.to(torch.int32).to(device), x.to(device), w.to(device),
+                   kp.to(device), inp["kp.extent"], rows_sorted=True).cpu()
+    ref = O.kpconv(pts.double(), pts.double(), nb, x.double(), w.double(), kp.double(), float(inp["kp.extent"]))
+    scale = float(ref.abs().max())
+    err = float((y.double() - ref).abs().max())
+    assert torch.isfinite(y).all()
+    assert err <= 1e-5 * scale, f"kpconv {tag} |x|~{mx:g} |w|~{mw:g}: {err:.3e} vs scale {scale:.3e}"
+
+
+def test_correlation_gemm_small_features(device):
+    """Matching head on features of magnitude 1e-3: the dual-softmax arg-max and the
+    Sinkhorn weights go through the range-scaled correlation GEMM."""
+    inp = ops_inputs()
+    fs, ft = inp["sk.fs"] * 1e-3, inp["sk.ft"] * 1e-3
+    feat = torch.cat([fs, ft]).to(device)
+    cu_host = [0, fs.shape[0], fs.shape[0] + ft.shape[0]]
+    cu = torch.tensor(cu_host, dtype=torch.int32, device=device)
+    val, ind = ops.match_dualsoftmax(feat, cu, cu_host, 1)
+    corr = fs.double() @ ft.double().t() / 16.0
+    a = torch.softmax(corr, 0) * torch.softmax(corr, 1)
+    n, m = corr.shape
+    rv, ri = (a.max(0) if n > m else a.max(1))
+    got_v = val.cpu()[n:] if n > m else val.cpu()[:n]
+    got_i = ind.cpu()[n:] if n > m else ind.cpu()[:n]
+    assert torch.equal(got_i.long(), ri)
+    assert float((got_v.double() - rv).abs().max()) <= 1e-5 * float(rv.max())
+
+
+def test_end_to_end_with_small_weights(device):
+    """Every weight matrix of the model scaled by 0.01 (trained checkpoints carry weights of
+    1e-3..1e-2): pose and conditioned features against the float32 CPU oracle."""
+    cfg = get_config("3dmatch")
+    src, tgt, _ = synthetic.make_pair(2048, seed=5, extent=0.6, jitter=0.002)
+    model = RegTR(cfg)
+    synthetic.fill_parameters(model, seed=1)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() >= 2 and not name.endswith(".W"):
+                p.mul_(0.01)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(device).eval()
+    out = model({"src_xyz": [T(src).to(device)], "tgt_xyz": [T(tgt).to(device)]})
+    ref = O.regtr_forward(cfg, sd, [src], [tgt])
+    err = float(np.linalg.norm(out["pose"][0].cpu().numpy() - ref["pose"][0].numpy()))
+    assert err < 1e-4, f"pose error with 0.01x weights: {err:.3e}"
+    sf = out["src_feat"][0][0].cpu().numpy()
+    rf = ref["src_feat"][0].numpy().reshape(sf.shape)
+    assert np.abs(sf - rf).max() <= 1e-4 * max(np.abs(rf).max(), 1e-30)
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_attention_mode2_single_pass_fp16(device, shared):
+    """Mode 2 = hi planes only (11-bit operands, fp32 softmax / accumulation): the throughput
+    mode of BASELINE configs[4].  Accuracy target 2e-3 of the output scale."""
+    ops.set_attn_mode(2)
+    try:
+        lens = [301, 70, 257, 33, 129, 1]
+        kv_seg = [1, 0, 3, 2, 5, 4]
+        tot = sum(lens)
+        x_qk = synthetic.rand((tot, 256), 31, -1.5, 1.5)
+        x_v = x_qk if shared else synthetic.rand((tot, 256), 32, -1.5, 1.5)
+        w, b = synthetic.rand((768, 256), 33, -0.1, 0.1), synthetic.rand((768,), 34, -0.2, 0.2)
+        cu = ops.lengths_to_cu(lens, device)
+        seg = torch.tensor(kv_seg, dtype=torch.int32, device=device)
+        d_qk = x_qk.to(device)
+        d_v = d_qk if shared else x_v.to(device)
+        o = ops.attention_inproj(d_qk, d_v, w.to(device), b.to(device), cu, seg, max(lens), 8).cpu()
+        qk = x_qk.double() @ w[:512].double().t() + b[:512].double()
+        vv = x_v.double() @ w[512:].double().t() + b[512:].double()
+        ref = _attn_ref(qk[:, :256], qk[:, 256:], vv, lens, kv_seg, torch.float64)
+        err = float((o.double() - ref).abs().max())
+        assert err <= 2e-3 * float(ref.abs().max()), err
+        assert err >= 1e-6 * float(ref.abs().max()), "mode 2 is suspiciously exact: is the hi-only kernel running?"
+    finally:
+        ops.set_attn_mode(1)
