@@ -247,13 +247,15 @@ int spr_weighted_procrustes(const float* a, const float* b, const float* w,
  *   affinity = -(score - softplus(alpha)) / (exp(beta) + 0.02)
  *   n_iters x (row normalise incl. slack col; col normalise incl. slack row)
  *   P = exp(.), w_i = sum_j P_ij, t_hat_i = sum_j P_ij tgt_j / (w_i + 1e-6)
+ * alpha, beta: DEVICE pointers to the model's learnable scalars
+ * (qk_regtr_full.py:77-78) -- read by the kernel, no host round trip.
  * Outputs per src token: w [Tsrc], t_hat [Tsrc,3] (packed like the src
  * segments).  Feed (src_xyz, t_hat, w) to spr_weighted_procrustes.
  */
 size_t spr_sinkhorn_workspace_bytes(const int* cu_host, int npairs);
 int spr_sinkhorn_correspondences(const float* feat, int d, const float* xyz,
                                  const int* cu, const int* cu_host, int npairs,
-                                 float alpha, float beta, int n_iters,
+                                 const float* alpha, const float* beta, int n_iters,
                                  int slack, float* out_w, float* out_that,
                                  void* ws, size_t ws_bytes, void* stream);
 
@@ -296,7 +298,7 @@ int spr_sum_scaled(const float* values, int n, float scale, float* out,
  * with HIP events recorded on the launch stream (used by bench.py for the
  * roofline figures; off by default).
  * spr_prof_enable(1) clears the log and starts recording, spr_prof_enable(0)
- * clears and stops.  spr_prof_read synchronises on the recorded events and
+ * clears and stops.  spr_prof_read synchronises on the recorded events, CONSUMES them and
  * returns up to max_records entries (all arrays HOST memory):
  *   codes[i] = cin * 100000 + cout (KPConv) or -1 (attention core), nqs[i] =
  *   query / token count, ms[i] = duration. */

@@ -161,6 +161,31 @@ def gen_ops():
     print('ops.npz', len(out), 'arrays', os.path.getsize(os.path.join(OUT, 'ops.npz')) // 1024, 'KB')
 
 
+def gen_ops_extra():
+    """Cases added after ops.npz was frozen (kept in their own file so that the first
+    fixture set stays byte-identical): the post-norm branch of the cross-encoder layer
+    (transformers.py:124-182) with and without positional embedding on the values."""
+    ns = ref_harness.load()
+    tr, seq = ns['transformers'], ns['seq']
+    d = ops_inputs()
+    out = {}
+    sp, sm, _ = seq.pad_sequence(d['tl.src'], require_padding_mask=True)
+    tp, tm, _ = seq.pad_sequence(d['tl.tgt'], require_padding_mask=True)
+    spp, _, _ = seq.pad_sequence(d['tl.src_pe'])
+    tpp, _, _ = seq.pad_sequence(d['tl.tgt_pe'])
+    for tag, pre, sa_pe, ca_pe in (('post', False, True, True), ('post_nope', False, False, False),
+                                   ('pre_nope', True, False, False)):
+        layer = tr.TransformerCrossEncoderLayer(256, 8, 1024, 0.0, 'relu', pre, sa_pe, ca_pe, 'dot_prod')
+        synthetic.fill_parameters(layer, seed=21)
+        layer.eval()
+        with torch.no_grad():
+            so, to = layer(sp, tp, src_key_padding_mask=sm, tgt_key_padding_mask=tm, src_pos=spp, tgt_pos=tpp)
+        out[f'tl.{tag}.src_out'] = torch.cat(seq.unpad_sequences(so, d['tl.s_l'])).numpy()
+        out[f'tl.{tag}.tgt_out'] = torch.cat(seq.unpad_sequences(to, d['tl.t_l'])).numpy()
+    np.savez_compressed(os.path.join(OUT, 'ops_extra.npz'), **out)
+    print('ops_extra.npz', len(out), 'arrays', os.path.getsize(os.path.join(OUT, 'ops_extra.npz')) // 1024, 'KB')
+
+
 def pairs_for(cfg_tag, B):
     if cfg_tag == '3dmatch':
         sizes = [(1024, 900), (800, 1100)][:B]
@@ -277,6 +302,8 @@ def main():
             gen_preprocess()
         if 'ops' in what:
             gen_ops()
+        if 'ops_extra' in what:
+            gen_ops_extra()
         for tag in ('3dmatch', 'kitti', 'modelnet'):
             if tag in what:
                 gen_regtr(tag, 2)

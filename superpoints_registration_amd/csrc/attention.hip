@@ -750,8 +750,7 @@ extern "C" int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k,
   AttnPlanes pl{};
   AttnSmall sm{};
   if (int rc = carve(ws, ws_bytes, t, nseg, d_model, tp, pl, sm)) return rc;
-  if (int rc = launch_absmax(q, t, d_model, q_stride, sm.p0, stream)) return rc;
-  if (int rc = launch_absmax(k, t, d_model, k_stride, sm.p1, stream)) return rc;
+  if (int rc = launch_absmax2(q, t, d_model, q_stride, sm.p0, k, t, d_model, k_stride, sm.p1, stream)) return rc;
   if (int rc = launch_absmax(v, t, d_model, v_stride, sm.p2, stream)) return rc;
   hipLaunchKernelGGL(k_plane_scales, dim3(1), dim3(256), 0, stream, sm.p0, sm.p1, sm.p2, (const float*)nullptr,
                      (const float*)nullptr, d_model, scale * 1.4426950408889634f, sm.scales);
@@ -826,13 +825,12 @@ extern "C" int spr_attn_inproj_varlen_fwd(const float* x_qk, const float* x_v, i
   pl.tp = (int)tp;
   // operand ranges: max|x| (inputs), max|w| (the projection's own operand scale) and the plane
   // multipliers from the bounds max|x| * max row-L1(W block) + max|bias block|
-  if (int rc = launch_absmax(x_qk, t, d, d, sm.p0, stream)) return rc;
+  if (int rc = launch_absmax2(x_qk, t, d, d, sm.p0, w_in, 3 * d, d, d, sm.p1, stream)) return rc;
   const float* xvp = sm.p0;
   if (x_v != x_qk) {
     if (int rc = launch_absmax(x_v, t, d, d, sm.p2, stream)) return rc;
     xvp = sm.p2;
   }
-  if (int rc = launch_absmax(w_in, 3 * d, d, d, sm.p1, stream)) return rc;
   hipLaunchKernelGGL(k_row_l1, dim3(cdiv((long)3 * d * 64, 256)), dim3(256), 0, stream, w_in, 3 * d, d, sm.rowl1);
   hipLaunchKernelGGL(k_plane_scales, dim3(1), dim3(256), 0, stream, sm.p0, sm.p0, xvp, sm.rowl1, b_in, d,
                      scale * 1.4426950408889634f, sm.scales);

@@ -39,8 +39,20 @@ namespace {
 // per-block partials.  Fixed grid of kAmaxParts blocks: every slot is written.
 // cols4 = cols / 4 when the view is float4-addressable (cols, stride % 4 == 0 and
 // 16-byte aligned base), else 0 -> scalar path.
-__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, long rows, int cols,
-                                                long stride, int cols4, float* __restrict__ parts) {
+struct AbsmaxJob {
+  const float* x;
+  long rows, stride;
+  int cols, cols4;
+  float* parts;
+};
+// blockIdx.y selects the tensor (a second, usually small one -- the weights -- rides along in
+// the same launch)
+__global__ __launch_bounds__(256) void k_absmax(AbsmaxJob j0, AbsmaxJob j1) {
+  const AbsmaxJob j = blockIdx.y == 0 ? j0 : j1;
+  const float* __restrict__ x = j.x;
+  const long rows = j.rows, stride = j.stride;
+  const int cols = j.cols, cols4 = j.cols4;
+  float* __restrict__ parts = j.parts;
   __shared__ float sh[4];
   float m = 0.f;
   const long nthr = (long)gridDim.x * 256, t0 = (long)blockIdx.x * 256 + threadIdx.x;
@@ -139,12 +151,30 @@ int spr::device_cu_count() {
   return n;
 }
 
-int spr::launch_absmax(const float* x, long rows, int cols, long stride, float* parts, hipStream_t stream) {
+namespace {
+int make_job(const float* x, long rows, int cols, long stride, float* parts, AbsmaxJob* j) {
   SPR_REQUIRE(x != nullptr && parts != nullptr && rows >= 0 && cols >= 1 && stride >= cols,
               "absmax: bad arguments (rows=%ld cols=%d stride=%ld)", rows, cols, stride);
   const bool v4 = cols % 4 == 0 && stride % 4 == 0 && ((uintptr_t)x & 15) == 0;
-  hipLaunchKernelGGL(k_absmax, dim3(kAmaxParts), dim3(256), 0, stream, x, rows, cols, stride,
-                     v4 ? cols / 4 : 0, parts);
+  *j = AbsmaxJob{x, rows, stride, cols, v4 ? cols / 4 : 0, parts};
+  return 0;
+}
+}  // namespace
+
+int spr::launch_absmax(const float* x, long rows, int cols, long stride, float* parts, hipStream_t stream) {
+  AbsmaxJob j;
+  if (int rc = make_job(x, rows, cols, stride, parts, &j)) return rc;
+  hipLaunchKernelGGL(k_absmax, dim3(kAmaxParts, 1), dim3(256), 0, stream, j, j);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+int spr::launch_absmax2(const float* x0, long rows0, int cols0, long stride0, float* parts0, const float* x1,
+                        long rows1, int cols1, long stride1, float* parts1, hipStream_t stream) {
+  AbsmaxJob j0, j1;
+  if (int rc = make_job(x0, rows0, cols0, stride0, parts0, &j0)) return rc;
+  if (int rc = make_job(x1, rows1, cols1, stride1, parts1, &j1)) return rc;
+  hipLaunchKernelGGL(k_absmax, dim3(kAmaxParts, 2), dim3(256), 0, stream, j0, j1);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -173,6 +203,13 @@ extern "C" int spr_prof_read(int max_records, int* codes, int* nqs, float* ms) {
     ms[n] = t;
     ++n;
   }
+  // the records are consumed: release their events (a long-running caller that enables
+  // profiling once would otherwise leak two events per launch)
+  for (auto& r : g_prof) {
+    (void)hipEventDestroy(r.beg);
+    (void)hipEventDestroy(r.end);
+  }
+  g_prof.clear();
   return n;
 }
 
@@ -181,7 +218,15 @@ extern "C" const char* spr_last_error(void) { return g_err; }
 
 extern "C" int spr_selftest(int* status_host) {
   *status_host = -1;
-  float *dA, *dB, *dD;
+  float *dA = nullptr, *dB = nullptr, *dD = nullptr;
+  struct Free {   // releases the scratch on every return path
+    float **a, **b, **d;
+    ~Free() {
+      if (*a) (void)hipFree(*a);
+      if (*b) (void)hipFree(*b);
+      if (*d) (void)hipFree(*d);
+    }
+  } guard{&dA, &dB, &dD};
   SPR_HIP_CHECK(hipMalloc(&dA, 4096));
   SPR_HIP_CHECK(hipMalloc(&dB, 4096));
   SPR_HIP_CHECK(hipMalloc(&dD, 8192));
@@ -218,9 +263,6 @@ extern "C" int spr_selftest(int* status_host) {
     for (int i = 0; i < 1024; ++i)
       if (D[i] != R[i]) bad |= 2;
   }
-  (void)hipFree(dA);
-  (void)hipFree(dB);
-  (void)hipFree(dD);
   *status_host = bad;
   if (bad) set_error("MFMA layout self test failed (mask %d)", bad);
   return bad ? 1 : 0;

@@ -40,7 +40,11 @@ struct CloudInfo {
   unsigned int nx, ny;
 };
 
-__constant__ unsigned int c_sched[kMaxSched];
+// The bucket schedule travels as a kernel ARGUMENT (160 bytes): no per-device constant
+// upload, no process-wide once-flag -- correct on whichever device the stream belongs to.
+struct SchedArg {
+  unsigned int v[kMaxSched];
+};
 
 // ---- bucket schedule of the platform's libstdc++ ---------------------------
 // Measured, not assumed: drive a real std::unordered_map<size_t,char> and
@@ -287,7 +291,7 @@ __device__ void block_inclusive_scan(int* data, int m, int* lds /*[1024]*/) {
 
 __global__ __launch_bounds__(1024) void k_umap_order(
     const unsigned long long* __restrict__ vkey, const int* __restrict__ ins,
-    const int* __restrict__ vcu, const int* __restrict__ cu, int nsched,
+    const int* __restrict__ vcu, const int* __restrict__ cu, int nsched, SchedArg sched,
     int* listA, int* listB, int* tfirst, int* tcnt, int* thead, int* nxt,
     int* scan, const float* __restrict__ bary, const int* __restrict__ out_cu,
     const int* __restrict__ out_lens, float* out) {
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(1024) void k_umap_order(
   while (done < m) {
     e += 1;
     if (e >= nsched) break;  // cannot happen: schedule covers 4M voxels
-    const int nbk = (int)c_sched[e];
+    const int nbk = (int)sched.v[e];
     const int upto = min(m, nbk);
     const int len = upto;  // arrival sequence length = done + (upto - done)
     for (int b = t; b < nbk; b += T) {
@@ -480,15 +484,9 @@ extern "C" int spr_grid_subsample(const float* xyz, const int* cu, int n, int nb
                        vkey, nvox, vcu, out_cu, out_lens, out_xyz);
   } else {
     const Schedule& s = host_schedule();
-    static std::once_flag sched_once;
-    static hipError_t sched_err = hipSuccess;
-    std::call_once(sched_once, [&] {
-      unsigned int h[kMaxSched];
-      for (int i = 0; i < kMaxSched; ++i)
-        h[i] = i < (int)s.buckets.size() ? s.buckets[i] : 0xffffffffu;
-      sched_err = hipMemcpyToSymbol(HIP_SYMBOL(c_sched), h, sizeof(h));
-    });
-    SPR_HIP_CHECK(sched_err);
+    SchedArg sched;
+    for (int i = 0; i < kMaxSched; ++i)
+      sched.v[i] = i < (int)s.buckets.size() ? s.buckets[i] : 0xffffffffu;
     const int nsched = (int)(s.buckets.size() < (size_t)kMaxSched ? s.buckets.size() : kMaxSched);
     hipLaunchKernelGGL(k_inskeys, dim3(cdiv(n, TB)), dim3(TB), 0, stream, vkey, vfirst,
                        nvox, n, skey, sval);
@@ -496,7 +494,7 @@ extern "C" int spr_grid_subsample(const float* xyz, const int* cu, int n, int nb
     SPR_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, skey, skey2, sval, sval2,
                                             (unsigned int)n, 0, 64, stream));
     hipLaunchKernelGGL(k_umap_order, dim3(nb), dim3(1024), 0, stream, vkey, sval2, vcu, cu,
-                       nsched, listA, listB, tfirst, tcnt, thead, nxt, scan, bary, out_cu,
+                       nsched, sched, listA, listB, tfirst, tcnt, thead, nxt, scan, bary, out_cu,
                        out_lens, out_xyz);
   }
   hipLaunchKernelGGL(k_check_err, dim3(1), dim3(1), 0, stream, err, out_total);

@@ -628,8 +628,7 @@ extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, in
 
   if (impl == 0 && n_kp == kKP && cin % 32 == 0 && cout % 32 == 0 && cout <= 256) {
     const int ktot = n_kp * cin;
-    if (int rc = launch_absmax(x, ns, cin, cin, x_parts, stream)) return rc;
-    if (int rc = launch_absmax(weights, ktot, cout, cout, w_parts, stream)) return rc;
+    if (int rc = launch_absmax2(x, ns, cin, cin, x_parts, weights, ktot, cout, cout, w_parts, stream)) return rc;
     hipLaunchKernelGGL(k_w_prep, dim3(cdiv((long)ktot * cout, 256)), dim3(256), 0, stream, weights, cin, cout,
                        cin % 64 == 0 ? 64 : 32, w_parts, wh, wl);
 #define SPR_KP_ARGS                                                                         \

@@ -554,8 +554,7 @@ extern "C" int spr_linear(const float* x, int m, int k, const float* w, int n, c
     Workspace wk(ws, ws_bytes);
     float* ap = wk.take<float>(kAmaxParts);
     float* wp = wk.take<float>(kAmaxParts);
-    if (int rc = launch_absmax(x, m, k, k, ap, stream)) return rc;
-    if (int rc = launch_absmax(w, n, k, k, wp, stream)) return rc;
+    if (int rc = launch_absmax2(x, m, k, k, ap, w, n, k, k, wp, stream)) return rc;
     a_parts = ap;
     w_parts = wp;
   }

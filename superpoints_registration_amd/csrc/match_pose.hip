@@ -181,9 +181,14 @@ __global__ void k_scale(float* __restrict__ mat, long long total, float s) {
   if (i < total) mat[i] *= s;
 }
 // affinity = -(max(c*scale, 0) - sp_alpha) * inv_den      (qk_regtr_full.py:532-535)
-__global__ void k_affinity(float* __restrict__ mat, long long total, float scale, float sp_alpha,
-                           float inv_den) {
+// alpha, beta: the model's learnable scalars, read from DEVICE memory (no host round trip);
+// softplus with threshold 20 like torch.nn.Softplus, evaluated in float64.
+__global__ void k_affinity(float* __restrict__ mat, long long total, float scale,
+                           const float* __restrict__ alpha_p, const float* __restrict__ beta_p) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const float alpha = alpha_p[0], beta = beta_p[0];
+  const float sp_alpha = (float)(alpha > 20.f ? (double)alpha : log1p(exp((double)alpha)));
+  const float inv_den = (float)(1.0 / (exp((double)beta) + 0.02));
   if (i < total) {
     const float sc = fmaxf(mat[i] * scale, 0.f);
     mat[i] = -(sc - sp_alpha) * inv_den;
@@ -413,7 +418,7 @@ size_t match_ws_bytes(const int* cu_host, int npairs) {
     off = (off + 63) / 64 * 64;
   }
   return align_up((size_t)off * 4, 256) + align_up(sizeof(PairDesc) * npairs, 256) +
-         4 * align_up((size_t)tmax * 4, 256) + align_up(kAmaxParts * sizeof(float), 256) + 1024;
+         4 * align_up((size_t)tmax * 4, 256) + 2 * align_up(kAmaxParts * sizeof(float), 256) + 1024;
 }
 
 }  // namespace
@@ -459,18 +464,22 @@ int correlate(const float* feat, int d, const int* cu_dev, const int* cu_host, i
   hipLaunchKernelGGL(k_build_pairs, dim3(1), dim3(64), 0, stream, cu_dev, npairs, pd);
   *max_n = 0;
   *max_m = 0;
-  // one range measurement of the whole feature tensor serves both operands of every pair
-  const float* parts = nullptr;
+  // two range measurements serve every pair: all src tokens (A operands), all tgt tokens (B)
+  const float *sparts = nullptr, *tparts = nullptr;
   if (gemm_mode() == 1) {
-    float* pp = w.take<float>(kAmaxParts);
-    SPR_REQUIRE(pp != nullptr, "match: workspace carve failed");
-    if (int rc = launch_absmax(feat, cu_host[2 * npairs], d, d, pp, stream)) return rc;
-    parts = pp;
+    float* ps = w.take<float>(kAmaxParts);
+    float* pt = w.take<float>(kAmaxParts);
+    SPR_REQUIRE(pt != nullptr, "match: workspace carve failed");
+    const int nsrc = cu_host[npairs], ntot = cu_host[2 * npairs];
+    if (int rc = launch_absmax(feat, nsrc, d, d, ps, stream)) return rc;
+    if (int rc = launch_absmax(feat + (size_t)nsrc * d, ntot - nsrc, d, d, pt, stream)) return rc;
+    sparts = ps;
+    tparts = pt;
   }
   for (int b = 0; b < npairs; ++b) {
     SPR_REQUIRE(h[b].n > 0 && h[b].m > 0, "match: empty cloud in pair %d", b);
     if (launch_linear_ranged(feat + (size_t)h[b].src_beg * d, h[b].n, d, feat + (size_t)h[b].tgt_beg * d,
-                             h[b].m, nullptr, mat + h[b].off, parts, parts, stream))
+                             h[b].m, nullptr, mat + h[b].off, sparts, tparts, stream))
       return 1;
     *max_n = h[b].n > *max_n ? h[b].n : *max_n;
     *max_m = h[b].m > *max_m ? h[b].m : *max_m;
@@ -513,8 +522,9 @@ extern "C" int spr_match_dualsoftmax(const float* feat, int d, const int* cu, co
 }
 
 extern "C" int spr_sinkhorn_correspondences(const float* feat, int d, const float* xyz, const int* cu,
-                                            const int* cu_host, int npairs, float alpha, float beta,
-                                            int n_iters, int slack, float* out_w, float* out_that,
+                                            const int* cu_host, int npairs, const float* alpha,
+                                            const float* beta, int n_iters, int slack, float* out_w,
+                                            float* out_that,
                                             void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   (void)slack;  // the reference's sinkhorn() always pads the slack row/col (se3_torch.py:182-184)
@@ -532,11 +542,8 @@ extern "C" int spr_sinkhorn_correspondences(const float* feat, int d, const floa
   float* v = w.take<float>(T);
   SPR_REQUIRE(v != nullptr, "sinkhorn: workspace carve failed");
   const float scale = 1.0f / sqrtf((float)d);
-  // softplus(alpha) (threshold 20 like torch.nn.Softplus), exp(beta) + 0.02
-  const double sp = alpha > 20.f ? (double)alpha : log1p(exp((double)alpha));
-  const float inv_den = (float)(1.0 / (exp((double)beta) + 0.02));
-  hipLaunchKernelGGL(k_affinity, dim3(cdiv(total, 256)), dim3(256), 0, stream, mat, total, scale,
-                     (float)sp, inv_den);
+  SPR_REQUIRE(alpha != nullptr && beta != nullptr, "sinkhorn: alpha / beta must be device pointers");
+  hipLaunchKernelGGL(k_affinity, dim3(cdiv(total, 256)), dim3(256), 0, stream, mat, total, scale, alpha, beta);
   SPR_HIP_CHECK(hipMemsetAsync(u, 0, sizeof(float) * T, stream));
   SPR_HIP_CHECK(hipMemsetAsync(v, 0, sizeof(float) * T, stream));
   for (int it = 0; it < n_iters; ++it) {

@@ -96,6 +96,9 @@ int device_cu_count();
 // max |x| over a [rows, cols] view with row stride `stride` (floats) -> parts[kAmaxParts]
 // (device); see block_absmax.  Defined in core.hip.
 int launch_absmax(const float* x, long rows, int cols, long stride, float* parts, hipStream_t stream);
+// two tensors in one launch (an activation and the weights it meets)
+int launch_absmax2(const float* x0, long rows0, int cols0, long stride0, float* parts0, const float* x1,
+                   long rows1, int cols1, long stride1, float* parts1, hipStream_t stream);
 
 // ---- device helpers --------------------------------------------------------
 #ifdef __HIPCC__

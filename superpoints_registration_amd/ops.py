@@ -304,10 +304,20 @@ def match_dualsoftmax(feat, cu, cu_host: Sequence[int], npairs: int):
     return val, ind
 
 
-def sinkhorn_correspondences(feat, xyz, cu, cu_host: Sequence[int], npairs: int, alpha: float,
-                             beta: float, n_iters: int, slack: bool = True):
-    """a13.  Returns (w [Tsrc] f32, t_hat [Tsrc,3] f32) for the src tokens."""
+def _dev_scalar(v, device) -> torch.Tensor:
+    """A 0-d / 1-element float32 device tensor for a learnable scalar (device tensors are
+    passed through without a host read; Python numbers are uploaded)."""
+    if isinstance(v, torch.Tensor):
+        return v.detach().to(device=device, dtype=torch.float32).reshape(1).contiguous()
+    return torch.tensor([float(v)], dtype=torch.float32, device=device)
+
+
+def sinkhorn_correspondences(feat, xyz, cu, cu_host: Sequence[int], npairs: int, alpha,
+                             beta, n_iters: int, slack: bool = True):
+    """a13.  Returns (w [Tsrc] f32, t_hat [Tsrc,3] f32) for the src tokens.  alpha / beta:
+    device tensors (the model's parameters -- read on the device, no sync) or floats."""
     feat = _dev(feat, "feat", torch.float32)
+    alpha_t, beta_t = _dev_scalar(alpha, feat.device), _dev_scalar(beta, feat.device)
     xyz = _dev(xyz, "xyz", torch.float32)
     cu = _dev(cu, "cu", torch.int32)
     T, d = feat.shape
@@ -318,7 +328,7 @@ def sinkhorn_correspondences(feat, xyz, cu, cu_host: Sequence[int], npairs: int,
     w = torch.empty((tsrc,), dtype=torch.float32, device=feat.device)
     that = torch.empty((tsrc, 3), dtype=torch.float32, device=feat.device)
     _lib.check(L.spr_sinkhorn_correspondences(_ptr(feat), d, _ptr(xyz), _ptr(cu), arr, npairs,
-                                              float(alpha), float(beta), int(n_iters), int(bool(slack)),
+                                              _ptr(alpha_t), _ptr(beta_t), int(n_iters), int(bool(slack)),
                                               _ptr(w), _ptr(that), _ptr(ws), ws.numel(), _stream(feat)),
                "spr_sinkhorn_correspondences")
     return w, that

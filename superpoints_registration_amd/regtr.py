@@ -105,7 +105,7 @@ class RegTR(nn.Module):
         src_xyz_all, tgt_xyz_all = xyz_c[:n_src], xyz_c[n_src:]
         if cfg.use_sinkhorn:
             w, t_hat = ops.sinkhorn_correspondences(cond, xyz_c, cu, cu_host, B,
-                                                    float(self.alpha), float(self.beta),
+                                                    self.alpha, self.beta,   # device scalars, no sync
                                                     int(cfg.sinkhorn_itr), bool(cfg.slack))
             pose = ops.weighted_procrustes(src_xyz_all, t_hat, w, cu[:B + 1].contiguous())
         else:
@@ -187,8 +187,11 @@ class RegTR(nn.Module):
 
         W = self.feature_criterion.W.detach()
         feat, t_l1 = [], []
+        # the reference overwrites `feature_loss` for every entry of feature_loss_on
+        # (qk_regtr_full.py:340-345): only the LAST index contributes
+        last = list(cfg.get('feature_loss_on', [0]))[-1:]
         for b in range(B):
-            for i in cfg.get('feature_loss_on', [0]):
+            for i in last:
                 feat.append(ops.infonce_pair(pred['src_feat'][b][i].contiguous(), pred['tgt_feat'][b][i].contiguous(),
                                              pred['src_kp'][b].contiguous(), pose_gt[b], pred['tgt_kp'][b].contiguous(),
                                              W, cfg.r_p, cfg.r_n))

@@ -187,6 +187,22 @@ def test_transformer_layer_packed_vs_reference(gold, inp, device):
     _close(y[ns:], gold["tl.tgt_out"], 2e-5, "layer tgt")
 
 
+@pytest.mark.parametrize("tag,pre,pe", [("post", False, True), ("post_nope", False, False), ("pre_nope", True, False)])
+def test_transformer_layer_post_norm_and_value_without_pos(inp, device, tag, pre, pe):
+    """Post-norm branch (transformers.py:122-182) and values without positional embedding."""
+    gold = load_golden("ops_extra.npz")
+    layer = TransformerCrossEncoderLayer(256, 8, 1024, 0.0, 'relu', pre, pe, pe, 'dot_prod')
+    synthetic.fill_parameters(layer, seed=21)
+    layer = layer.to(device)
+    x = torch.cat(inp["tl.src"] + inp["tl.tgt"]).to(device)
+    pos = torch.cat(inp["tl.src_pe"] + inp["tl.tgt_pe"]).to(device)
+    cu, s_self, s_cross, mx = make_segments(inp["tl.s_l"], inp["tl.t_l"], device)
+    y = layer.forward_packed(x, cu, s_self, s_cross, mx, pos=pos).cpu().numpy()
+    ns = sum(inp["tl.s_l"])
+    _close(y[:ns], gold[f"tl.{tag}.src_out"], 2e-5, f"layer {tag} src")
+    _close(y[ns:], gold[f"tl.{tag}.tgt_out"], 2e-5, f"layer {tag} tgt")
+
+
 def test_transformer_reference_signature_padded(gold, inp, device):
     enc = TransformerCrossEncoder(_layer(device), 1, None).to(device)
     synthetic.fill_parameters(enc.layers[0], seed=21)

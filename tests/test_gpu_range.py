@@ -170,23 +170,22 @@ def test_kpconv_phase2_every_magnitude(device, tag, mx, mw):
     assert err <= 1e-5 * scale, f"kpconv {tag} |x|~{mx:g} |w|~{mw:g}: {err:.3e} vs scale {scale:.3e}"
 
 
-def test_correlation_gemm_small_features(device):
-    """Matching head on features of magnitude 1e-3: the dual-softmax arg-max and the
-    Sinkhorn weights go through the range-scaled correlation GEMM."""
-    inp = ops_inputs()
-    fs, ft = inp["sk.fs"] * 1e-3, inp["sk.ft"] * 1e-3
+@pytest.mark.parametrize("ms,mt", [(1e-3, 1e3), (1e2, 1e-2), (1.0, 1.0)])
+def test_correlation_gemm_unbalanced_features(device, ms, mt):
+    """Matching head with src features scaled by ms and tgt features by mt = 1/ms: the
+    correlation -- hence the reference's dual-softmax arg-max, values and Sinkhorn weights
+    (goldens) -- is unchanged, but the two GEMM operands now sit decades apart."""
+    gold, inp = load_golden("ops.npz"), ops_inputs()
+    fs, ft = inp["sk.fs"] * ms, inp["sk.ft"] * mt
     feat = torch.cat([fs, ft]).to(device)
-    cu_host = [0, fs.shape[0], fs.shape[0] + ft.shape[0]]
+    xyz = torch.cat([inp["sk.xs"], inp["sk.xt"]]).to(device)
+    cu_host = [0, 60, 107]
     cu = torch.tensor(cu_host, dtype=torch.int32, device=device)
-    val, ind = ops.match_dualsoftmax(feat, cu, cu_host, 1)
-    corr = fs.double() @ ft.double().t() / 16.0
-    a = torch.softmax(corr, 0) * torch.softmax(corr, 1)
-    n, m = corr.shape
-    rv, ri = (a.max(0) if n > m else a.max(1))
-    got_v = val.cpu()[n:] if n > m else val.cpu()[:n]
-    got_i = ind.cpu()[n:] if n > m else ind.cpu()[:n]
-    assert torch.equal(got_i.long(), ri)
-    assert float((got_v.double() - rv).abs().max()) <= 1e-5 * float(rv.max())
+    val, ind = ops.match_dualsoftmax(feat, cu, cu_host, 1)          # N=60 > M=47: lives on tgt tokens
+    assert np.array_equal(ind.cpu().numpy()[60:], gold["ds.ind_nm"])
+    assert np.abs(val.cpu().numpy()[60:] - gold["ds.val_nm"]).max() <= 1e-5 * np.abs(gold["ds.val_nm"]).max()
+    w, that = ops.sinkhorn_correspondences(feat, xyz, cu, cu_host, 1, inp["sk.alpha"], inp["sk.beta"], 3)
+    assert np.abs(w.cpu().numpy() - gold["sk.w"]).max() <= 1e-5 * np.abs(gold["sk.w"]).max()
 
 
 def test_end_to_end_with_small_weights(device):
@@ -207,7 +206,7 @@ def test_end_to_end_with_small_weights(device):
     err = float(np.linalg.norm(out["pose"][0].cpu().numpy() - ref["pose"][0].numpy()))
     assert err < 1e-4, f"pose error with 0.01x weights: {err:.3e}"
     sf = out["src_feat"][0][0].cpu().numpy()
-    rf = ref["src_feat"][0].numpy().reshape(sf.shape)
+    rf = ref["cond"][0][0].numpy().reshape(sf.shape)
     assert np.abs(sf - rf).max() <= 1e-4 * max(np.abs(rf).max(), 1e-30)
 
 

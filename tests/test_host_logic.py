@@ -88,3 +88,25 @@ def test_synthetic_pairs_are_reproducible():
     b = synthetic.make_pair(256, seed=9)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     assert a[0].dtype == np.float32 and a[0].shape == (256, 3)
+
+
+def test_load_kernels_reproduces_the_reference_kernel_points():
+    """a14: with the reference's RNG protocol (np.random.seed, one rand() for the z rotation,
+    one normal(size=(15,3)) for the noise -- kernel_points.py:435-461) load_kernels returns the
+    very kernel points the reference's KPConv constructor produced (goldens kp.*.kpts were
+    captured from blocks.KPConv(...) after np.random.seed(5), radius 0.125)."""
+    import numpy as np
+    from conftest import load_golden
+    from superpoints_registration_amd.kernel_points import load_kernels
+    gold = load_golden("ops.npz")
+    for tag in ("c1", "c32", "c64", "c128", "c48"):
+        np.random.seed(5)
+        kp = load_kernels(0.125, 15, dimension=3, fixed="center")
+        assert kp.dtype == np.float32 and kp.shape == (15, 3)
+        assert np.array_equal(kp.view(np.uint32), gold[f"kp.{tag}.kpts"].view(np.uint32)), tag
+    # the KPConv module draws them the same way (frozen parameter, kpconv_blocks.py:244-266)
+    from superpoints_registration_amd.kpconv_blocks import KPConv
+    np.random.seed(5)
+    conv = KPConv(15, 3, 32, 32, 0.1, 0.125)
+    assert np.array_equal(conv.kernel_points.detach().numpy().view(np.uint32), gold["kp.c32.kpts"].view(np.uint32))
+    assert not conv.kernel_points.requires_grad

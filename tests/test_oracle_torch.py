@@ -70,6 +70,34 @@ def test_transformer_layer(gold, inp):
     assert torch.allclose(torch.cat(to), ref_t, rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("tag,pre,pe", [("post", False, True), ("post_nope", False, False), ("pre_nope", True, False)])
+def test_transformer_layer_post_norm_and_value_without_pos(inp, tag, pre, pe):
+    """Post-norm branch (transformers.py:122-182) and sa/ca_val_has_pos_emb=False, which no
+    shipped config selects but the operator API exposes: oracle vs reference goldens."""
+    gold = load_golden("ops_extra.npz")
+
+    class Shell(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.self_attn = torch.nn.MultiheadAttention(256, 8)
+            self.multihead_attn = torch.nn.MultiheadAttention(256, 8)
+            self.linear1, self.linear2 = torch.nn.Linear(256, 1024), torch.nn.Linear(1024, 256)
+            self.norm1, self.norm2, self.norm3 = (torch.nn.LayerNorm(256), torch.nn.LayerNorm(256),
+                                                  torch.nn.LayerNorm(256))
+    sh = Shell()
+    synthetic.fill_parameters(sh, seed=21)
+    sd = dict(sh.state_dict())
+    fn = O.layer_pre if pre else O.layer_post
+    so, to = [], []
+    for b in range(2):
+        s, t = fn(sd, "", inp["tl.src"][b], inp["tl.tgt"][b], inp["tl.src_pe"][b], inp["tl.tgt_pe"][b],
+                  8, pe, pe)
+        so.append(s)
+        to.append(t)
+    assert torch.allclose(torch.cat(so), T(gold[f"tl.{tag}.src_out"]), rtol=1e-4, atol=2e-5)
+    assert torch.allclose(torch.cat(to), T(gold[f"tl.{tag}.tgt_out"]), rtol=1e-4, atol=2e-5)
+
+
 def test_rigid_transform(gold, inp):
     for k in range(3):
         Tw = O.compute_rigid_transform(inp["rt.a"][k], inp["rt.b"][k], inp["rt.w"][k])
