@@ -104,3 +104,20 @@ def test_oracle_vs_compiled_reference_live():
         rb, _ = native.radius_neighbors(pts, pts, lens, lens, 2.5 * dl)
         s_ext = np.concatenate([pts, np.full((1, 3), 1e6, np.float32)])
         assert np.array_equal(canon_ties(ra, pts, s_ext)[0], canon_ties(rb, pts, s_ext)[0])
+
+
+@pytest.mark.parametrize("case", ["ragged", "lattice", "tiny", "dense"])
+@pytest.mark.parametrize("limit", [8, 20, 40, 119])
+def test_oracle_rows_equal_reference_up_to_ties_incl_truncation(case, limit):
+    """Strict neighbour contract (conftest.assert_rows_equal_up_to_ties) of the C restatement
+    against the reference's own output, also when `limit` cuts through equal-d2 runs."""
+    import numpy as np
+    from conftest import assert_rows_equal_up_to_ties, load_golden
+    from oracle import native
+    g = load_golden("preprocess.npz")
+    pts, lens, r = g[f"{case}.pts"], g[f"{case}.lens"], float(g[f"{case}.radius"])
+    ref = g[f"{case}.nb"].astype(np.int64)
+    s_ext = np.concatenate([pts, np.full((1, 3), 1e6, np.float32)])
+    orc, _ = native.radius_neighbors(pts, pts, lens, lens, r, limit=limit)
+    w = min(limit, ref.shape[1])
+    assert_rows_equal_up_to_ties(ref[:, :w], orc, pts, s_ext, truncated=w < ref.shape[1])
