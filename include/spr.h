@@ -294,6 +294,93 @@ int spr_transform_l1_pair(const float* pose_gt, const float* pose_pred,
 int spr_sum_scaled(const float* values, int n, float scale, float* out,
                    void* stream);
 
+/* ==== backward ===============================================
+ * The reference trains through the path with torch autograd
+ * (models/generic_reg_model.py:82-84 training_step -> trainer.py:107-124
+ * backward / clip / step).  These entry points are the explicit gradients of the
+ * operators above; autograd.py wires them into torch.autograd.Function objects.
+ *
+ * spr_bgemm: batched strided exact-f32 GEMM, the matrix-product workhorse
+ *   C_b(i,j) = alpha * sum_k A_b(i,k) B_b(k,j) + beta * C_b(i,j),
+ *   X_b(p,q) = X[x_off_b + p * sx_p + q * sx_q]; desc: device array of nbatch records
+ *   {int64 a_off, b_off, c_off; int32 m, n, k, pad} (element offsets / sizes per batch).
+ *   Gives dX = dY W, dW = dY^T X (nn.Linear), the KPConv weight / feature gradients
+ *   and every product of the attention backward.
+ * spr_reduce_parts: out[j] (+)= scale * sum_p parts[p][j] in fixed order (deterministic split-K).
+ * spr_act_bwd: dy * act'(y) for SPR_ACT_RELU / SPR_ACT_SIGMOID.   spr_colsum: bias gradients.
+ * spr_layernorm_bwd / spr_instnorm_bwd / spr_maxpool_bwd / spr_scatter_rows_add: gradients of
+ *   spr_layernorm (both outputs), spr_instnorm (incl. fused add + LeakyReLU), spr_maxpool_gather,
+ *   spr_gather_rows.
+ * spr_kpconv_weighted_features: recomputes wf[n,p,c] = sum_k infl[n,p,k] x[idx[n,k],c]
+ *   (kpconv_blocks.py:394) and the neighbour count (:409-411); spr_kpconv_bwd_dx scatters
+ *   d wf back to d x.  Together with two spr_bgemm calls = KPConv backward.
+ * spr_softmax_rows / spr_softmax_bwd_rows: row softmax of per-batch matrices (located by
+ *   c_off, m rows, n columns of the same descriptor records) and its backward -- the
+ *   non-GEMM steps of the attention backward.
+ */
+int spr_bgemm(const float* A, const float* B, float* C, const void* desc_dev, int nbatch,
+              int max_m, int max_n, long sa_i, long sa_k, long sb_k, long sb_j, long sc_i,
+              long sc_j, float alpha, float beta, void* stream);
+int spr_reduce_parts(const float* parts, int nparts, long n, float scale, float* out,
+                     int accumulate, void* stream);
+int spr_act_bwd(const float* y, const float* dy, int act, long n, float* out, void* stream);
+size_t spr_colsum_workspace_bytes(int n);
+int spr_colsum(const float* x, long m, int n, float* out, void* ws, size_t ws_bytes, void* stream);
+size_t spr_layernorm_bwd_workspace_bytes(int c);
+int spr_layernorm_bwd(const float* x, int m, int c, const float* gamma, float eps,
+                      const float* dy_norm, const float* dy_pos, float* dx, float* dgamma,
+                      float* dbeta, void* ws, size_t ws_bytes, void* stream);
+size_t spr_instnorm_bwd_workspace_bytes(int max_len_host, int nb, int c);
+int spr_instnorm_bwd(const float* x, const float* out, const float* dout, const int* cu, int n,
+                     int nb, int max_len_host, int c, float eps, int norm, float slope,
+                     float* dx, float* dadd, void* ws, size_t ws_bytes, void* stream);
+int spr_maxpool_bwd(const float* x, int ns, int c, const int* idx, int nq, int idx_stride, int k,
+                    const float* dy, float* dx, void* stream);
+int spr_scatter_rows_add(const float* dy, const int* idx, int n, int c, int n_src, float* dx,
+                         void* stream);
+int spr_kpconv_weighted_features(const float* q_xyz, int nq, const float* s_xyz, int ns,
+                                 const int* nbr, int nbr_stride, int kmax, const float* x, int cin,
+                                 const float* kernel_points, int n_kp, float kp_extent,
+                                 float* wf, float* cnt, void* stream);
+int spr_kpconv_bwd_dx(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
+                      int nbr_stride, int kmax, int cin, const float* kernel_points, int n_kp,
+                      float kp_extent, const float* dwf, float* dx, void* stream);
+int spr_softmax_rows(float* mat, const void* desc_dev, int nbatch, int max_m, void* stream);
+int spr_softmax_bwd_rows(const float* p, float* dp, const void* desc_dev, int nbatch, int max_m,
+                         void* stream);
+
+/* Loss and pose-head gradients.
+ * spr_bce_logits_mean_bwd: dx = gout[0] (sigmoid(x) - y) / n.
+ * spr_infonce_pair_dlogits: recomputes the pair's logits and writes the un-normalised
+ *   d logits [n, m] + row mask [n] (divide by sum(mask)); also returns W_sym [d, d] and
+ *   t = A W_sym [n, d] for the caller's GEMM chain; spr_wsym_bwd maps d W_sym to d W.
+ * spr_transform_l1_pair_bwd: d pose_pred [3,4] of spr_transform_l1_pair.
+ * spr_weighted_procrustes_bwd: gradient of the Kabsch solve w.r.t. b, w (and a if da != NULL)
+ *   by implicit differentiation of the SVD-based rotation (se3_torch.py:141-162; the reference
+ *   uses torch.svd's autograd).  da / db / dw packed like a / b / w.
+ * spr_sinkhorn_bwd: gradient of spr_sinkhorn_correspondences w.r.t. feat, alpha, beta
+ *   (unrolled over the n_iters slack-Sinkhorn iterations; se3_torch.py:166-239,
+ *   qk_regtr_full.py:525-536).
+ */
+int spr_bce_logits_mean_bwd(const float* x, const float* y, int n, const float* gout, float* dx,
+                            void* stream);
+int spr_infonce_pair_dlogits(const float* anchor_feat, int n, const float* positive_feat, int m,
+                             int d, const float* anchor_xyz, const float* pose_gt,
+                             const float* positive_xyz, const float* W, float r_p, float r_n,
+                             float* dlogits, float* row_mask, float* wsym_out, float* t_out,
+                             void* ws, size_t ws_bytes, void* stream);
+int spr_wsym_bwd(const float* dwsym, int d, float* dW, void* stream);
+int spr_transform_l1_pair_bwd(const float* pose_gt, const float* pose_pred, const float* xyz, int n,
+                              const float* gout, float* dpose_pred, void* stream);
+int spr_weighted_procrustes_bwd(const float* a, const float* b, const float* w,
+                                const int* pair_cu, int npairs, const float* dpose, float* da,
+                                float* db, float* dw, void* stream);
+size_t spr_sinkhorn_bwd_workspace_bytes(const int* cu_host, int npairs, int n_iters);
+int spr_sinkhorn_bwd(const float* feat, int d, const float* xyz, const int* cu,
+                     const int* cu_host, int npairs, const float* alpha, const float* beta,
+                     int n_iters, const float* dw, const float* dthat, float* dfeat,
+                     float* dalpha, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+
 /* Per-launch timing of the fused KPConv kernel and of the attention core kernel
  * with HIP events recorded on the launch stream (used by bench.py for the
  * roofline figures; off by default).

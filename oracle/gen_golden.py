@@ -292,6 +292,52 @@ def gen_loss(cfg_tag, B=2):
     print(os.path.basename(path), {k: float(v) for k, v in losses.items()})
 
 
+def grad_sample_indices(name, numel, k=64):
+    """The fixed pseudo-random positions at which a large gradient tensor is pinned (shared by
+    the generator and the tests; seeded by the parameter name)."""
+    rng = np.random.default_rng(synthetic._seed_of(name, 123) % (2 ** 32))
+    return rng.integers(0, numel, size=min(k, numel))
+
+
+def gen_grad(cfg_tag, B=2):
+    """Reference training step (generic_reg_model.py:82-84): forward + compute_loss, then
+    .backward() of (a) the total loss and (b) 0.1 * feature + overlap alone (the part that does
+    not pass through the pose head).  Stored per parameter: gradient norm, sum, 64 sampled
+    entries, and the whole tensor when it has <= 4096 elements."""
+    model, cfg = ref_harness.make_model(f'qk_regtr_full_{cfg_tag}.yaml', seed=0)
+    synthetic.fill_parameters(model, seed=0)
+    model.train()
+    pairs, sizes = pairs_for(cfg_tag, B)
+    src = [p[0][:n] for p, (n, m) in zip(pairs, sizes)]
+    tgt = [p[1][:m] for p, (n, m) in zip(pairs, sizes)]
+    pose, src_ov, tgt_ov = loss_inputs(cfg_tag, B)
+    batch = {'src_xyz': [torch.from_numpy(s) for s in src], 'tgt_xyz': [torch.from_numpy(t) for t in tgt],
+             'pose': torch.from_numpy(pose),
+             'src_overlap': [torch.from_numpy(o) for o in src_ov],
+             'tgt_overlap': [torch.from_numpy(o) for o in tgt_ov]}
+    out = model(batch)
+    losses = model.compute_loss(out, batch)
+    fx = {'B': np.int32(B), 'seed': np.int32(0)}
+    for k, v in losses.items():
+        fx[f'loss_{k}'] = np.float64(float(v))
+    for tag, loss in (('fo', 0.1 * losses['feature'] + losses['overlap']), ('total', losses['total'])):
+        model.zero_grad(set_to_none=True)
+        loss.backward(retain_graph=True)
+        for name, p in model.named_parameters():
+            if p.grad is None:
+                fx[f'{tag}|{name}|none'] = np.int32(1)
+                continue
+            g = p.grad.detach().double().reshape(-1).numpy()
+            fx[f'{tag}|{name}|norm'] = np.float64(np.linalg.norm(g))
+            fx[f'{tag}|{name}|sum'] = np.float64(g.sum())
+            fx[f'{tag}|{name}|samples'] = g[grad_sample_indices(name, g.size)].astype(np.float32)
+            if g.size <= 4096:
+                fx[f'{tag}|{name}|full'] = g.astype(np.float32)
+    path = os.path.join(OUT, f'grad_{cfg_tag}_b{B}.npz')
+    np.savez_compressed(path, **fx)
+    print(os.path.basename(path), os.path.getsize(path) // 1024, 'KB', {k: float(v) for k, v in losses.items()})
+
+
 def main():
     assert ref_harness.available(), "needs /root/reference (dev container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -310,6 +356,9 @@ def main():
         for tag in ('3dmatch', 'kitti', 'modelnet'):
             if f'loss_{tag}' in what or 'loss' in what:
                 gen_loss(tag, 2)
+        for tag in ('3dmatch', 'kitti', 'modelnet'):
+            if f'grad_{tag}' in what or 'grad' in what:
+                gen_grad(tag, 2)
     finally:
         os.chdir(cwd)
 

@@ -11,6 +11,7 @@ qkv = torch.randn(T, 768, generator=g).to(dev)
 cu = (torch.arange(0, nseg + 1, dtype=torch.int32) * L).to(dev)
 kv = (torch.arange(nseg, dtype=torch.int32) ^ 1).to(dev)
 out = torch.empty(T, 256, device=dev)
+ops.set_attn_mode(int(os.environ.get('SPR_ATTN_MODE', '1')))
 q, k, v = qkv[:, :256], qkv[:, 256:512], qkv[:, 512:]
 for _ in range(3):
     ops.attention(q, k, v, cu, kv, L, nhead, out=out)
@@ -20,4 +21,4 @@ e0.record()
 for _ in range(10):
     ops.attention(q, k, v, cu, kv, L, nhead, out=out)
 e1.record(); torch.cuda.synchronize()
-print('ABL', os.environ.get('SPR_ATTN_ABL', '0'), 'us/call %.1f' % (e0.elapsed_time(e1) * 100))
+print('mode', os.environ.get('SPR_ATTN_MODE', '1'), 'us/call (range pre-pass + pack + core) %.1f' % (e0.elapsed_time(e1) * 100))

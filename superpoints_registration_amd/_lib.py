@@ -9,12 +9,14 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspr_hip.so")
+# SPR_HIP_LIB: experiment builds only (scripts/abl: ablation variants of single kernels)
+LIB_PATH = os.environ.get("SPR_HIP_LIB") or os.path.join(_HERE, "libspr_hip.so")
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
 _f = ctypes.c_float
 _sz = ctypes.c_size_t
+_l = ctypes.c_long
 
 # name -> (restype, argtypes); mirrors include/spr.h exactly
 SIGNATURES = {
@@ -55,6 +57,29 @@ SIGNATURES = {
     "spr_transform_l1_pair": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "spr_sum_scaled": (_i, [_vp, _i, _f, _vp, _vp]),
     "spr_gather_rows": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
+    "spr_bgemm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _l, _l, _l, _f, _f, _vp]),
+    "spr_reduce_parts": (_i, [_vp, _i, _l, _f, _vp, _i, _vp]),
+    "spr_act_bwd": (_i, [_vp, _vp, _i, _l, _vp, _vp]),
+    "spr_colsum_workspace_bytes": (_sz, [_i]),
+    "spr_colsum": (_i, [_vp, _l, _i, _vp, _vp, _sz, _vp]),
+    "spr_layernorm_bwd_workspace_bytes": (_sz, [_i]),
+    "spr_layernorm_bwd": (_i, [_vp, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "spr_instnorm_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "spr_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "spr_maxpool_bwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "spr_scatter_rows_add": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "spr_kpconv_weighted_features": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp]),
+    "spr_kpconv_bwd_dx": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp]),
+    "spr_softmax_rows": (_i, [_vp, _vp, _i, _i, _vp]),
+    "spr_softmax_bwd_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "spr_bce_logits_mean_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "spr_infonce_pair_dlogits": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz,
+                                      _vp]),
+    "spr_wsym_bwd": (_i, [_vp, _i, _vp, _vp]),
+    "spr_transform_l1_pair_bwd": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "spr_weighted_procrustes_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "spr_sinkhorn_bwd_workspace_bytes": (_sz, [_vp, _i, _i]),
+    "spr_sinkhorn_bwd": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "spr_selftest": (_i, [_vp]),
     "spr_prof_enable": (_i, [_i]),
     "spr_prof_read": (_i, [_i, _vp, _vp, _vp]),

@@ -1,0 +1,360 @@
+// Backward kernels of the hot path that are not matrix products (those go
+// through bgemm.hip) -- SURVEY 8f row 1.  In the reference every one of these
+// gradients is produced by torch autograd from the forward expressions cited
+// at each kernel; here they are explicit HIP kernels behind the C ABI and the
+// Python side wires them into torch.autograd.Function objects (autograd.py).
+//
+// Scatter-type gradients (max-pool, KPConv dX) accumulate with float atomics;
+// reductions over rows (LayerNorm dgamma / dbeta, bias gradients) are
+// deterministic two-stage sums.
+#include "spr_common.h"
+
+namespace spr {
+namespace {
+
+// dy' = dy * act'(y): ReLU (y > 0), sigmoid (y (1 - y)); transformers.py:236, qk_regtr_full.py:249
+__global__ void k_act_bwd(const float* __restrict__ y, const float* __restrict__ dy, int act, long n,
+                          float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = y[i];
+  out[i] = act == SPR_ACT_RELU ? (v > 0.f ? dy[i] : 0.f) : act == SPR_ACT_SIGMOID ? dy[i] * v * (1.f - v) : dy[i];
+}
+
+// column sums of x [m, n] over a fixed number of row chunks: parts [nchunk][n]
+constexpr int kColChunks = 128;
+__global__ __launch_bounds__(256) void k_colsum_parts(const float* __restrict__ x, long m, int n,
+                                                      float* __restrict__ parts) {
+  const int chunk = blockIdx.y;
+  const long rows_per = (m + kColChunks - 1) / kColChunks;
+  const long r0 = chunk * rows_per, r1 = r0 + rows_per < m ? r0 + rows_per : m;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float s = 0.f;
+  for (long r = r0; r < r1; ++r) s += x[r * n + j];
+  parts[(long)chunk * n + j] = s;
+}
+
+// ---- LayerNorm backward (transformers.py:121,:196-197: y = LN(x) gamma + beta; optional second
+// output y + pos).  One wave per row; per-block partial sums of dgamma / dbeta over the block's rows.
+constexpr int kLnBlocks = 256;
+template <int MAXV>
+__global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__ x, int m, int c,
+                                                       const float* __restrict__ gamma, float eps,
+                                                       const float* __restrict__ dy_a,
+                                                       const float* __restrict__ dy_b, float* __restrict__ dx,
+                                                       float* __restrict__ dg_parts, float* __restrict__ db_parts) {
+  __shared__ float sg[4][64 * MAXV], sb[4][64 * MAXV];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nv = c >> 6;
+  float ag[MAXV], ab[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) ag[i] = ab[i] = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < m; row += kLnBlocks * 4) {
+    float v[MAXV], g[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const bool ok = i < nv;
+      const size_t o = (size_t)row * c + i * 64 + lane;
+      v[i] = ok ? x[o] : 0.f;
+      g[i] = ok ? (dy_a ? dy_a[o] : 0.f) + (dy_b ? dy_b[o] : 0.f) : 0.f;
+      s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)c;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const float d = i < nv ? v[i] - mean : 0.f;
+      ss += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)c + eps);
+    float s1 = 0.f, s2 = 0.f;
+    float xh[MAXV], dxh[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const bool ok = i < nv;
+      xh[i] = ok ? (v[i] - mean) * rstd : 0.f;
+      dxh[i] = ok ? g[i] * gamma[i * 64 + lane] : 0.f;
+      s1 += dxh[i];
+      s2 += dxh[i] * xh[i];
+      ag[i] += g[i] * xh[i];
+      ab[i] += g[i];
+    }
+    s1 = wave_sum(s1) / (float)c;
+    s2 = wave_sum(s2) / (float)c;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+      if (i < nv) dx[(size_t)row * c + i * 64 + lane] = rstd * (dxh[i] - s1 - xh[i] * s2);
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    sg[wave][i * 64 + lane] = ag[i];
+    sb[wave][i * 64 + lane] = ab[i];
+  }
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    dg_parts[(size_t)blockIdx.x * c + ch] = sg[0][ch] + sg[1][ch] + sg[2][ch] + sg[3][ch];
+    db_parts[(size_t)blockIdx.x * c + ch] = sb[0][ch] + sb[1][ch] + sb[2][ch] + sb[3][ch];
+  }
+}
+
+// ---- max-pool backward (kpconv_blocks.py:127-143): dy goes to the arg-max source row of every
+// (query, channel); the shadow row (index ns) receives nothing.  First maximum wins, like
+// torch.max's index on ties.
+__global__ void k_maxpool_bwd(const float* __restrict__ x, int ns, int c, const int* __restrict__ idx, int nq,
+                              int idx_stride, int k, const float* __restrict__ dy, float* __restrict__ dx) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)nq * c) return;
+  const int row = (int)(gid / c), ch = (int)(gid % c);
+  const int* ir = idx + (size_t)row * idx_stride;
+  float best = -3.0e38f;
+  int bi = -1;
+  for (int j = 0; j < k; ++j) {
+    const int id = ir[j];
+    const bool ok = id >= 0 && id < ns;
+    const float v = ok ? x[(size_t)id * c + ch] : 0.f;
+    if (v > best) {
+      best = v;
+      bi = ok ? id : -1;
+    }
+  }
+  if (bi >= 0) atomicAdd(dx + (size_t)bi * c + ch, dy[gid]);
+}
+
+// rows gathered forward (spr_gather_rows) -> scatter-add backward
+__global__ void k_scatter_rows_add(const float* __restrict__ dy, const int* __restrict__ idx, int n, int c,
+                                   int n_src, float* __restrict__ dx) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)n * c) return;
+  const int row = (int)(gid / c), ch = (int)(gid % c);
+  const int id = idx[row];
+  if (id >= 0 && id < n_src) atomicAdd(dx + (size_t)id * c + ch, dy[gid]);
+}
+
+// ---- KPConv backward helpers (kpconv_blocks.py:309-412) --------------------------------------
+// One wave per query.  Per neighbour the 15 influence weights are computed by lanes 0..14 and
+// broadcast through LDS; lanes then walk the channels.
+//   WF mode : wf[n, p * cin + c] = sum_k infl[p][k] x[idx[n,k], c]     (recomputed forward, un-normalised)
+//             cnt[n] = max(1, #{k : sum_c x[idx[n,k], :] > 0})          (flag from k_rowflag-like pass)
+//   DX mode : dx[idx[n,k], c] += sum_p infl[p][k] dwf[n, p * cin + c]
+constexpr int kKPmax = 16;
+template <bool DX>
+__global__ __launch_bounds__(256) void k_kpconv_aux(const float* __restrict__ q_xyz, int nq,
+                                                    const float* __restrict__ s_xyz, int ns,
+                                                    const int* __restrict__ nbr, int nbr_stride, int kmax,
+                                                    const float* __restrict__ x, int cin,
+                                                    const float* __restrict__ kpts, int n_kp, float inv_extent,
+                                                    const float* __restrict__ dwf, float* __restrict__ wf,
+                                                    float* __restrict__ cnt_out, float* __restrict__ dx) {
+  __shared__ float infl[4][kKPmax];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= nq) return;   // whole wave
+  const float qx = q_xyz[3 * (size_t)n], qy = q_xyz[3 * (size_t)n + 1], qz = q_xyz[3 * (size_t)n + 2];
+  float kx = 0.f, ky = 0.f, kz = 0.f;
+  if (lane < n_kp) {
+    kx = kpts[3 * lane];
+    ky = kpts[3 * lane + 1];
+    kz = kpts[3 * lane + 2];
+  }
+  const int nchunk = (cin + 63) / 64;
+  int cnt = 0;
+  for (int c0 = 0; c0 < nchunk; ++c0) {
+    const int c = c0 * 64 + lane;
+    const bool cok = c < cin;
+    float acc[kKPmax];
+#pragma unroll
+    for (int p = 0; p < kKPmax; ++p) acc[p] = 0.f;
+    float dw[kKPmax];
+    if (DX) {
+#pragma unroll
+      for (int p = 0; p < kKPmax; ++p) dw[p] = (cok && p < n_kp) ? dwf[((size_t)n * n_kp + p) * cin + c] : 0.f;
+    }
+    for (int k = 0; k < kmax; ++k) {
+      const int id = nbr[(size_t)n * nbr_stride + k];
+      const bool ok = id >= 0 && id < ns;
+      if (!ok) continue;   // wave uniform
+      if (lane < n_kp) {
+        const float dx_ = (s_xyz[3 * (size_t)id] - qx) - kx, dy_ = (s_xyz[3 * (size_t)id + 1] - qy) - ky,
+                    dz_ = (s_xyz[3 * (size_t)id + 2] - qz) - kz;
+        infl[wave][lane] = fmaxf(0.f, 1.f - sqrtf(dx_ * dx_ + dy_ * dy_ + dz_ * dz_) * inv_extent);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (DX) {
+        float v = 0.f;
+#pragma unroll
+        for (int p = 0; p < kKPmax; ++p)
+          if (p < n_kp) v += infl[wave][p] * dw[p];
+        if (cok && v != 0.f) atomicAdd(dx + (size_t)id * cin + c, v);
+      } else {
+        const float xv = cok ? x[(size_t)id * cin + c] : 0.f;
+#pragma unroll
+        for (int p = 0; p < kKPmax; ++p)
+          if (p < n_kp) acc[p] += infl[wave][p] * xv;
+        if (c0 == 0) {   // neighbour count of the reference: rows whose feature sum is > 0
+          float s = 0.f;
+          for (int cc = lane; cc < cin; cc += 64) s += x[(size_t)id * cin + cc];
+          s = wave_sum(s);
+          cnt += s > 0.f ? 1 : 0;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (!DX && cok) {
+#pragma unroll
+      for (int p = 0; p < kKPmax; ++p)
+        if (p < n_kp) wf[((size_t)n * n_kp + p) * cin + c] = acc[p];
+    }
+  }
+  if (!DX && lane == 0) cnt_out[n] = (float)(cnt > 1 ? cnt : 1);
+}
+
+// ---- softmax over the rows of per-batch matrices (attention backward) --------------------------
+struct MatDesc {
+  long long a_off, b_off, c_off;
+  int m, n, k, pad;
+};
+// in place: mat_b[i, :] = softmax(mat_b[i, :])          (one wave per row)
+__global__ void k_softmax_rows(float* __restrict__ mat, const MatDesc* __restrict__ desc) {
+  const MatDesc d = desc[blockIdx.y];
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= d.m) return;
+  float* r = mat + d.c_off + (size_t)row * d.n;
+  float mx = -INFINITY;
+  for (int j = lane; j < d.n; j += 64) mx = fmaxf(mx, r[j]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int j = lane; j < d.n; j += 64) s += expf(r[j] - mx);
+  s = wave_sum(s);
+  const float inv = 1.f / s;
+  for (int j = lane; j < d.n; j += 64) r[j] = expf(r[j] - mx) * inv;
+}
+// in place on dp: ds = p * (dp - sum_j p dp)
+__global__ void k_softmax_bwd_rows(const float* __restrict__ p, float* __restrict__ dp,
+                                   const MatDesc* __restrict__ desc) {
+  const MatDesc d = desc[blockIdx.y];
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= d.m) return;
+  const float* pr = p + d.c_off + (size_t)row * d.n;
+  float* dr = dp + d.c_off + (size_t)row * d.n;
+  float s = 0.f;
+  for (int j = lane; j < d.n; j += 64) s += pr[j] * dr[j];
+  s = wave_sum(s);
+  for (int j = lane; j < d.n; j += 64) dr[j] = pr[j] * (dr[j] - s);
+}
+
+}  // namespace
+}  // namespace spr
+
+using namespace spr;
+
+extern "C" int spr_act_bwd(const float* y, const float* dy, int act, long n, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(y && dy && out && n >= 1 && act >= 0 && act <= 2, "act_bwd: bad arguments");
+  hipLaunchKernelGGL(k_act_bwd, dim3(cdiv(n, 256)), dim3(256), 0, stream, y, dy, act, n, out);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t spr_colsum_workspace_bytes(int n) { return (size_t)kColChunks * (n > 0 ? n : 1) * sizeof(float); }
+
+extern "C" int spr_colsum(const float* x, long m, int n, float* out, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(x && out && m >= 1 && n >= 1, "colsum: bad arguments");
+  SPR_REQUIRE(ws && ws_bytes >= spr_colsum_workspace_bytes(n), "colsum: workspace too small");
+  float* parts = (float*)ws;
+  hipLaunchKernelGGL(k_colsum_parts, dim3(cdiv(n, 256), kColChunks), dim3(256), 0, stream, x, m, n, parts);
+  SPR_LAUNCH_CHECK();
+  return spr_reduce_parts(parts, kColChunks, n, 1.0f, out, 0, stream_);
+}
+
+extern "C" size_t spr_layernorm_bwd_workspace_bytes(int c) {
+  return 2 * (size_t)kLnBlocks * (c > 0 ? c : 1) * sizeof(float);
+}
+
+extern "C" int spr_layernorm_bwd(const float* x, int m, int c, const float* gamma, float eps, const float* dy_norm,
+                                 const float* dy_pos, float* dx, float* dgamma, float* dbeta, void* ws,
+                                 size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(m > 0 && c % 64 == 0 && c <= 1024, "layernorm_bwd: c must be a multiple of 64 and <= 1024 (c=%d)", c);
+  SPR_REQUIRE(x && gamma && dx && dgamma && dbeta && (dy_norm || dy_pos), "layernorm_bwd: null operand");
+  SPR_REQUIRE(ws && ws_bytes >= spr_layernorm_bwd_workspace_bytes(c), "layernorm_bwd: workspace too small");
+  float* dg = (float*)ws;
+  float* db = dg + (size_t)kLnBlocks * c;
+  if (c <= 256)
+    hipLaunchKernelGGL(k_layernorm_bwd<4>, dim3(kLnBlocks), dim3(256), 0, stream, x, m, c, gamma, eps, dy_norm,
+                       dy_pos, dx, dg, db);
+  else
+    hipLaunchKernelGGL(k_layernorm_bwd<16>, dim3(kLnBlocks), dim3(256), 0, stream, x, m, c, gamma, eps, dy_norm,
+                       dy_pos, dx, dg, db);
+  SPR_LAUNCH_CHECK();
+  if (int rc = spr_reduce_parts(dg, kLnBlocks, c, 1.0f, dgamma, 0, stream_)) return rc;
+  return spr_reduce_parts(db, kLnBlocks, c, 1.0f, dbeta, 0, stream_);
+}
+
+extern "C" int spr_maxpool_bwd(const float* x, int ns, int c, const int* idx, int nq, int idx_stride, int k,
+                               const float* dy, float* dx, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(nq > 0 && ns > 0 && c >= 1 && k >= 1 && k <= idx_stride, "maxpool_bwd: bad arguments");
+  hipLaunchKernelGGL(k_maxpool_bwd, dim3(cdiv((long)nq * c, 256)), dim3(256), 0, stream, x, ns, c, idx, nq,
+                     idx_stride, k, dy, dx);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_scatter_rows_add(const float* dy, const int* idx, int n, int c, int n_src, float* dx,
+                                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(n > 0 && c >= 1 && n_src > 0, "scatter_rows_add: bad arguments");
+  hipLaunchKernelGGL(k_scatter_rows_add, dim3(cdiv((long)n * c, 256)), dim3(256), 0, stream, dy, idx, n, c, n_src,
+                     dx);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_kpconv_weighted_features(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
+                                            int nbr_stride, int kmax, const float* x, int cin,
+                                            const float* kernel_points, int n_kp, float kp_extent, float* wf,
+                                            float* cnt, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(nq > 0 && ns > 0 && cin >= 1 && n_kp >= 1 && n_kp <= kKPmax && kp_extent > 0.f && kmax >= 1 &&
+                  kmax <= nbr_stride, "kpconv_weighted_features: bad arguments");
+  hipLaunchKernelGGL(k_kpconv_aux<false>, dim3(cdiv(nq, 4)), dim3(256), 0, stream, q_xyz, nq, s_xyz, ns, nbr,
+                     nbr_stride, kmax, x, cin, kernel_points, n_kp, 1.0f / kp_extent, (const float*)nullptr, wf, cnt,
+                     (float*)nullptr);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_kpconv_bwd_dx(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
+                                 int nbr_stride, int kmax, int cin, const float* kernel_points, int n_kp,
+                                 float kp_extent, const float* dwf, float* dx, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(nq > 0 && ns > 0 && cin >= 1 && n_kp >= 1 && n_kp <= kKPmax && kp_extent > 0.f && kmax >= 1 &&
+                  kmax <= nbr_stride, "kpconv_bwd_dx: bad arguments");
+  hipLaunchKernelGGL(k_kpconv_aux<true>, dim3(cdiv(nq, 4)), dim3(256), 0, stream, q_xyz, nq, s_xyz, ns, nbr,
+                     nbr_stride, kmax, (const float*)nullptr, cin, kernel_points, n_kp, 1.0f / kp_extent, dwf,
+                     (float*)nullptr, (float*)nullptr, dx);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_softmax_rows(float* mat, const void* desc_dev, int nbatch, int max_m, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(mat && desc_dev && nbatch >= 1 && nbatch <= 65535 && max_m >= 1, "softmax_rows: bad arguments");
+  hipLaunchKernelGGL(k_softmax_rows, dim3(cdiv((long)max_m * 64, 256), nbatch), dim3(256), 0, stream, mat,
+                     (const MatDesc*)desc_dev);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_softmax_bwd_rows(const float* p, float* dp, const void* desc_dev, int nbatch, int max_m,
+                                    void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(p && dp && desc_dev && nbatch >= 1 && nbatch <= 65535 && max_m >= 1, "softmax_bwd_rows: bad arguments");
+  hipLaunchKernelGGL(k_softmax_bwd_rows, dim3(cdiv((long)max_m * 64, 256), nbatch), dim3(256), 0, stream, p, dp,
+                     (const MatDesc*)desc_dev);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}

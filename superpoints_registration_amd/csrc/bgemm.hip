@@ -1,0 +1,141 @@
+// Generic batched, strided, exact-f32 MFMA GEMM -- the workhorse of the BACKWARD
+// pass.  Every gradient of the hot path that is a matrix
+// product is expressed through it:
+//   nn.Linear            dX = dY W            dW = dY^T X      (transformers.py:96-104,
+//                                                               kpconv_blocks.py:549)
+//   KPConv               d(weighted feats) = g W_flat^T,  dW_flat = wf^T g
+//                                                              (kpconv_blocks.py:394-406)
+//   attention core       S = Q K^T, dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q
+//                                                              (transformers.py:198-227)
+//   InfoNCE / correlation heads                                (feature_loss.py:268-296,
+//                                                               qk_regtr_full.py:453)
+// which in the reference are produced by torch autograd.
+//
+//   C_b(i, j) = alpha * sum_k A_b(i, k) B_b(k, j) + beta * C_b(i, j)
+//   A_b(i, k) = A[a_off_b + i * sa_i + k * sa_k]          (any strides: N / T operands,
+//   B_b(k, j) = B[b_off_b + k * sb_k + j * sb_j]           head slices of [T, 3d] rows, ...)
+//   C_b(i, j) = C[c_off_b + i * sc_i + j * sc_j]
+// Batches carry their own sizes (varlen segments) in a device descriptor array.
+// Arithmetic: v_mfma_f32_32x32x2_f32 (exact f32, a k-ordered fmaf chain per
+// output) -- gradients are formed in plain fp32 like the reference's.
+//
+// Kernel shape: 64 x 64 output tile per workgroup of 4 waves (one 32 x 32
+// accumulator each), K slabs of 16 staged k-major in LDS so that the MFMA
+// fragments (lane = row/col, k = 2 s + lane/32) are conflict-free reads whatever
+// the operand strides; the global side walks whichever operand dimension is
+// contiguous with consecutive lanes.
+#include "spr_common.h"
+
+namespace spr {
+namespace {
+
+struct BgemmDesc {
+  long long a_off, b_off, c_off;
+  int m, n, k, pad;
+};
+
+constexpr int TB = 64;    // output tile edge
+constexpr int KB = 16;    // K slab
+constexpr int LDT = TB + 1;
+
+__global__ __launch_bounds__(256) void k_bgemm_f32(const float* __restrict__ A, const float* __restrict__ B,
+                                                   float* __restrict__ C, const BgemmDesc* __restrict__ desc,
+                                                   long sa_i, long sa_k, long sb_k, long sb_j, long sc_i,
+                                                   long sc_j, float alpha, float beta, int tiles_n_max) {
+  __shared__ float As[KB * LDT];   // [k][i]
+  __shared__ float Bs[KB * LDT];   // [k][j]
+  const BgemmDesc d = desc[blockIdx.y];
+  const int tn = (d.n + TB - 1) / TB, tm = (d.m + TB - 1) / TB;
+  const int tile = blockIdx.x;
+  if (tile >= tn * tm) return;
+  const int i0 = (tile / tn) * TB, j0 = (tile % tn) * TB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+  const float* Ab = A + d.a_off;
+  const float* Bb = B + d.b_off;
+  float* Cb = C + d.c_off;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  // staging maps: 256 threads cover a [KB x TB] slab in 4 passes; consecutive threads walk
+  // the operand's contiguous dimension
+  const bool a_k_fast = sa_k == 1;     // rows contiguous along k
+  const bool b_k_fast = sb_k == 1;
+  for (int k0 = 0; k0 < d.k; k0 += KB) {
+#pragma unroll
+    for (int p = 0; p < (KB * TB) / 256; ++p) {
+      const int e = p * 256 + tid;
+      int ia, ka, jb, kb;
+      if (a_k_fast) { ka = e % KB; ia = e / KB; } else { ia = e % TB; ka = e / TB; }
+      if (b_k_fast) { kb = e % KB; jb = e / KB; } else { jb = e % TB; kb = e / TB; }
+      const bool oka = i0 + ia < d.m && k0 + ka < d.k;
+      const bool okb = j0 + jb < d.n && k0 + kb < d.k;
+      As[ka * LDT + ia] = oka ? Ab[(long)(i0 + ia) * sa_i + (long)(k0 + ka) * sa_k] : 0.f;
+      Bs[kb * LDT + jb] = okb ? Bb[(long)(k0 + kb) * sb_k + (long)(j0 + jb) * sb_j] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KB / 2; ++s) {
+      const float a = As[(2 * s + lh) * LDT + wi + l31];
+      const float b = Bs[(2 * s + lh) * LDT + wj + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  const int j = j0 + wj + l31;
+  if (j < d.n) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + wi + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (i < d.m) {
+        float* c = Cb + (long)i * sc_i + (long)j * sc_j;
+        const float v = alpha * acc[r];
+        *c = beta != 0.f ? v + beta * *c : v;
+      }
+    }
+  }
+}
+
+// out[j] = scale * sum over parts p of parts[p][j]   (fixed order: deterministic split-K)
+__global__ void k_reduce_parts(const float* __restrict__ parts, int nparts, long n, float scale,
+                               float* __restrict__ out, int accumulate) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += parts[(long)p * n + j];
+  s *= scale;
+  out[j] = accumulate ? out[j] + s : s;
+}
+
+}  // namespace
+}  // namespace spr
+
+using namespace spr;
+
+extern "C" int spr_bgemm(const float* A, const float* B, float* C, const void* desc_dev, int nbatch,
+                         int max_m, int max_n, long sa_i, long sa_k, long sb_k, long sb_j, long sc_i,
+                         long sc_j, float alpha, float beta, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(A && B && C && desc_dev && nbatch >= 1 && max_m >= 1 && max_n >= 1, "bgemm: bad arguments");
+  SPR_REQUIRE(nbatch <= 65535, "bgemm: too many batches (%d)", nbatch);
+  const long tiles = (long)cdiv(max_m, TB) * cdiv(max_n, TB);
+  SPR_REQUIRE(tiles < (1l << 31), "bgemm: grid too large");
+  hipLaunchKernelGGL(k_bgemm_f32, dim3((unsigned)tiles, nbatch), dim3(256), 0, stream, A, B, C,
+                     (const BgemmDesc*)desc_dev, sa_i, sa_k, sb_k, sb_j, sc_i, sc_j, alpha, beta, cdiv(max_n, TB));
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_reduce_parts(const float* parts, int nparts, long n, float scale, float* out,
+                                int accumulate, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(parts && out && nparts >= 1 && n >= 1, "reduce_parts: bad arguments");
+  hipLaunchKernelGGL(k_reduce_parts, dim3(cdiv(n, 256)), dim3(256), 0, stream, parts, nparts, n, scale, out,
+                     accumulate);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}

@@ -189,6 +189,110 @@ __global__ void k_tloss_partial(const float* __restrict__ pose_gt, const float* 
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
+// ---- backward kernels ----------------------------------------------------------
+// d/dx of mean(BCE-with-logits) = (sigmoid(x) - y) / n, times the upstream scalar gradient gout[0]
+__global__ void k_bce_bwd(const float* __restrict__ x, const float* __restrict__ y, int n,
+                          const float* __restrict__ gout, float* __restrict__ dx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float s = 1.f / (1.f + expf(-x[i]));
+  dx[i] = gout[0] * (s - y[i]) / (float)n;
+}
+
+// InfoNCE (feature_loss.py:268-296): row i with a positive contributes lse_i - logit[i, pos_i];
+// d logits[i, j] = mask_i (softmax over the non-ignored targets - [j == pos_i]).  Un-normalised:
+// the caller divides by the number of masked rows (row_mask is written too).
+__global__ void k_infonce_dlogits(const float* __restrict__ logits, int n, int m,
+                                  const float* __restrict__ a_xyz, const float* __restrict__ p_xyz,
+                                  float r_p, float r_n, float* __restrict__ dlogits,
+                                  float* __restrict__ row_mask) {
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const float ax = a_xyz[3 * i], ay = a_xyz[3 * i + 1], az = a_xyz[3 * i + 2];
+  const float* row = logits + (size_t)i * m;
+  float* drow = dlogits + (size_t)i * m;
+  float best = INFINITY;
+  int bj = 0x7fffffff;
+  for (int j = lane; j < m; j += 64) {
+    const float dx = ax - p_xyz[3 * j], dy = ay - p_xyz[3 * j + 1], dz = az - p_xyz[3 * j + 2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (d < best || (d == best && j < bj)) {
+      best = d;
+      bj = j;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oj = __shfl_xor(bj, o, 64);
+    if (ob < best || (ob == best && oj < bj)) {
+      best = ob;
+      bj = oj;
+    }
+  }
+  const bool mask = best < r_p;
+  float mx = -INFINITY;
+  for (int j = lane; j < m; j += 64) {
+    const float dx = ax - p_xyz[3 * j], dy = ay - p_xyz[3 * j + 1], dz = az - p_xyz[3 * j + 2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (!(d < r_n) || j == bj) mx = fmaxf(mx, row[j]);
+  }
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int j = lane; j < m; j += 64) {
+    const float dx = ax - p_xyz[3 * j], dy = ay - p_xyz[3 * j + 1], dz = az - p_xyz[3 * j + 2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (!(d < r_n) || j == bj) se += expf(row[j] - mx);
+  }
+  se = wave_sum(se);
+  const float inv = 1.f / se;
+  for (int j = lane; j < m; j += 64) {
+    const float dx = ax - p_xyz[3 * j], dy = ay - p_xyz[3 * j + 1], dz = az - p_xyz[3 * j + 2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    float g = 0.f;
+    if (mask && (!(d < r_n) || j == bj)) g = expf(row[j] - mx) * inv;
+    if (mask && j == bj) g -= 1.f;
+    drow[j] = g;
+  }
+  if (lane == 0) row_mask[i] = mask ? 1.f : 0.f;
+}
+
+// dW[r][c] = dWsym[r][c] + dWsym[c][r] for c >= r, 0 below the diagonal  (W_sym = triu(W) + triu(W)^T)
+__global__ void k_wsym_bwd(const float* __restrict__ dws, int d, float* __restrict__ dW) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d * d) return;
+  const int r = i / d, c = i % d;
+  dW[i] = c >= r ? dws[r * d + c] + dws[c * d + r] : 0.f;
+}
+
+// transform loss of one pair: mean over points and components of |T_gt x - T_pred x|;
+// d/d pose_pred[r][c] = -(gout/(3n)) sum_i sign(g - p)_r x_c   (c = 3: x_c = 1).  One workgroup.
+__global__ __launch_bounds__(RB) void k_tloss_bwd(const float* __restrict__ pose_gt,
+                                                  const float* __restrict__ pose_pred,
+                                                  const float* __restrict__ xyz, int n,
+                                                  const float* __restrict__ gout, float* __restrict__ dpose) {
+  __shared__ double sh[RB / 64];
+  double acc[12];
+  for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+  for (int i = threadIdx.x; i < n; i += RB) {
+    const float x[4] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 1.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float g = (x[0] * pose_gt[4 * r] + x[1] * pose_gt[4 * r + 1] + x[2] * pose_gt[4 * r + 2]) + pose_gt[4 * r + 3];
+      const float p = (x[0] * pose_pred[4 * r] + x[1] * pose_pred[4 * r + 1] + x[2] * pose_pred[4 * r + 2]) + pose_pred[4 * r + 3];
+      const float df = g - p;
+      const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[4 * r + c] -= (double)(sgn * x[c]);
+    }
+  }
+  for (int k = 0; k < 12; ++k) {
+    const double t = block_sum(acc[k], sh);
+    if (threadIdx.x == 0) dpose[k] = (float)(t * (double)gout[0] / (3.0 * (double)n));
+  }
+}
+
 // out[0] = sum_b pair[b]
 __global__ void k_sum_small(const float* __restrict__ pair, int n, float scale, float* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -285,6 +389,67 @@ extern "C" int spr_sum_scaled(const float* values, int n, float scale, float* ou
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(n >= 1, "sum_scaled: n must be >= 1");
   hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(64), 0, stream, values, n, scale, out);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- backward entry points ---------------------------------------------------------------------
+extern "C" int spr_bce_logits_mean_bwd(const float* x, const float* y, int n, const float* gout, float* dx,
+                                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(n >= 1 && x && y && gout && dx, "bce_bwd: bad arguments");
+  hipLaunchKernelGGL(k_bce_bwd, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, y, n, gout, dx);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+// Step 1 of the InfoNCE backward of one pair: logits (recomputed like the forward) ->
+// un-normalised d logits [n, m] and the row mask [n].  wsym_out [d, d] and t_out [n, d] (= A W_sym) are
+// returned for the caller's GEMM chain (dA = (dlogits B) W_sym, dB = dlogits^T t, dW_sym = A^T (dlogits B)).
+extern "C" int spr_infonce_pair_dlogits(const float* anchor_feat, int n, const float* positive_feat, int m, int d,
+                                        const float* anchor_xyz, const float* pose_gt, const float* positive_xyz,
+                                        const float* W, float r_p, float r_n, float* dlogits, float* row_mask,
+                                        float* wsym_out, float* t_out, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(n >= 1 && m >= 1 && d >= 32 && d % 32 == 0, "infonce_bwd: bad sizes n=%d m=%d d=%d", n, m, d);
+  SPR_REQUIRE(ws != nullptr && ws_bytes >= spr_loss_workspace_bytes(n, m, d), "infonce_bwd: workspace too small");
+  Workspace w(ws, ws_bytes);
+  float* logits = w.take<float>((size_t)n * m);
+  (void)w.take<float>((size_t)n * d);
+  (void)w.take<float>((size_t)d * d);
+  float* axyz = w.take<float>((size_t)n * 3);
+  (void)w.take<float>(n);
+  (void)w.take<float>(n);
+  const int nb = cdiv(n, RB);
+  (void)w.take<double>(nb);
+  (void)w.take<double>(nb);
+  const size_t lws = spr_linear_workspace_bytes();
+  char* lw1 = w.take<char>(lws);
+  char* lw2 = w.take<char>(lws);
+  SPR_REQUIRE(lw2 != nullptr, "infonce_bwd: workspace carve failed");
+  hipLaunchKernelGGL(k_wsym, dim3(cdiv(d * d, 256)), dim3(256), 0, stream, W, d, wsym_out);
+  hipLaunchKernelGGL(k_transform, dim3(cdiv(n, 256)), dim3(256), 0, stream, pose_gt, anchor_xyz, n, axyz);
+  if (int rc = spr_linear(anchor_feat, n, d, wsym_out, d, nullptr, nullptr, SPR_ACT_NONE, t_out, lw1, lws, stream_)) return rc;
+  if (int rc = spr_linear(t_out, n, d, positive_feat, m, nullptr, nullptr, SPR_ACT_NONE, logits, lw2, lws, stream_)) return rc;
+  hipLaunchKernelGGL(k_infonce_dlogits, dim3(cdiv((long)n * 64, 256)), dim3(256), 0, stream, logits, n, m, axyz,
+                     positive_xyz, r_p, r_n, dlogits, row_mask);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_wsym_bwd(const float* dwsym, int d, float* dW, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(d >= 1 && dwsym && dW, "wsym_bwd: bad arguments");
+  hipLaunchKernelGGL(k_wsym_bwd, dim3(cdiv(d * d, 256)), dim3(256), 0, stream, dwsym, d, dW);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_transform_l1_pair_bwd(const float* pose_gt, const float* pose_pred, const float* xyz, int n,
+                                         const float* gout, float* dpose_pred, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(n >= 1 && pose_gt && pose_pred && xyz && gout && dpose_pred, "transform_l1_bwd: bad arguments");
+  hipLaunchKernelGGL(k_tloss_bwd, dim3(1), dim3(RB), 0, stream, pose_gt, pose_pred, xyz, n, gout, dpose_pred);
   SPR_LAUNCH_CHECK();
   return 0;
 }

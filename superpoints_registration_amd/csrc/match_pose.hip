@@ -394,6 +394,309 @@ __global__ __launch_bounds__(256) void k_procrustes(const float* __restrict__ a,
   }
 }
 
+// ---- weighted Procrustes backward (se3_torch.py:109-163 differentiated; the reference relies on
+// torch.svd's autograd) -------------------------------------------------------------------------
+// With H = sum w~ (a - abar)(b - bbar)^T = U S V^T and R = V D U^T:  H^T = R P,  P = U L U^T,
+// L = diag(s1, s2, d s3).  For a perturbation dH:  R^T dR = Om (skew) solves
+// Om P + P Om = Z - Z^T, Z = R^T dH^T, i.e. in P's eigenbasis Om~_ij = (Z - Z^T)~_ij / (l_i + l_j).
+// Adjoint: with Y = R^T G_R, Q = U [ (U^T (Y - Y^T)/2 U)_ij / (l_i + l_j) ] U^T,
+//   dL/dH = -2 Q R^T.
+// Then dL/db_i = w~_i (dL/dH^T (a_i - abar) + g_t), dL/dw~_i = (a_i - abar)^T dL/dH (b_i - bbar)
+// - (R^T g_t) . a_i + g_t . b_i, and w~ = w / sum(w).
+__global__ __launch_bounds__(256) void k_procrustes_bwd(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const float* __restrict__ w,
+                                                        const int* __restrict__ pair_cu,
+                                                        const float* __restrict__ dpose, float* __restrict__ da,
+                                                        float* __restrict__ db, float* __restrict__ dw) {
+  const int pr = blockIdx.x;
+  const int beg = pair_cu[pr], end = pair_cu[pr + 1];
+  __shared__ double sh[256];
+  __shared__ double bc[32];   // GH (9), g_t (3), g_abar (3)
+  double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int i = beg + threadIdx.x; i < end; i += 256) {
+    const double wi = w ? (double)w[i] : 1.0;
+    acc[0] += wi;
+    for (int d = 0; d < 3; ++d) {
+      acc[1 + d] += wi * (double)a[3 * (size_t)i + d];
+      acc[4 + d] += wi * (double)b[3 * (size_t)i + d];
+    }
+  }
+  block_reduce_d(acc, 7, sh);
+  const bool clamped = w ? acc[0] < 1e-6 : acc[0] < 1.0;
+  const double den = w ? fmax(acc[0], 1e-6) : fmax(acc[0], 1.0);
+  double ca[3], cb[3];
+  for (int d = 0; d < 3; ++d) {
+    ca[d] = acc[1 + d] / den;
+    cb[d] = acc[4 + d] / den;
+  }
+  double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = beg + threadIdx.x; i < end; i += 256) {
+    const double wi = (w ? (double)w[i] : 1.0) / den;
+    double da_[3], db_[3];
+    for (int d = 0; d < 3; ++d) {
+      da_[d] = (double)a[3 * (size_t)i + d] - ca[d];
+      db_[d] = ((double)b[3 * (size_t)i + d] - cb[d]) * wi;
+    }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) cov[3 * r + c] += da_[r] * db_[c];
+  }
+  block_reduce_d(cov, 9, sh);
+  if (threadIdx.x == 0) {
+    double A[3][3], U[3][3], S[3], V[3][3], R[3][3];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) A[r][c] = cov[3 * r + c];
+    svd3_jacobi(A, U, S, V);
+    double dsign = 1.0;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) R[r][c] = V[r][0] * U[c][0] + V[r][1] * U[c][1] + V[r][2] * U[c][2];
+      const double det = R[0][0] * (R[1][1] * R[2][2] - R[1][2] * R[2][1]) -
+                         R[0][1] * (R[1][0] * R[2][2] - R[1][2] * R[2][0]) +
+                         R[0][2] * (R[1][0] * R[2][1] - R[1][1] * R[2][0]);
+      if (det > 0.0) break;
+      for (int r = 0; r < 3; ++r) V[r][2] = -V[r][2];
+      dsign = -1.0;
+    }
+    const float* G = dpose + 12 * (size_t)pr;
+    double GR[3][3], gt[3];
+    for (int r = 0; r < 3; ++r) {
+      gt[r] = (double)G[4 * r + 3];
+      for (int c = 0; c < 3; ++c) GR[r][c] = (double)G[4 * r + c] - gt[r] * ca[c];   // t = bbar - R abar
+    }
+    const double lam[3] = {S[0], S[1], dsign * S[2]};
+    double Y[3][3], Ysk[3][3], T1[3][3], Yt[3][3], Qt[3][3], Q[3][3], GH[3][3];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) Y[r][c] = R[0][r] * GR[0][c] + R[1][r] * GR[1][c] + R[2][r] * GR[2][c];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) Ysk[r][c] = 0.5 * (Y[r][c] - Y[c][r]);
+    for (int r = 0; r < 3; ++r)      // T1 = U^T Ysk
+      for (int c = 0; c < 3; ++c) T1[r][c] = U[0][r] * Ysk[0][c] + U[1][r] * Ysk[1][c] + U[2][r] * Ysk[2][c];
+    for (int r = 0; r < 3; ++r)      // Yt = T1 U
+      for (int c = 0; c < 3; ++c) Yt[r][c] = T1[r][0] * U[0][c] + T1[r][1] * U[1][c] + T1[r][2] * U[2][c];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        const double s = lam[r] + lam[c];
+        Qt[r][c] = (r != c && fabs(s) > 1e-300) ? Yt[r][c] / s : 0.0;
+      }
+    for (int r = 0; r < 3; ++r)      // T1 = U Qt
+      for (int c = 0; c < 3; ++c) T1[r][c] = U[r][0] * Qt[0][c] + U[r][1] * Qt[1][c] + U[r][2] * Qt[2][c];
+    for (int r = 0; r < 3; ++r)      // Q = T1 U^T
+      for (int c = 0; c < 3; ++c) Q[r][c] = T1[r][0] * U[c][0] + T1[r][1] * U[c][1] + T1[r][2] * U[c][2];
+    for (int r = 0; r < 3; ++r)      // GH = -2 Q R^T
+      for (int c = 0; c < 3; ++c) GH[r][c] = -2.0 * (Q[r][0] * R[c][0] + Q[r][1] * R[c][1] + Q[r][2] * R[c][2]);
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) bc[3 * r + c] = GH[r][c];
+      bc[9 + r] = gt[r];
+      bc[12 + r] = -(R[0][r] * gt[0] + R[1][r] * gt[1] + R[2][r] * gt[2]);   // g_abar = -R^T g_t
+    }
+  }
+  __syncthreads();
+  double GH[9], gt[3], ga[3];
+  for (int k = 0; k < 9; ++k) GH[k] = bc[k];
+  for (int k = 0; k < 3; ++k) {
+    gt[k] = bc[9 + k];
+    ga[k] = bc[12 + k];
+  }
+  // first pass: dL/dw~_i and its weighted sum
+  double s2[1] = {0.0};
+  for (int i = beg + threadIdx.x; i < end; i += 256) {
+    const double wt = (w ? (double)w[i] : 1.0) / den;
+    double ac[3], bcv[3], ai[3], bi[3];
+    for (int d = 0; d < 3; ++d) {
+      ai[d] = (double)a[3 * (size_t)i + d];
+      bi[d] = (double)b[3 * (size_t)i + d];
+      ac[d] = ai[d] - ca[d];
+      bcv[d] = bi[d] - cb[d];
+    }
+    double q = 0.0;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) q += ac[r] * GH[3 * r + c] * bcv[c];
+    for (int d = 0; d < 3; ++d) q += ga[d] * ai[d] + gt[d] * bi[d];
+    s2[0] += wt * q;
+    if (db)
+      for (int c = 0; c < 3; ++c)
+        db[3 * (size_t)i + c] = (float)(wt * (GH[c] * ac[0] + GH[3 + c] * ac[1] + GH[6 + c] * ac[2] + gt[c]));
+    if (da)
+      for (int r = 0; r < 3; ++r)
+        da[3 * (size_t)i + r] = (float)(wt * (GH[3 * r] * bcv[0] + GH[3 * r + 1] * bcv[1] + GH[3 * r + 2] * bcv[2] + ga[r]));
+    if (dw) dw[i] = (float)q;   // completed below
+  }
+  block_reduce_d(s2, 1, sh);
+  if (dw) {
+    __syncthreads();
+    for (int i = beg + threadIdx.x; i < end; i += 256)
+      dw[i] = (float)(((double)dw[i] - (clamped ? 0.0 : s2[0])) / den);
+  }
+}
+
+// ---- Sinkhorn (slack) backward -------------------------------------------------------------------
+// Forward (spr_sinkhorn_correspondences): v_0 = 0; for t = 1..n: u_t = log(1 + sum_j e^{A_ij - v_{t-1,j}}),
+// v_t = log(1 + sum_i e^{A_ij - u_{t,i}});  P = e^{A - u_n - v_n};  w_i = sum_j P_ij,
+// that_i = sum_j P_ij tgt_j / (w_i + 1e-6).
+// Final step, row part: Y_ij = gP_ij P_ij with gP_ij = dw_i + dthat_i . (tgt_j - that_i) / (w_i + 1e-6);
+// dA = Y, du_i = -sum_j Y_ij.   One wave per src row.
+__global__ void k_sk_bwd_final(const float* __restrict__ mat, float* __restrict__ dmat,
+                               const PairDesc* __restrict__ pd, const float* __restrict__ u,
+                               const float* __restrict__ v, const float* __restrict__ xyz,
+                               const float* __restrict__ dw, const float* __restrict__ dthat,
+                               float* __restrict__ du) {
+  const PairDesc p = pd[blockIdx.y];
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= p.n) return;
+  const int gi = p.src_beg + row;
+  const float ui = u[gi];
+  const float* ar = mat + p.off + (size_t)row * p.m;
+  float* dr = dmat + p.off + (size_t)row * p.m;
+  float wsum = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
+  for (int j = lane; j < p.m; j += 64) {
+    const float pij = expf(ar[j] - ui - v[p.tgt_beg + j]);
+    const float* t = xyz + 3 * (size_t)(p.tgt_beg + j);
+    wsum += pij;
+    tx += pij * t[0];
+    ty += pij * t[1];
+    tz += pij * t[2];
+  }
+  wsum = wave_sum(wsum);
+  tx = wave_sum(tx);
+  ty = wave_sum(ty);
+  tz = wave_sum(tz);
+  const float dn = wsum + 1e-6f;
+  const float hx = tx / dn, hy = ty / dn, hz = tz / dn;
+  const float gw = dw[gi], gx = dthat[3 * (size_t)gi], gy = dthat[3 * (size_t)gi + 1], gz = dthat[3 * (size_t)gi + 2];
+  float s = 0.f;
+  for (int j = lane; j < p.m; j += 64) {
+    const float pij = expf(ar[j] - ui - v[p.tgt_beg + j]);
+    const float* t = xyz + 3 * (size_t)(p.tgt_beg + j);
+    const float gp = gw + (gx * (t[0] - hx) + gy * (t[1] - hy) + gz * (t[2] - hz)) / dn;
+    const float y = gp * pij;
+    dr[j] = y;
+    s += y;
+  }
+  s = wave_sum(s);
+  if (lane == 0) du[gi] = -s;
+}
+// column sums of dmat: dv_j = -sum_i dmat_ij  (64 columns x 16 row lanes)
+__global__ __launch_bounds__(1024) void k_sk_colsum_neg(const float* __restrict__ dmat,
+                                                       const PairDesc* __restrict__ pd, float* __restrict__ dv) {
+  const PairDesc p = pd[blockIdx.y];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  __shared__ float ss[kColLanes][64];
+  float s = 0.f;
+  if (col < p.m)
+    for (int i = rl; i < p.n; i += kColLanes) s += dmat[p.off + (size_t)i * p.m + col];
+  ss[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && col < p.m) {
+    float t = 0.f;
+    for (int k = 0; k < kColLanes; ++k) t += ss[k][cl];
+    dv[p.tgt_beg + col] = -t;
+  }
+}
+// column step of iteration t (v_t from u_t): C_ij = e^{A_ij - u_i - v_j}; dA_ij += dv_j C_ij;
+// du_i -= sum_j dv_j C_ij.   One wave per src row.
+__global__ void k_sk_bwd_col(const float* __restrict__ mat, float* __restrict__ dmat,
+                             const PairDesc* __restrict__ pd, const float* __restrict__ u,
+                             const float* __restrict__ v, const float* __restrict__ dv, float* __restrict__ du) {
+  const PairDesc p = pd[blockIdx.y];
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= p.n) return;
+  const int gi = p.src_beg + row;
+  const float ui = u[gi];
+  const float* ar = mat + p.off + (size_t)row * p.m;
+  float* dr = dmat + p.off + (size_t)row * p.m;
+  float s = 0.f;
+  for (int j = lane; j < p.m; j += 64) {
+    const float c = dv[p.tgt_beg + j] * expf(ar[j] - ui - v[p.tgt_beg + j]);
+    dr[j] += c;
+    s += c;
+  }
+  s = wave_sum(s);
+  if (lane == 0) du[gi] -= s;
+}
+// row step of iteration t (u_t from v_{t-1}): R_ij = e^{A_ij - v_j - u_i}; dA_ij += du_i R_ij;
+// dv_prev_j = -sum_i du_i R_ij  (written, not accumulated: v_{t-1} has no other consumer).
+__global__ __launch_bounds__(1024) void k_sk_bwd_row(const float* __restrict__ mat, float* __restrict__ dmat,
+                                                    const PairDesc* __restrict__ pd, const float* __restrict__ u,
+                                                    const float* __restrict__ vprev,
+                                                    const float* __restrict__ du, float* __restrict__ dvprev) {
+  const PairDesc p = pd[blockIdx.y];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  __shared__ float ss[kColLanes][64];
+  float s = 0.f;
+  if (col < p.m) {
+    const float vj = vprev ? vprev[p.tgt_beg + col] : 0.f;
+    for (int i = rl; i < p.n; i += kColLanes) {
+      const size_t o = p.off + (size_t)i * p.m + col;
+      const float r = du[p.src_beg + i] * expf(mat[o] - vj - u[p.src_beg + i]);
+      dmat[o] += r;
+      s += r;
+    }
+  }
+  ss[rl][cl] = s;
+  __syncthreads();
+  if (dvprev && rl == 0 && col < p.m) {
+    float t = 0.f;
+    for (int k = 0; k < kColLanes; ++k) t += ss[k][cl];
+    dvprev[p.tgt_beg + col] = -t;
+  }
+}
+// affinity backward: A = -(max(c s, 0) - sp) inv_den.  In place: dmat <- d corr = -dA inv_den s [c s > 0];
+// per-block partial sums of dA and dA * A (for d alpha, d beta) in float64.
+__global__ __launch_bounds__(256) void k_affinity_bwd(const float* __restrict__ corr, const float* __restrict__ amat,
+                                                      float* __restrict__ dmat, long long total, float scale,
+                                                      const float* __restrict__ beta_p, double* __restrict__ parts) {
+  __shared__ double sh[4];
+  const float inv_den = (float)(1.0 / (exp((double)beta_p[0]) + 0.02));
+  double s1 = 0.0, s2 = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const float dA = dmat[i];   // alignment padding between pairs holds zeros (memset by the caller)
+    s1 += (double)dA;
+    if (dA != 0.f) s2 += (double)dA * (double)amat[i];
+    dmat[i] = corr[i] * scale > 0.f ? -dA * inv_den * scale : 0.f;
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s1;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[2 * blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s2;
+  __syncthreads();
+  if (threadIdx.x == 0) parts[2 * blockIdx.x + 1] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// d alpha = (sum dA) inv_den sigmoid(alpha);  d beta = (sum dA A) (-e^beta / den)
+__global__ void k_affinity_bwd_final(const double* __restrict__ parts, int nparts, const float* __restrict__ alpha_p,
+                                     const float* __restrict__ beta_p, float* __restrict__ dalpha,
+                                     float* __restrict__ dbeta) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < nparts; ++i) {
+    s1 += parts[2 * i];
+    s2 += parts[2 * i + 1];
+  }
+  const double al = (double)alpha_p[0], be = (double)beta_p[0];
+  const double den = exp(be) + 0.02;
+  const double sig = al > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-al));
+  dalpha[0] = (float)(s1 / den * sig);
+  dbeta[0] = (float)(-s2 * exp(be) / den);
+}
+// device descriptors for the two feature-gradient GEMMs (spr_bgemm records)
+struct GemmRec {
+  long long a_off, b_off, c_off;
+  int m, n, k, pad;
+};
+__global__ void k_build_grad_recs(const PairDesc* __restrict__ pd, int npairs, int d, GemmRec* rs, GemmRec* rt) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= npairs) return;
+  const PairDesc p = pd[b];
+  // dFs[n, d] = dcorr[n, m] Ft[m, d]
+  rs[b] = GemmRec{p.off, (long long)p.tgt_beg * d, (long long)p.src_beg * d, p.n, d, p.m, 0};
+  // dFt[m, d] = dcorr^T[m, n] Fs[n, d]
+  rt[b] = GemmRec{p.off, (long long)p.src_beg * d, (long long)p.tgt_beg * d, p.m, d, p.n, 0};
+}
+
 int build_pairs(const int* cu_host, int npairs, PairDesc* h, long long* total) {
   long long off = 0;
   for (int b = 0; b < npairs; ++b) {
@@ -565,5 +868,114 @@ extern "C" int spr_weighted_procrustes(const float* a, const float* b, const flo
   SPR_REQUIRE(npairs >= 1, "procrustes: npairs must be >= 1");
   hipLaunchKernelGGL(k_procrustes, dim3(npairs), dim3(256), 0, stream, a, b, w, pair_cu, out_pose);
   SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- backward entry points ---------------------------------------------------
+extern "C" int spr_weighted_procrustes_bwd(const float* a, const float* b, const float* w, const int* pair_cu,
+                                           int npairs, const float* dpose, float* da, float* db, float* dw,
+                                           void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(npairs >= 1 && a && b && pair_cu && dpose, "procrustes_bwd: bad arguments");
+  SPR_REQUIRE(dw == nullptr || w != nullptr, "procrustes_bwd: dw needs w");
+  hipLaunchKernelGGL(k_procrustes_bwd, dim3(npairs), dim3(256), 0, stream, a, b, w, pair_cu, dpose, da, db, dw);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t spr_sinkhorn_bwd_workspace_bytes(const int* cu_host, int npairs, int n_iters) {
+  long long off = 0;
+  const int tmax = cu_host[2 * npairs];
+  for (int b = 0; b < npairs; ++b) {
+    off += (long long)(cu_host[b + 1] - cu_host[b]) * (cu_host[npairs + b + 1] - cu_host[npairs + b]);
+    off = (off + 63) / 64 * 64;
+  }
+  const int it = n_iters > 0 ? n_iters : 1;
+  return 3 * align_up((size_t)off * 4, 256) + align_up(sizeof(PairDesc) * npairs, 256) +
+         2 * align_up(sizeof(GemmRec) * npairs, 256) + (size_t)(2 * it + 4) * align_up((size_t)tmax * 4, 256) +
+         2 * align_up(kAmaxParts * sizeof(float), 256) + align_up(2 * 1024 * sizeof(double), 256) + 2048;
+}
+
+// Gradient of (w, t_hat) = spr_sinkhorn_correspondences(feat, ...) w.r.t. feat, alpha, beta.
+//   dw [Tsrc], dthat [Tsrc, 3] in;  dfeat [T, d] (written completely), dalpha [1], dbeta [1] out.
+extern "C" int spr_sinkhorn_bwd(const float* feat, int d, const float* xyz, const int* cu, const int* cu_host,
+                                int npairs, const float* alpha, const float* beta, int n_iters, const float* dw,
+                                const float* dthat, float* dfeat, float* dalpha, float* dbeta, void* ws,
+                                size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(npairs >= 1 && d % 32 == 0 && n_iters >= 0, "sinkhorn_bwd: bad arguments");
+  SPR_REQUIRE(feat && xyz && cu && cu_host && alpha && beta && dw && dthat && dfeat && dalpha && dbeta,
+              "sinkhorn_bwd: null operand");
+  SPR_REQUIRE(ws_bytes >= spr_sinkhorn_bwd_workspace_bytes(cu_host, npairs, n_iters), "sinkhorn_bwd: workspace too small");
+  Workspace w(ws, ws_bytes);
+  float* mat;
+  PairDesc* pd;
+  std::vector<PairDesc> h;
+  long long total;
+  int max_n, max_m;
+  if (correlate(feat, d, cu, cu_host, npairs, w, &mat, &pd, h, &total, &max_n, &max_m, stream)) return 1;
+  const int T = cu_host[2 * npairs];
+  float* corr = w.take<float>((size_t)total);
+  float* dmat = w.take<float>((size_t)total);
+  GemmRec* rs = w.take<GemmRec>(npairs);
+  GemmRec* rt = w.take<GemmRec>(npairs);
+  const int it_n = n_iters > 0 ? n_iters : 1;
+  float* U = w.take<float>((size_t)it_n * T);
+  float* V = w.take<float>((size_t)it_n * T);
+  float* du = w.take<float>(T);
+  float* dva = w.take<float>(T);
+  float* dvb = w.take<float>(T);
+  float* zero = w.take<float>(T);
+  double* parts = w.take<double>(2 * 1024);
+  SPR_REQUIRE(parts != nullptr, "sinkhorn_bwd: workspace carve failed");
+  const float scale = 1.0f / sqrtf((float)d);
+  SPR_HIP_CHECK(hipMemsetAsync(dmat, 0, sizeof(float) * (size_t)total, stream));
+  SPR_HIP_CHECK(hipMemcpyAsync(corr, mat, sizeof(float) * (size_t)total, hipMemcpyDeviceToDevice, stream));
+  hipLaunchKernelGGL(k_affinity, dim3(cdiv(total, 256)), dim3(256), 0, stream, mat, total, scale, alpha, beta);
+  SPR_HIP_CHECK(hipMemsetAsync(zero, 0, sizeof(float) * T, stream));
+  const dim3 grow(cdiv((long)max_n * 64, 256), npairs), gcol(cdiv(max_m, 64), npairs);
+  // forward potentials, every iteration kept
+  for (int it = 0; it < n_iters; ++it) {
+    const float* vprev = it == 0 ? zero : V + (size_t)(it - 1) * T;
+    hipLaunchKernelGGL(k_row_lse, grow, dim3(256), 0, stream, mat, pd, U + (size_t)it * T, vprev, 1);
+    hipLaunchKernelGGL(k_col_lse, gcol, dim3(1024), 0, stream, mat, pd, V + (size_t)it * T,
+                       (const float*)(U + (size_t)it * T), 1);
+  }
+  const float* un = n_iters > 0 ? U + (size_t)(n_iters - 1) * T : zero;
+  const float* vn = n_iters > 0 ? V + (size_t)(n_iters - 1) * T : zero;
+  // final step: dA = gP * P, du_n, dv_n
+  hipLaunchKernelGGL(k_sk_bwd_final, grow, dim3(256), 0, stream, mat, dmat, pd, un, vn, xyz, dw, dthat, du);
+  hipLaunchKernelGGL(k_sk_colsum_neg, gcol, dim3(1024), 0, stream, dmat, pd, dva);
+  float* dv_cur = dva;
+  float* dv_prev = dvb;
+  for (int it = n_iters - 1; it >= 0; --it) {
+    const float* ut = U + (size_t)it * T;
+    const float* vt = V + (size_t)it * T;
+    // v_t = colLSE(A - u_t): adds to dA and to du_t
+    hipLaunchKernelGGL(k_sk_bwd_col, grow, dim3(256), 0, stream, mat, dmat, pd, ut, vt, (const float*)dv_cur, du);
+    // u_t = rowLSE(A - v_{t-1}): adds to dA, produces dv_{t-1} (v_0 = 0 is a constant)
+    const float* vprev = it == 0 ? nullptr : V + (size_t)(it - 1) * T;
+    hipLaunchKernelGGL(k_sk_bwd_row, gcol, dim3(1024), 0, stream, mat, dmat, pd, ut, vprev, (const float*)du,
+                       it == 0 ? (float*)nullptr : dv_prev);
+    if (it > 0) {
+      // du_{t-1} starts from zero: only v_{t-1} depends on it
+      SPR_HIP_CHECK(hipMemsetAsync(du, 0, sizeof(float) * T, stream));
+      float* t = dv_cur;
+      dv_cur = dv_prev;
+      dv_prev = t;
+    }
+  }
+  // affinity -> correlation, alpha, beta
+  const int nparts = 1024;
+  hipLaunchKernelGGL(k_affinity_bwd, dim3(nparts), dim3(256), 0, stream, corr, mat, dmat, total, scale, beta, parts);
+  hipLaunchKernelGGL(k_affinity_bwd_final, dim3(1), dim3(64), 0, stream, parts, nparts, alpha, beta, dalpha, dbeta);
+  // correlation -> features: dFs = dcorr Ft, dFt = dcorr^T Fs (exact-f32 batched GEMM, one launch per pair
+  // because the matrix row stride is the pair's own M)
+  hipLaunchKernelGGL(k_build_grad_recs, dim3(cdiv(npairs, 64)), dim3(64), 0, stream, pd, npairs, d, rs, rt);
+  SPR_LAUNCH_CHECK();
+  for (int b = 0; b < npairs; ++b) {
+    if (int rc = spr_bgemm(dmat, feat, dfeat, rs + b, 1, h[b].n, d, h[b].m, 1, d, 1, d, 1, 1.0f, 0.0f, stream_)) return rc;
+    if (int rc = spr_bgemm(dmat, feat, dfeat, rt + b, 1, h[b].m, d, 1, h[b].m, d, 1, d, 1, 1.0f, 0.0f, stream_)) return rc;
+  }
   return 0;
 }

@@ -147,6 +147,72 @@ __global__ void k_in_apply(const float* __restrict__ x, const int* __restrict__ 
   reinterpret_cast<float4*>(out)[gid] = v;
 }
 
+// ---- backward of out = lrelu(IN(x) + add, slope) (kpconv_blocks.py:510-525, :553-561, :741) -----
+// g = dout * (out >= 0 ? 1 : slope);  d add = g;
+// d x = rstd * (g - mean_n(g) - xhat * mean_n(g xhat)),  xhat = (x - mean) rstd   (per cloud, channel)
+// Same deterministic slicing as the forward statistics: partial sums of g and g*xhat in float64.
+__global__ __launch_bounds__(256) void k_in_bwd_stats(const float* __restrict__ x, const float* __restrict__ out,
+                                                      const float* __restrict__ dout, const int* __restrict__ cu,
+                                                      int c, int nsplit, float slope,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      double* __restrict__ part /*[nb][nsplit][2][c]*/) {
+  const int cloud = blockIdx.x, split = blockIdx.y;
+  const int beg = cu[cloud], end = cu[cloud + 1];
+  const int r0 = beg + split * kSliceRows;
+  const int r1 = min(r0 + kSliceRows, end);
+  // thread -> channel (strided), rows sequential: simple and deterministic
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    const float mu = mean[(size_t)cloud * c + ch], rs = rstd[(size_t)cloud * c + ch];
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = r0; r < r1; ++r) {
+      const size_t o = (size_t)r * c + ch;
+      const float g = dout[o] * (out[o] >= 0.f ? 1.f : slope);
+      s1 += (double)g;
+      s2 += (double)g * (double)((x[o] - mu) * rs);
+    }
+    double* p = part + (((size_t)cloud * nsplit + split) * 2) * c;
+    p[ch] = s1;
+    p[c + ch] = s2;
+  }
+}
+
+__global__ void k_in_bwd_final(const double* __restrict__ part, const int* __restrict__ cu, int nb, int c,
+                               int nsplit, float* __restrict__ m1, float* __restrict__ m2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb * c) return;
+  const int cloud = i / c, ch = i % c;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nsplit; ++k) {
+    const double* p = part + (((size_t)cloud * nsplit + k) * 2) * c;
+    s1 += p[ch];
+    s2 += p[c + ch];
+  }
+  const int len = cu[cloud + 1] - cu[cloud];
+  const double n = len > 0 ? (double)len : 1.0;
+  m1[i] = (float)(s1 / n);
+  m2[i] = (float)(s2 / n);
+}
+
+__global__ void k_in_bwd_apply(const float* __restrict__ x, const float* __restrict__ out,
+                               const float* __restrict__ dout, const int* __restrict__ cu, int n, int nb, int c,
+                               int norm, float slope, const float* __restrict__ mean,
+                               const float* __restrict__ rstd, const float* __restrict__ m1,
+                               const float* __restrict__ m2, float* __restrict__ dx, float* __restrict__ dadd) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)n * c) return;
+  const int row = (int)(gid / c), ch = (int)(gid % c);
+  const float g = dout[gid] * (out[gid] >= 0.f ? 1.f : slope);
+  if (dadd) dadd[gid] = g;
+  if (!norm) {
+    dx[gid] = g;
+    return;
+  }
+  const int cloud = find_segment(cu, nb, row);
+  const size_t s = (size_t)cloud * c + ch;
+  const float xh = (x[gid] - mean[s]) * rstd[s];
+  dx[gid] = rstd[s] * (g - m1[s] - xh * m2[s]);
+}
+
 __global__ void k_maxpool(const float* __restrict__ x, int ns, int c, const int* __restrict__ idx,
                           int nq, int idx_stride, int k, float* __restrict__ out) {
   const int c4 = c >> 2;
@@ -211,6 +277,46 @@ extern "C" int spr_instnorm(const float* x, const int* cu, int n, int nb, int ma
   const long total = (long)n * (c / 4);
   hipLaunchKernelGGL(k_in_apply, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, cu, n, nb, c,
                      norm, mean, rstd, add, slope, out);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t spr_instnorm_bwd_workspace_bytes(int max_len, int nb, int c) {
+  const size_t B = (size_t)(nb > 0 ? nb : 1), C = (size_t)(c > 0 ? c : 1);
+  return spr_instnorm_workspace_bytes(max_len, nb, c) + 2 * align_up(B * C * sizeof(float), 256);
+}
+
+// x: the forward input, out: the forward output (sign pattern of the LeakyReLU), dout: its gradient.
+// dx [n,c]; dadd [n,c] or NULL.
+extern "C" int spr_instnorm_bwd(const float* x, const float* out, const float* dout, const int* cu, int n, int nb,
+                                int max_len_host, int c, float eps, int norm, float slope, float* dx, float* dadd,
+                                void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(n > 0 && nb >= 1 && c >= 4 && c % 4 == 0, "instnorm_bwd: need n>0 and c %% 4 == 0 (c=%d)", c);
+  SPR_REQUIRE(x && out && dout && dx, "instnorm_bwd: null operand");
+  float *mean = nullptr, *rstd = nullptr, *m1 = nullptr, *m2 = nullptr;
+  if (norm) {
+    SPR_REQUIRE(max_len_host >= 1 && max_len_host <= n, "instnorm_bwd: bad max_len_host=%d", max_len_host);
+    SPR_REQUIRE(ws_bytes >= spr_instnorm_bwd_workspace_bytes(max_len_host, nb, c), "instnorm_bwd: workspace too small");
+    Workspace w(ws, ws_bytes);
+    const int nsplit = in_nsplit(max_len_host);
+    double* part = w.take<double>((size_t)nb * nsplit * 2 * c);
+    mean = w.take<float>((size_t)nb * c);
+    rstd = w.take<float>((size_t)nb * c);
+    m1 = w.take<float>((size_t)nb * c);
+    m2 = w.take<float>((size_t)nb * c);
+    SPR_REQUIRE(m2 != nullptr, "instnorm_bwd: workspace carve failed");
+    hipLaunchKernelGGL(k_in_stats, dim3(nb, nsplit, cdiv(c, 64)), dim3(256), 0, stream, x, cu, c, nsplit, part);
+    hipLaunchKernelGGL(k_in_final, dim3(cdiv((long)nb * c, 256)), dim3(256), 0, stream, part, cu, nb, c, nsplit,
+                       eps, mean, rstd);
+    hipLaunchKernelGGL(k_in_bwd_stats, dim3(nb, nsplit), dim3(256), 0, stream, x, out, dout, cu, c, nsplit, slope,
+                       mean, rstd, part);
+    hipLaunchKernelGGL(k_in_bwd_final, dim3(cdiv((long)nb * c, 256)), dim3(256), 0, stream, part, cu, nb, c, nsplit,
+                       m1, m2);
+    SPR_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_in_bwd_apply, dim3(cdiv((long)n * c, 256)), dim3(256), 0, stream, x, out, dout, cu, n, nb, c,
+                     norm, slope, mean, rstd, m1, m2, dx, dadd);
   SPR_LAUNCH_CHECK();
   return 0;
 }

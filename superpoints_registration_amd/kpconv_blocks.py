@@ -1,8 +1,8 @@
 """KPConv operator and block modules -- host-side mirror of the reference's
 ``src/models/backbone_kpconv/kpconv_blocks.py`` (same class names, constructor
 arguments, forward signatures and state-dict names), computing through the HIP
-library.  Forward only: the HIP backward kernels are a later row of the scope
-table, so tensors returned here carry no autograd graph.
+library.  Under torch.no_grad() (inference) the calls are plain C-ABI launches; with
+gradients enabled they go through the explicit HIP backward of autograd.py.
 
 Not mirrored (never selected by a shipped config):
 deformable / modulated KPConv, 'closest' aggregation, 'constant'/'gaussian'
@@ -106,7 +106,7 @@ class KPConv(nn.Module):
         return Parameter(torch.tensor(K_points_numpy, dtype=torch.float32), requires_grad=False)
 
     def forward(self, q_pts, s_pts, neighb_inds, x):
-        return ops.kpconv(q_pts, s_pts, neighb_inds, x, self.weights.detach(),
+        return ops.kpconv(q_pts, s_pts, neighb_inds, x, self.weights,
                           self.kernel_points.detach(), self.KP_extent,
                           rows_sorted=self.rows_sorted, impl=self.impl)
 
@@ -147,7 +147,7 @@ class BatchNormBlock(nn.Module):
             cu = ops.lengths_to_cu(stack_lengths, x.device)
         if self.use_bn:
             return ops.instnorm(x, cu, eps=self.eps, norm=True, add=add, slope=slope, max_len=max_len)
-        y = x + self.bias.detach()
+        y = x + self.bias
         return ops.instnorm(y, cu, norm=False, add=add, slope=slope, max_len=max_len)
 
     def __repr__(self):
@@ -173,7 +173,7 @@ class UnaryBlock(nn.Module):
     def forward(self, x, stack_lengths=None, cu=None, add=None, final_slope=None, max_len=None):
         """out = act(norm(x W^T) [+ add]); `add` / `final_slope` let the
         bottleneck block fuse its residual add + LeakyReLU into this pass."""
-        y = ops.linear(x, self.mlp.weight.detach())
+        y = ops.linear(x, self.mlp.weight)
         slope = 1.0 if self.no_relu else 0.1
         if final_slope is not None:
             slope = final_slope

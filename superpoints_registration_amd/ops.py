@@ -118,9 +118,25 @@ def radius_neighbors(queries: torch.Tensor, supports: torch.Tensor, q_cu: torch.
     return out[:, :min(m, limit)], m
 
 
+def _wants_grad(*tensors) -> bool:
+    """True when the call must go through autograd.py (gradients enabled and asked for)."""
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
 def kpconv(q_pts, s_pts, nbr, x, weights, kernel_points, kp_extent: float, rows_sorted: bool = False,
            impl: int = 0) -> torch.Tensor:
-    """a4.  nbr may be int32 or int64 [Nq, K] (possibly a column slice)."""
+    """a4.  nbr may be int32 or int64 [Nq, K] (possibly a column slice).  Differentiable in x and
+    weights (autograd.KPConvFn)."""
+    if _wants_grad(x, weights):
+        from .autograd import KPConvFn
+        return KPConvFn.apply(_dev(q_pts, "q_pts", torch.float32), _dev(s_pts, "s_pts", torch.float32), nbr,
+                              _dev(x, "x", torch.float32), weights, kernel_points, float(kp_extent),
+                              bool(rows_sorted), int(impl))
+    return kpconv_raw(q_pts, s_pts, nbr, x, weights, kernel_points, kp_extent, rows_sorted, impl)
+
+
+def kpconv_raw(q_pts, s_pts, nbr, x, weights, kernel_points, kp_extent: float, rows_sorted: bool = False,
+               impl: int = 0) -> torch.Tensor:
     q_pts = _dev(q_pts, "q_pts", torch.float32)
     s_pts = _dev(s_pts, "s_pts", torch.float32)
     x = _dev(x, "x", torch.float32)
@@ -151,7 +167,16 @@ def instnorm(x, cu, eps: float = 1e-5, norm: bool = True, add=None, slope: float
              out=None, max_len: Optional[int] = None) -> torch.Tensor:
     """a5.  out = lrelu(InstanceNorm_per_cloud(x) + add, slope).  max_len: host
     upper bound of the longest cloud (defaults to n: correct, just a larger
-    statistics grid)."""
+    statistics grid).  Differentiable in x and add (autograd.InstNormFn)."""
+    if _wants_grad(x, add):
+        from .autograd import InstNormFn
+        return InstNormFn.apply(_dev(x, "x", torch.float32), _dev(cu, "cu", torch.int32), float(eps), bool(norm),
+                                None if add is None else _dev(add, "add", torch.float32), float(slope), max_len)
+    return instnorm_raw(x, cu, eps, norm, add, slope, out, max_len)
+
+
+def instnorm_raw(x, cu, eps: float = 1e-5, norm: bool = True, add=None, slope: float = 1.0,
+                 out=None, max_len: Optional[int] = None) -> torch.Tensor:
     x = _dev(x, "x", torch.float32)
     cu = _dev(cu, "cu", torch.int32)
     n, c = x.shape
@@ -171,6 +196,13 @@ def instnorm(x, cu, eps: float = 1e-5, norm: bool = True, add=None, slope: float
 
 
 def maxpool(x, idx) -> torch.Tensor:
+    if _wants_grad(x):
+        from .autograd import MaxPoolFn
+        return MaxPoolFn.apply(_dev(x, "x", torch.float32), idx)
+    return maxpool_raw(x, idx)
+
+
+def maxpool_raw(x, idx) -> torch.Tensor:
     x = _dev(x, "x", torch.float32)
     if idx.dtype != torch.int32:
         idx = idx.to(torch.int32)
@@ -187,6 +219,14 @@ def maxpool(x, idx) -> torch.Tensor:
 
 
 def linear(x, weight, bias=None, residual=None, act: int = ACT_NONE) -> torch.Tensor:
+    """act(x W^T + bias + residual).  Differentiable in all four tensors (autograd.LinearFn)."""
+    if _wants_grad(x, weight, bias, residual):
+        from .autograd import LinearFn
+        return LinearFn.apply(_dev(x, "x", torch.float32), weight, bias, residual, int(act))
+    return linear_raw(x, weight, bias, residual, act)
+
+
+def linear_raw(x, weight, bias=None, residual=None, act: int = ACT_NONE) -> torch.Tensor:
     x = _dev(x, "x", torch.float32)
     weight = _dev(weight, "weight", torch.float32)
     m, k = x.shape
@@ -211,7 +251,16 @@ def set_gemm_mode(mode: int) -> None:
 
 
 def layernorm(x, gamma, beta, eps: float = 1e-5, pos=None, want_norm: bool = True):
-    """Returns (LN(x) or None, LN(x)+pos or None)."""
+    """Returns (LN(x) or None, LN(x)+pos or None).  Differentiable in x, gamma, beta
+    (autograd.LayerNormFn)."""
+    if _wants_grad(x, gamma, beta):
+        from .autograd import LayerNormFn
+        n, p = LayerNormFn.apply(_dev(x, "x", torch.float32), gamma, beta, float(eps), pos, bool(want_norm))
+        return (n if (want_norm or pos is None) else None), (p if pos is not None else None)
+    return layernorm_raw(x, gamma, beta, eps, pos, want_norm)
+
+
+def layernorm_raw(x, gamma, beta, eps: float = 1e-5, pos=None, want_norm: bool = True):
     x = _dev(x, "x", torch.float32)
     m, c = x.shape
     out_norm = torch.empty_like(x) if want_norm else None
@@ -235,9 +284,24 @@ def posemb_sine(xyz, d_model: int, scale: float = 1.0, temperature: float = 1000
     return out
 
 
-def attention(q, k, v, cu, kv_seg, max_len: int, nhead: int, out=None) -> torch.Tensor:
+def attention(q, k, v, cu, kv_seg, max_len: int, nhead: int, out=None, lens_host=None,
+              kv_seg_host=None) -> torch.Tensor:
     """a9.  q,k,v: [T, nhead*32] views (row stride may exceed the width, e.g.
-    slices of a fused [T, 3*d] projection)."""
+    slices of a fused [T, 3*d] projection).  Differentiable in q, k, v (autograd.AttentionFn;
+    needs the host-side segment lengths / kv map, read back from the device if not given)."""
+    if _wants_grad(q, k, v):
+        from .autograd import AttentionFn
+        if lens_host is None:
+            c = cu.cpu().tolist()
+            lens_host = [c[i + 1] - c[i] for i in range(len(c) - 1)]
+        if kv_seg_host is None:
+            kv_seg_host = kv_seg.cpu().tolist()
+        return AttentionFn.apply(q, k, v, _dev(cu, "cu", torch.int32), _dev(kv_seg, "kv_seg", torch.int32),
+                                 int(max_len), int(nhead), list(lens_host), list(kv_seg_host))
+    return attention_raw(q, k, v, cu, kv_seg, max_len, nhead, out)
+
+
+def attention_raw(q, k, v, cu, kv_seg, max_len: int, nhead: int, out=None) -> torch.Tensor:
     for t, nm in ((q, "q"), (k, "k"), (v, "v")):
         if not t.is_cuda or t.dtype != torch.float32 or t.stride(1) != 1:
             raise RuntimeError(f"attention: {nm} must be a float32 device tensor with unit inner stride")
@@ -290,7 +354,16 @@ def _cu_host_arr(cu_host: Sequence[int]):
 
 
 def match_dualsoftmax(feat, cu, cu_host: Sequence[int], npairs: int):
-    """a11.  Returns (val [T] f32, ind [T] i32) -- see include/spr.h."""
+    """a11.  Returns (val [T] f32, ind [T] i32) -- see include/spr.h.  val is differentiable in
+    feat (autograd.MatchDualSoftmaxFn)."""
+    if _wants_grad(feat):
+        from .autograd import MatchDualSoftmaxFn
+        return MatchDualSoftmaxFn.apply(_dev(feat, "feat", torch.float32), _dev(cu, "cu", torch.int32),
+                                        list(cu_host), int(npairs))
+    return match_dualsoftmax_raw(feat, cu, cu_host, npairs)
+
+
+def match_dualsoftmax_raw(feat, cu, cu_host: Sequence[int], npairs: int):
     feat = _dev(feat, "feat", torch.float32)
     cu = _dev(cu, "cu", torch.int32)
     T, d = feat.shape
@@ -315,7 +388,21 @@ def _dev_scalar(v, device) -> torch.Tensor:
 def sinkhorn_correspondences(feat, xyz, cu, cu_host: Sequence[int], npairs: int, alpha,
                              beta, n_iters: int, slack: bool = True):
     """a13.  Returns (w [Tsrc] f32, t_hat [Tsrc,3] f32) for the src tokens.  alpha / beta:
-    device tensors (the model's parameters -- read on the device, no sync) or floats."""
+    device tensors (the model's parameters -- read on the device, no sync) or floats.
+    Differentiable in feat, alpha, beta (autograd.SinkhornFn)."""
+    if _wants_grad(feat, alpha, beta):
+        from .autograd import SinkhornFn
+        dev = feat.device
+        a = alpha if isinstance(alpha, torch.Tensor) else torch.tensor(float(alpha), device=dev)
+        b = beta if isinstance(beta, torch.Tensor) else torch.tensor(float(beta), device=dev)
+        return SinkhornFn.apply(_dev(feat, "feat", torch.float32), _dev(xyz, "xyz", torch.float32),
+                                _dev(cu, "cu", torch.int32), list(cu_host), int(npairs), a, b, int(n_iters),
+                                bool(slack))
+    return sinkhorn_correspondences_raw(feat, xyz, cu, cu_host, npairs, alpha, beta, n_iters, slack)
+
+
+def sinkhorn_correspondences_raw(feat, xyz, cu, cu_host: Sequence[int], npairs: int, alpha,
+                                 beta, n_iters: int, slack: bool = True):
     feat = _dev(feat, "feat", torch.float32)
     alpha_t, beta_t = _dev_scalar(alpha, feat.device), _dev_scalar(beta, feat.device)
     xyz = _dev(xyz, "xyz", torch.float32)
@@ -335,7 +422,16 @@ def sinkhorn_correspondences(feat, xyz, cu, cu_host: Sequence[int], npairs: int,
 
 
 def weighted_procrustes(a, b, w, pair_cu) -> torch.Tensor:
-    """a12.  a,b [T,3], w [T] or None, pair_cu int32 [P+1] -> [P,3,4]."""
+    """a12.  a,b [T,3], w [T] or None, pair_cu int32 [P+1] -> [P,3,4].  Differentiable in a, b, w
+    (autograd.ProcrustesFn)."""
+    if _wants_grad(a, b, w):
+        from .autograd import ProcrustesFn
+        return ProcrustesFn.apply(_dev(a, "a", torch.float32), _dev(b, "b", torch.float32),
+                                  None if w is None else _dev(w, "w", torch.float32), _dev(pair_cu, "pair_cu", torch.int32))
+    return weighted_procrustes_raw(a, b, w, pair_cu)
+
+
+def weighted_procrustes_raw(a, b, w, pair_cu) -> torch.Tensor:
     a = _dev(a, "a", torch.float32)
     b = _dev(b, "b", torch.float32)
     if w is not None:
@@ -365,6 +461,13 @@ def _loss_ws(n, m, d, device):
 
 
 def bce_logits_mean(x, y):
+    if _wants_grad(x):
+        from .autograd import BCELogitsMeanFn
+        return BCELogitsMeanFn.apply(_dev(x, "x", torch.float32), _dev(y, "y", torch.float32))
+    return bce_logits_mean_raw(x, y)
+
+
+def bce_logits_mean_raw(x, y):
     x = _dev(x, "x", torch.float32)
     y = _dev(y, "y", torch.float32)
     assert x.shape == y.shape and x.dim() == 1
@@ -376,7 +479,17 @@ def bce_logits_mean(x, y):
 
 
 def infonce_pair(anchor_feat, positive_feat, anchor_xyz, pose_gt, positive_xyz, W, r_p: float, r_n: float):
-    """InfoNCELossFull.compute_infonce for one pair; anchor_xyz is transformed by pose_gt [3,4] inside."""
+    """InfoNCELossFull.compute_infonce for one pair; anchor_xyz is transformed by pose_gt [3,4] inside.
+    Differentiable in the two feature sets and W (autograd.InfoNCEFn)."""
+    if _wants_grad(anchor_feat, positive_feat, W):
+        from .autograd import InfoNCEFn
+        return InfoNCEFn.apply(_dev(anchor_feat, "anchor_feat", torch.float32),
+                               _dev(positive_feat, "positive_feat", torch.float32), anchor_xyz, pose_gt, positive_xyz,
+                               W, float(r_p), float(r_n))
+    return infonce_pair_raw(anchor_feat, positive_feat, anchor_xyz, pose_gt, positive_xyz, W, r_p, r_n)
+
+
+def infonce_pair_raw(anchor_feat, positive_feat, anchor_xyz, pose_gt, positive_xyz, W, r_p: float, r_n: float):
     a = _dev(anchor_feat, "anchor_feat", torch.float32)
     p = _dev(positive_feat, "positive_feat", torch.float32)
     n, d = a.shape
@@ -392,6 +505,13 @@ def infonce_pair(anchor_feat, positive_feat, anchor_xyz, pose_gt, positive_xyz, 
 
 
 def transform_l1_pair(pose_gt, pose_pred, xyz):
+    if _wants_grad(pose_pred):
+        from .autograd import TransformL1Fn
+        return TransformL1Fn.apply(_dev(pose_gt, "pose_gt", torch.float32), pose_pred, _dev(xyz, "xyz", torch.float32))
+    return transform_l1_pair_raw(pose_gt, pose_pred, xyz)
+
+
+def transform_l1_pair_raw(pose_gt, pose_pred, xyz):
     xyz = _dev(xyz, "xyz", torch.float32)
     out = torch.empty((1,), dtype=torch.float32, device=xyz.device)
     ws = _loss_ws(xyz.shape[0], 1, 32, xyz.device)
@@ -411,6 +531,13 @@ def sum_scaled(values, scale: float = 1.0):
 
 
 def gather_rows(x, idx) -> torch.Tensor:
+    if _wants_grad(x):
+        from .autograd import GatherRowsFn
+        return GatherRowsFn.apply(_dev(x, "x", torch.float32), _dev(idx, "idx", torch.int32))
+    return gather_rows_raw(x, idx)
+
+
+def gather_rows_raw(x, idx) -> torch.Tensor:
     x = _dev(x, "x", torch.float32)
     idx = _dev(idx, "idx", torch.int32)
     n_src, c = x.shape

@@ -11,7 +11,10 @@ Differences by design (documented in DESIGN.md):
     entry is a list of None unless `return_attn=True`;
   * config-off refinements (LGR, RANSAC, ratio test, overlap weighting, top-k
     pruning, attention/correlation affinity) raise NotImplementedError;
-  * forward only -- compute_loss / backward are the "next" rows.
+  * training: with gradients enabled every operator runs through its explicit HIP backward
+    (autograd.py), so `compute_loss(model(batch), batch)['total'].backward()` fills the
+    same parameter gradients as the reference's training_step (generic_reg_model.py:82-84);
+    under torch.no_grad() the forward is the plain inference path.
 """
 import torch
 import torch.nn as nn
@@ -71,11 +74,20 @@ class RegTR(nn.Module):
             self.feature_criterion_un = _BilinearW(cfg.d_embed)
 
     # ------------------------------------------------------------------ #
-    @torch.no_grad()
     def forward(self, batch):
+        """model.train() + gradients enabled: differentiable (HIP backward, autograd.py).
+        model.eval() (the reference's test loop, trainer.py:216-260) or torch.no_grad():
+        the inference path -- fused in-projection, no tape, nothing saved."""
+        if not self.training and torch.is_grad_enabled():
+            with torch.no_grad():
+                return self._forward(batch)
+        return self._forward(batch)
+
+    def _forward(self, batch):
         cfg = self.cfg
         B = len(batch['src_xyz'])
-        meta = self.preprocessor(list(batch['src_xyz']) + list(batch['tgt_xyz']))
+        with torch.no_grad():   # index work: never differentiated (qk_regtr_full.py:152)
+            meta = self.preprocessor(list(batch['src_xyz']) + list(batch['tgt_xyz']))
         batch['kpconv_meta'] = meta                      # qk_regtr_full.py:153
         lens_c = meta['_lens_host'][-1]
         src_lens, tgt_lens = lens_c[:B], lens_c[B:]
@@ -85,16 +97,19 @@ class RegTR(nn.Module):
         # KPConv encoder on a column of ones (qk_regtr_full.py:157-166)
         feats0 = torch.ones((meta['points'][0].shape[0], 1), dtype=torch.float32, device=device)
         feats_un, _ = self.kpf_encoder(feats0, meta)
-        tokens = ops.linear(feats_un, self.feat_proj.weight.detach(), self.feat_proj.bias.detach())
+        tokens = ops.linear(feats_un, self.feat_proj.weight, self.feat_proj.bias)
 
         # superpoint attention on packed tokens (qk_regtr_full.py:199-230)
         pe = self.pos_embed(xyz_c) if cfg.transformer_encoder_has_pos_emb else None
         cu, seg_self, seg_cross, max_len = make_segments(src_lens, tgt_lens, device)
-        cond = self.transformer_encoder.forward_packed(tokens, cu, seg_self, seg_cross, max_len, pos=pe)
+        seg_host = ([int(n) for n in list(src_lens) + list(tgt_lens)], list(range(2 * B)),
+                    list(range(B, 2 * B)) + list(range(B)))
+        cond = self.transformer_encoder.forward_packed(tokens, cu, seg_self, seg_cross, max_len, pos=pe,
+                                                       seg_host=seg_host)
 
         # overlap head (qk_regtr_full.py:248-249)
-        overlap = ops.linear(cond, self.overlap_predictor.weight.detach(),
-                             self.overlap_predictor.bias.detach(), act=ops.ACT_SIGMOID)
+        overlap = ops.linear(cond, self.overlap_predictor.weight, self.overlap_predictor.bias,
+                             act=ops.ACT_SIGMOID)
 
         # matching + pose (qk_regtr_full.py:423-672), all pairs at once
         cu_host = [0]
@@ -155,14 +170,13 @@ class RegTR(nn.Module):
         }
 
     # ------------------------------------------------------------------ #
-    @torch.no_grad()
     def compute_loss(self, pred, batch):
         """Forward of RegTR.compute_loss (qk_regtr_full.py:313-368): overlap BCE on the
         coarsest level of compute_overlaps, InfoNCE feature loss against the ground-truth
         transformed keypoints, L1 transform loss; total = T + 0.1 feature + overlap.
         batch needs 'pose' [B,3,4], 'src_overlap' / 'tgt_overlap' (per-point masks) and the
-        'kpconv_meta' a forward left there.  Values only: no autograd graph (backward is
-        the next row)."""
+        'kpconv_meta' a forward left there.  Differentiable when `pred` came from a forward with
+        gradients enabled: losses['total'].backward() then runs the HIP backward (autograd.py)."""
         cfg = self.cfg
         if cfg.get('feature_loss_type', 'infonce') != 'infonce':
             raise NotImplementedError("only the InfoNCE feature loss is selected by the shipped configs")
@@ -174,18 +188,19 @@ class RegTR(nn.Module):
         pose_gt = batch['pose'].to(device=device, dtype=torch.float32).contiguous()
 
         # compute_overlaps (kpconv.py:552-578): average the per-point masks up the pyramid
-        ov = torch.cat([o.to(device) for o in list(batch['src_overlap']) + list(batch['tgt_overlap'])]).float()
-        pyr = {'pyr_0': ov}
-        for p in range(1, len(meta['points'])):
-            ov = ops.overlap_pool(ov, meta['_i32'][('pools', p - 1)], meta['points'][p - 1].shape[0])
-            pyr[f'pyr_{p}'] = ov
-        batch['overlap_pyr'] = pyr
+        with torch.no_grad():   # ground-truth side: no gradient
+            ov = torch.cat([o.to(device) for o in list(batch['src_overlap']) + list(batch['tgt_overlap'])]).float()
+            pyr = {'pyr_0': ov}
+            for p in range(1, len(meta['points'])):
+                ov = ops.overlap_pool(ov, meta['_i32'][('pools', p - 1)], meta['points'][p - 1].shape[0])
+                pyr[f'pyr_{p}'] = ov
+            batch['overlap_pyr'] = pyr
 
         # overlap loss: the (already sigmoided) predictions go through BCEWithLogits (:248, :329)
         pred_ov = torch.cat([o[0, :, 0] for o in list(pred['src_overlap']) + list(pred['tgt_overlap'])])
         losses = {'overlap': ops.bce_logits_mean(pred_ov.contiguous(), ov)}
 
-        W = self.feature_criterion.W.detach()
+        W = self.feature_criterion.W
         feat, t_l1 = [], []
         # the reference overwrites `feature_loss` for every entry of feature_loss_on
         # (qk_regtr_full.py:340-345): only the LAST index contributes
@@ -196,8 +211,12 @@ class RegTR(nn.Module):
                                              pred['src_kp'][b].contiguous(), pose_gt[b], pred['tgt_kp'][b].contiguous(),
                                              W, cfg.r_p, cfg.r_n))
             t_l1.append(ops.transform_l1_pair(pose_gt[b], pred['pose'][b].contiguous(), pred['src_kp'][b].contiguous()))
-        losses['feature'] = ops.sum_scaled(torch.stack(feat), 1.0 / len(feat))      # mean over pairs (:314)
-        losses['T'] = ops.sum_scaled(torch.stack(t_l1), 1.0)                        # sum over pairs (:353)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in feat + t_l1):
+            losses['feature'] = torch.stack(feat).mean()                            # on the tape
+            losses['T'] = torch.stack(t_l1).sum()
+        else:
+            losses['feature'] = ops.sum_scaled(torch.stack(feat), 1.0 / len(feat))  # mean over pairs (:314)
+            losses['T'] = ops.sum_scaled(torch.stack(t_l1), 1.0)                    # sum over pairs (:353)
         losses['total'] = losses['T'] + 0.1 * losses['feature'] + losses['overlap']
         return losses
 

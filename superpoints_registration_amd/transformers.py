@@ -105,12 +105,13 @@ class TransformerCrossEncoderLayer(nn.Module):
         self.satt_weights, self.xatt_weights = None, None  # never materialised here
 
     # -- one MHA over packed tokens: in_proj GEMM, attention core, out_proj GEMM (+ residual)
-    def _mha(self, mha: nn.MultiheadAttention, qk_in, v_in, cu, kv_seg, max_len, residual):
+    def _mha(self, mha: nn.MultiheadAttention, qk_in, v_in, cu, kv_seg, max_len, residual, seg_host=None):
         d = self.d_model
-        W, b = mha.in_proj_weight.detach(), mha.in_proj_bias.detach()
-        if d == 256:
-            # in-projection GEMM writes the attention operand planes directly
-            o = ops.attention_inproj(qk_in, v_in, W, b, cu, kv_seg, max_len, self.nhead)
+        W, b = mha.in_proj_weight, mha.in_proj_bias
+        training = torch.is_grad_enabled() and (qk_in.requires_grad or W.requires_grad)
+        if d == 256 and not training:
+            # in-projection GEMM writes the attention operand planes directly (inference path)
+            o = ops.attention_inproj(qk_in, v_in, W.detach(), b.detach(), cu, kv_seg, max_len, self.nhead)
         else:
             if v_in is qk_in:
                 qkv = ops.linear(qk_in, W, b)                      # [T, 3d]
@@ -119,43 +120,46 @@ class TransformerCrossEncoderLayer(nn.Module):
                 qk = ops.linear(qk_in, W[:2 * d], b[:2 * d])       # [T, 2d]
                 q, k = qk[:, :d], qk[:, d:]
                 v = ops.linear(v_in, W[2 * d:], b[2 * d:])
-            o = ops.attention(q, k, v, cu, kv_seg, max_len, self.nhead)
-        return ops.linear(o, mha.out_proj.weight.detach(), mha.out_proj.bias.detach(),
-                          residual=residual)
+            lens_host, kv_host = seg_host if seg_host is not None else (None, None)
+            o = ops.attention(q, k, v, cu, kv_seg, max_len, self.nhead, lens_host=lens_host, kv_seg_host=kv_host)
+        return ops.linear(o, mha.out_proj.weight, mha.out_proj.bias, residual=residual)
 
     def _ln(self, norm: nn.LayerNorm, x, pos, need_plain):
-        plain, with_pos = ops.layernorm(x, norm.weight.detach(), norm.bias.detach(), norm.eps,
+        plain, with_pos = ops.layernorm(x, norm.weight, norm.bias, norm.eps,
                                         pos=pos, want_norm=need_plain or pos is None)
         return plain, (with_pos if pos is not None else plain)
 
-    def forward_packed(self, x, cu, seg_self, seg_cross, max_len, pos=None):
+    def forward_packed(self, x, cu, seg_self, seg_cross, max_len, pos=None, seg_host=None):
         """x: [T, d] packed tokens of all 2B clouds; returns the updated tokens.
-        Pre-norm (transformers.py:184-245) or post-norm (:124-182)."""
+        Pre-norm (transformers.py:184-245) or post-norm (:124-182).  seg_host: optional
+        (lens, self map, cross map) host lists -- spares the attention backward a device read."""
+        sh_self = (seg_host[0], seg_host[1]) if seg_host is not None else None
+        sh_cross = (seg_host[0], seg_host[2]) if seg_host is not None else None
         if self.normalize_before:
             # self attention (same weights for src and tgt clouds)
             x2, x2p = self._ln(self.norm1, x, pos, need_plain=not self.sa_val_has_pos_emb)
             x = self._mha(self.self_attn, x2p, x2p if self.sa_val_has_pos_emb else x2, cu, seg_self,
-                          max_len, residual=x)
+                          max_len, residual=x, seg_host=sh_self)
             # cross attention (keys/values from the partner cloud)
             x2, x2p = self._ln(self.norm2, x, pos, need_plain=not self.ca_val_has_pos_emb)
             x = self._mha(self.multihead_attn, x2p, x2p if self.ca_val_has_pos_emb else x2, cu,
-                          seg_cross, max_len, residual=x)
+                          seg_cross, max_len, residual=x, seg_host=sh_cross)
             # feed forward
             x2, _ = self._ln(self.norm3, x, None, need_plain=True)
-            h = ops.linear(x2, self.linear1.weight.detach(), self.linear1.bias.detach(), act=ops.ACT_RELU)
-            x = ops.linear(h, self.linear2.weight.detach(), self.linear2.bias.detach(), residual=x)
+            h = ops.linear(x2, self.linear1.weight, self.linear1.bias, act=ops.ACT_RELU)
+            x = ops.linear(h, self.linear2.weight, self.linear2.bias, residual=x)
             return x
         # post-norm
         xp = x + pos if pos is not None else x
         y = self._mha(self.self_attn, xp, xp if self.sa_val_has_pos_emb else x, cu, seg_self, max_len,
-                      residual=x)
+                      residual=x, seg_host=sh_self)
         x, _ = self._ln(self.norm1, y, None, True)
         xp = x + pos if pos is not None else x
         y = self._mha(self.multihead_attn, xp, xp if self.ca_val_has_pos_emb else x, cu, seg_cross,
-                      max_len, residual=x)
+                      max_len, residual=x, seg_host=sh_cross)
         x, _ = self._ln(self.norm2, y, None, True)
-        h = ops.linear(x, self.linear1.weight.detach(), self.linear1.bias.detach(), act=ops.ACT_RELU)
-        y = ops.linear(h, self.linear2.weight.detach(), self.linear2.bias.detach(), residual=x)
+        h = ops.linear(x, self.linear1.weight, self.linear1.bias, act=ops.ACT_RELU)
+        y = ops.linear(h, self.linear2.weight, self.linear2.bias, residual=x)
         x, _ = self._ln(self.norm3, y, None, True)
         return x
 
@@ -188,11 +192,11 @@ class TransformerCrossEncoder(nn.Module):
         self.norm = norm
         self.return_intermediate = return_intermediate
 
-    def forward_packed(self, x, cu, seg_self, seg_cross, max_len, pos=None):
+    def forward_packed(self, x, cu, seg_self, seg_cross, max_len, pos=None, seg_host=None):
         for layer in self.layers:
-            x = layer.forward_packed(x, cu, seg_self, seg_cross, max_len, pos=pos)
+            x = layer.forward_packed(x, cu, seg_self, seg_cross, max_len, pos=pos, seg_host=seg_host)
         if self.norm is not None:
-            x, _ = ops.layernorm(x, self.norm.weight.detach(), self.norm.bias.detach(), self.norm.eps)
+            x, _ = ops.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x
 
     def forward(self, src, tgt, src_mask: Optional[Tensor] = None, tgt_mask: Optional[Tensor] = None,

@@ -181,10 +181,17 @@ def test_transformer_layer_packed_vs_reference(gold, inp, device):
     x = torch.cat(inp["tl.src"] + inp["tl.tgt"]).to(device)
     pe = torch.cat(inp["tl.src_pe"] + inp["tl.tgt_pe"]).to(device)
     cu, s_self, s_cross, mx = make_segments(inp["tl.s_l"], inp["tl.t_l"], device)
-    y = layer.forward_packed(x, cu, s_self, s_cross, mx, pos=pe).cpu().numpy()
     ns = sum(inp["tl.s_l"])
+    with torch.no_grad():                                      # inference path (fused in-projection)
+        y = layer.forward_packed(x, cu, s_self, s_cross, mx, pos=pe).cpu().numpy()
     _close(y[:ns], gold["tl.src_out"], 2e-5, "layer src")     # conditioned features <= 2e-5 rel
     _close(y[ns:], gold["tl.tgt_out"], 2e-5, "layer tgt")
+    # training path (gradients enabled: autograd Functions, unfused projection + attention core)
+    yt = layer.forward_packed(x, cu, s_self, s_cross, mx, pos=pe)
+    assert yt.requires_grad
+    yt = yt.detach().cpu().numpy()
+    _close(yt[:ns], gold["tl.src_out"], 2e-5, "layer src (training path)")
+    _close(yt[ns:], gold["tl.tgt_out"], 2e-5, "layer tgt (training path)")
 
 
 @pytest.mark.parametrize("tag,pre,pe", [("post", False, True), ("post_nope", False, False), ("pre_nope", True, False)])
@@ -197,7 +204,8 @@ def test_transformer_layer_post_norm_and_value_without_pos(inp, device, tag, pre
     x = torch.cat(inp["tl.src"] + inp["tl.tgt"]).to(device)
     pos = torch.cat(inp["tl.src_pe"] + inp["tl.tgt_pe"]).to(device)
     cu, s_self, s_cross, mx = make_segments(inp["tl.s_l"], inp["tl.t_l"], device)
-    y = layer.forward_packed(x, cu, s_self, s_cross, mx, pos=pos).cpu().numpy()
+    with torch.no_grad():
+        y = layer.forward_packed(x, cu, s_self, s_cross, mx, pos=pos).cpu().numpy()
     ns = sum(inp["tl.s_l"])
     _close(y[:ns], gold[f"tl.{tag}.src_out"], 2e-5, f"layer {tag} src")
     _close(y[ns:], gold[f"tl.{tag}.tgt_out"], 2e-5, f"layer {tag} tgt")
@@ -210,7 +218,8 @@ def test_transformer_reference_signature_padded(gold, inp, device):
     tp, tm, _ = pad_sequence([t.to(device) for t in inp["tl.tgt"]], require_padding_mask=True)
     spp, _, _ = pad_sequence([t.to(device) for t in inp["tl.src_pe"]])
     tpp, _, _ = pad_sequence([t.to(device) for t in inp["tl.tgt_pe"]])
-    so, to = enc(sp, tp, src_key_padding_mask=sm, tgt_key_padding_mask=tm, src_pos=spp, tgt_pos=tpp)
+    with torch.no_grad():
+        so, to = enc(sp, tp, src_key_padding_mask=sm, tgt_key_padding_mask=tm, src_pos=spp, tgt_pos=tpp)
     assert so.shape == (1, 50, 2, 256) and to.shape == (1, 45, 2, 256)
     _close(torch.cat(unpad_sequences(so, inp["tl.s_l"]), dim=1)[0].cpu().numpy(), gold["tl.src_out"], 2e-5, "padded src")
     _close(torch.cat(unpad_sequences(to, inp["tl.t_l"]), dim=1)[0].cpu().numpy(), gold["tl.tgt_out"], 2e-5, "padded tgt")

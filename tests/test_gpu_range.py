@@ -235,3 +235,49 @@ def test_attention_mode2_single_pass_fp16(device, shared):
         assert err >= 1e-6 * float(ref.abs().max()), "mode 2 is suspiciously exact: is the hi-only kernel running?"
     finally:
         ops.set_attn_mode(1)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("pattern", ["rising", "falling", "spike_late", "flat_then_huge"])
+def test_attention_deferred_max_recentring(device, mode, pattern):
+    """The attention core keeps a per-query reference exponent that is only moved when a later
+    key tile would push exp2(s - ref) past fp16's range (attention.hip, "defer-max").  These key
+    orders force that rare path: scores rising by > 2^5 from tile to tile, a late spike, and the
+    reverse (a huge first tile followed by negligible ones)."""
+    ops.set_attn_mode(mode)
+    try:
+        lens = [700, 333]
+        kv_seg = [0, 1]
+        tot = sum(lens)
+        g = torch.Generator().manual_seed(5)
+        q = torch.randn((tot, 256), generator=g)
+        k = torch.randn((tot, 256), generator=g) * 0.3
+        v = torch.randn((tot, 256), generator=g)
+        offs = [0, lens[0], tot]
+        for s_ in range(2):
+            n = lens[s_]
+            j = torch.arange(n, dtype=torch.float32) / n
+            if pattern == "rising":
+                gain = 0.2 + 6.0 * j                       # scores grow along the key axis
+            elif pattern == "falling":
+                gain = 6.2 - 6.0 * j
+            elif pattern == "spike_late":
+                gain = torch.full((n,), 0.3)
+                gain[int(0.8 * n)] = 9.0
+            else:
+                gain = torch.full((n,), 0.05)
+                gain[n - 3:] = 12.0
+            k[offs[s_]:offs[s_ + 1]] *= gain.unsqueeze(1)
+        cu = ops.lengths_to_cu(lens, device)
+        seg = torch.tensor(kv_seg, dtype=torch.int32, device=device)
+        o = ops.attention(q.to(device), k.to(device), v.to(device), cu, seg, max(lens), 8).cpu()
+        ref = _attn_ref(q, k, v, lens, kv_seg, torch.float64)
+        ref32 = _attn_ref(q, k, v, lens, kv_seg, torch.float32).double()
+        scale = float(ref.abs().max())
+        err = float((o.double() - ref).abs().max())
+        err32 = float((ref32 - ref).abs().max())
+        tol = 3e-6 if mode == 1 else 3e-3
+        assert torch.isfinite(o).all()
+        assert err <= max(tol * scale, 4 * err32), f"{pattern} mode {mode}: {err:.3e} (fp32 {err32:.3e}, scale {scale:.3e})"
+    finally:
+        ops.set_attn_mode(1)
