@@ -338,6 +338,54 @@ def gen_grad(cfg_tag, B=2):
     print(os.path.basename(path), os.path.getsize(path) // 1024, 'KB', {k: float(v) for k, v in losses.items()})
 
 
+def gen_train(cfg_tag='3dmatch', B=2, steps=2):
+    """Two steps of the reference's training loop on one batch (trainer.py:107-124: zero_grad ->
+    backward -> clip_grad_norm_(grad_clip) -> AdamW step -> StepLR step, optimiser built by
+    generic_reg_model.py:46-76 from the YAML) and the reference's validation metrics
+    (generic_reg_model.py:294-372) of the golden poses.  Stored: per-step losses, parameter
+    UPDATES (after - before) at the pinned entries, metric values."""
+    ns = ref_harness.load_regtr()
+    model, cfg = ref_harness.make_model(f'qk_regtr_full_{cfg_tag}.yaml', seed=0)
+    synthetic.fill_parameters(model, seed=0)
+    model.train()
+    pairs, sizes = pairs_for(cfg_tag, B)
+    src = [p[0][:n] for p, (n, m) in zip(pairs, sizes)]
+    tgt = [p[1][:m] for p, (n, m) in zip(pairs, sizes)]
+    pose, src_ov, tgt_ov = loss_inputs(cfg_tag, B)
+
+    def batch():
+        return {'src_xyz': [torch.from_numpy(s) for s in src], 'tgt_xyz': [torch.from_numpy(t) for t in tgt],
+                'pose': torch.from_numpy(pose), 'src_overlap': [torch.from_numpy(o) for o in src_ov],
+                'tgt_overlap': [torch.from_numpy(o) for o in tgt_ov]}
+    opt = torch.optim.AdamW(model.parameters(), lr=cfg.base_lr, weight_decay=cfg.weight_decay)
+    sched = torch.optim.lr_scheduler.StepLR(opt, cfg.scheduler_param[0], cfg.scheduler_param[1])
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    fx = {'B': np.int32(B), 'steps': np.int32(steps), 'grad_clip': np.float64(cfg.grad_clip)}
+    for st in range(steps):
+        b = batch()
+        out = model(b)
+        losses = model.compute_loss(out, b)
+        opt.zero_grad()
+        losses['total'].backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=cfg.grad_clip)
+        opt.step()
+        sched.step()
+        fx[f'step{st}_total'] = np.float64(float(losses['total']))
+        fx[f'step{st}_gradnorm'] = np.float64(float(gn))
+    for n, p in model.named_parameters():
+        d = (p.detach() - before[n]).double().reshape(-1).numpy()
+        fx[f'delta|{n}'] = d[grad_sample_indices(n, d.size)].astype(np.float32)
+    # validation metrics of the golden forward poses (eval mode, the parameters of the fixtures)
+    g = np.load(os.path.join(OUT, f'regtr_{cfg_tag}_b2.npz'))
+    err = ns['se3'].se3_compare(torch.from_numpy(g['pose'])[None], torch.from_numpy(pose)[None, :])
+    fx['rot_err_deg'] = err['rot_deg'].numpy()
+    fx['trans_err'] = err['trans'].numpy()
+    path = os.path.join(OUT, f'train_{cfg_tag}_b{B}.npz')
+    np.savez_compressed(path, **fx)
+    print(os.path.basename(path), os.path.getsize(path) // 1024, 'KB', {k: float(v) for k, v in fx.items() if k.startswith('step')},
+          fx['rot_err_deg'], fx['trans_err'])
+
+
 def main():
     assert ref_harness.available(), "needs /root/reference (dev container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -359,6 +407,8 @@ def main():
         for tag in ('3dmatch', 'kitti', 'modelnet'):
             if f'grad_{tag}' in what or 'grad' in what:
                 gen_grad(tag, 2)
+        if 'train' in what:
+            gen_train('3dmatch', 2, 2)
     finally:
         os.chdir(cwd)
 

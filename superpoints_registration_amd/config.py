@@ -39,6 +39,9 @@ _COMMON = dict(
     transformer_encoder_has_pos_emb=True, sa_val_has_pos_emb=True, ca_val_has_pos_emb=True,
     pos_emb_type='sine', feature_loss_type='infonce', wt_feature=0.1, wt_feature_un=0.0,
     wt_overlap=1.0, wt_corr=1.0,
+    # solver section of the YAML files (read by training.configure_optimizers / Trainer)
+    optimizer='AdamW', base_lr=0.0001, weight_decay=0.0001, grad_clip=0.1, scheduler='step',
+    scheduler_param=[127800, 0.5], reg_success_thresh_rot=10, reg_success_thresh_trans=0.1,
 )
 
 _RESNET = ['resnetb', 'resnetb_strided', 'resnetb', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb']
@@ -56,6 +59,7 @@ CONFIGS = {
         first_feats_dim=128, conv_radius=4.25,
         architecture=['simple'] + _RESNET + ['resnetb_strided', 'resnetb', 'resnetb'],
         use_sinkhorn=False, sinkhorn_itr=3, slack=True, r_p=1.6, r_n=3.2, val_threshold=0.25,
+        scheduler_param=[135800, 0.5], reg_success_thresh_rot=5, reg_success_thresh_trans=2,
     ),
     # conf/qk_regtr_full_modelnet.yaml
     'modelnet': dict(

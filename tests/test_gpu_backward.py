@@ -302,3 +302,57 @@ def test_parameter_gradients_match_the_reference(device, tag, which):
     # so the entry-wise count is not asserted there (norm and RMS bounds above still are)
     if tag != "3dmatch":
         assert enc_loose <= 0.5 * n_enc, f"{enc_loose} of {n_enc} encoder tensors deviate entrywise"
+
+
+def test_two_training_steps_match_the_reference_loop(device):
+    """training.Trainer on the HIP model vs the reference's own loop (trainer.py:107-124 with the
+    optimiser of generic_reg_model.py:46-76) for two steps on one batch: losses, the clipped
+    gradient norm implied by the update, and the parameter UPDATES at the pinned entries
+    (golden: tests/golden/train_3dmatch_b2.npz, oracle/gen_golden.py gen_train).  Also the
+    validation metrics of the golden poses (generic_reg_model.py:294-321)."""
+    from superpoints_registration_amd.training import Trainer, compute_metrics
+    g = load_golden("train_3dmatch_b2.npz")
+    tag, B = "3dmatch", int(g["B"])
+    cfg = get_config(tag)
+    pairs, sizes = pairs_for(tag, B)
+    pose, src_ov, tgt_ov = loss_inputs(tag, B)
+    model = RegTR(cfg)
+    synthetic.fill_parameters(model, seed=0)
+    model = model.to(device)
+    batch = {"src_xyz": [T(p[0][:n]).to(device) for p, (n, m) in zip(pairs, sizes)],
+             "tgt_xyz": [T(p[1][:m]).to(device) for p, (n, m) in zip(pairs, sizes)],
+             "pose": T(pose).to(device),
+             "src_overlap": [T(o).to(device) for o in src_ov], "tgt_overlap": [T(o).to(device) for o in tgt_ov]}
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    tr = Trainer(cfg).setup(model)
+    for st in range(int(g["steps"])):
+        losses = tr.train_step(model, dict(batch))
+        ref = float(g[f"step{st}_total"])
+        assert abs(float(losses["total"]) - ref) <= 2e-4 * abs(ref), (st, float(losses["total"]), ref)
+    # AdamW's first steps move every entry by ~lr * sign-like terms: compare updates entry-wise,
+    # relative to the update scale lr = 1e-4 (a wrong step order -- no clipping, or clipping after
+    # the step -- changes the second step's m / sqrt(v) ratios by far more than this tolerance)
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        d = (p.detach() - before[n]).double().reshape(-1).cpu().numpy()
+        got = d[grad_sample_indices(n, d.size)]
+        refd = g[f"delta|{n}"].astype(np.float64)
+        dev = np.abs(got - refd)
+        # entries whose gradient is ~0 change sign freely under AdamW (update = lr * m / (sqrt(v) + eps)):
+        # require 85 % of the (64) pinned entries within 2 % of the two-step size and the pinned
+        # update vectors to be collinear (cosine >= 0.995)
+        frac = float((dev <= 0.02 * 2e-4).mean())
+        cos = float(np.dot(got, refd) / max(np.linalg.norm(got) * np.linalg.norm(refd), 1e-30))
+        worst = max(worst, 1 - frac)
+        assert d.size <= 4 or (frac >= 0.85 and cos >= 0.995), f"{n}: {frac:.3f} of the pinned updates agree, cosine {cos:.4f}"
+    print(f"two training steps: worst tensor has {worst * 100:.2f} % of pinned updates off")
+    # validation metrics on the golden forward (eval mode, untouched parameters)
+    model2 = RegTR(cfg)
+    synthetic.fill_parameters(model2, seed=0)
+    model2 = model2.to(device).eval()
+    out = model2({"src_xyz": batch["src_xyz"], "tgt_xyz": batch["tgt_xyz"]})
+    m = compute_metrics(out, {"pose": batch["pose"]})
+    assert np.allclose(m["rot_err_deg"].cpu().numpy(), g["rot_err_deg"], atol=2e-2)     # degrees
+    assert np.allclose(m["trans_err"].cpu().numpy(), g["trans_err"], atol=1e-4)
