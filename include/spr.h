@@ -230,6 +230,25 @@ int spr_match_dualsoftmax(const float* feat, int d, const int* cu,
                           int* match_ind, void* ws, size_t ws_bytes,
                           void* stream);
 
+/* Variant that also returns the runner-up value of every match (match_val2, may be NULL) --
+ * what RegTR.ratio_test needs (Lowe ratio, qk_regtr_full.py:370-384; cfg.use_ratio_test). */
+int spr_match_dualsoftmax2(const float* feat, int d, const int* cu,
+                           const int* cu_host, int npairs, float* match_val,
+                           float* match_val2, int* match_ind, void* ws, size_t ws_bytes,
+                           void* stream);
+
+/* ---- pose-hypothesis residuals (config-off refinements) -------
+ * spr_pose_residuals: res[i] = || b_i - T_s a_i || with one pose per set s of pair_cu
+ *   (RegTR.recompute_weights / local_global_registration, qk_regtr_full.py:386-398);
+ *   total_host = pair_cu[npairs] (host copy, sizes the grid).
+ * spr_pose_scores: score[h] = mean_i || b_i - T_h a_i || for nh hypotheses over ONE point
+ *   set (the RANSAC loop of qk_regtr_full.py:400-421, all hypotheses in one launch).
+ */
+int spr_pose_residuals(const float* pose, const float* a, const float* b, const int* pair_cu,
+                       int npairs, int total_host, float* res, void* stream);
+int spr_pose_scores(const float* poses, int nh, const float* a, const float* b, int n,
+                    float* score, void* stream);
+
 /* ---- a12: weighted Procrustes / Kabsch --------------------------------------
  * Replaces compute_rigid_transform(a, b, weights) (utils/se3_torch.py:109-163)
  * batched over pairs; 3x3 SVD by one-sided Jacobi in registers.

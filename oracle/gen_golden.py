@@ -386,6 +386,44 @@ def gen_train(cfg_tag='3dmatch', B=2, steps=2):
           fx['rot_err_deg'], fx['trans_err'])
 
 
+REFINE_CASES = {
+    'ratio': dict(use_ratio_test=True),
+    'median': dict(threshold_corr=True),
+    'overlap': dict(remove_outliers_overlap=True),
+    'overlap_w': dict(remove_outliers_overlap=True, use_overlap_as_weights=True),
+    'topk': dict(remove_points_from_val=True),
+    'lgr': dict(use_lgr=True),
+    'all': dict(use_ratio_test=True, remove_outliers_overlap=True, remove_points_from_val=True, use_lgr=True),
+}
+
+
+def gen_refine(cfg_tag='kitti', B=2):
+    """The config-off refinement switches of RegTR.softmax_correlation (qk_regtr_full.py:370-398,
+    :465-556), one reference forward per switch set on the golden pairs: pose, weights, indices.
+    (use_ransac cannot run here: the reference's ransac() calls .cuda(), qk_regtr_full.py:405.)"""
+    fx = {'B': np.int32(B)}
+    pairs, sizes = pairs_for(cfg_tag, B)
+    src = [p[0][:n] for p, (n, m) in zip(pairs, sizes)]
+    tgt = [p[1][:m] for p, (n, m) in zip(pairs, sizes)]
+    for case, flags in REFINE_CASES.items():
+        model, cfg = ref_harness.make_model(f'qk_regtr_full_{cfg_tag}.yaml', seed=0)
+        synthetic.fill_parameters(model, seed=0)
+        for k, v in flags.items():
+            model.cfg[k] = v
+        batch = {'src_xyz': [torch.from_numpy(s) for s in src], 'tgt_xyz': [torch.from_numpy(t) for t in tgt],
+                 'pose': torch.eye(4)[None, :3].repeat(B, 1, 1)}
+        with torch.no_grad():
+            out = model(batch)
+        fx[f'{case}.pose'] = out['pose'].numpy()
+        for b in range(B):
+            fx[f'{case}.val{b}'] = out['overlap_prob_list'][b].numpy()
+            fx[f'{case}.ind{b}'] = out['ind_list'][b].numpy().astype(np.int32)
+        print(case, out['pose'][:, :, 3].numpy().round(4).tolist())
+    path = os.path.join(OUT, f'refine_{cfg_tag}_b{B}.npz')
+    np.savez_compressed(path, **fx)
+    print(os.path.basename(path), os.path.getsize(path) // 1024, 'KB')
+
+
 def main():
     assert ref_harness.available(), "needs /root/reference (dev container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -409,6 +447,8 @@ def main():
                 gen_grad(tag, 2)
         if 'train' in what:
             gen_train('3dmatch', 2, 2)
+        if 'refine' in what:
+            gen_refine('kitti', 2)
     finally:
         os.chdir(cwd)
 

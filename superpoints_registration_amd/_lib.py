@@ -46,6 +46,9 @@ SIGNATURES = {
     "spr_set_attn_mode": (_i, [_i]),
     "spr_match_workspace_bytes": (_sz, [_vp, _i]),
     "spr_match_dualsoftmax": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "spr_match_dualsoftmax2": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "spr_pose_residuals": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "spr_pose_scores": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp]),
     "spr_weighted_procrustes": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "spr_sinkhorn_workspace_bytes": (_sz, [_vp, _i]),
     "spr_sinkhorn_correspondences": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp,

@@ -52,6 +52,7 @@ CONFIGS = {
         dataset='3dmatch', neighborhood_limits=[40, 40, 40, 40], first_subsampling_dl=0.025,
         first_feats_dim=128, conv_radius=2.5, architecture=['simple'] + _RESNET,
         use_sinkhorn=True, sinkhorn_itr=3, slack=True, r_p=0.2, r_n=0.4, val_threshold=0.15,
+        num_refinement_steps=4, acceptance_radius=0.1,
     ),
     # conf/qk_regtr_full_kitti.yaml
     'kitti': dict(
@@ -59,6 +60,7 @@ CONFIGS = {
         first_feats_dim=128, conv_radius=4.25,
         architecture=['simple'] + _RESNET + ['resnetb_strided', 'resnetb', 'resnetb'],
         use_sinkhorn=False, sinkhorn_itr=3, slack=True, r_p=1.6, r_n=3.2, val_threshold=0.25,
+        num_refinement_steps=10, acceptance_radius=0.6,
         scheduler_param=[135800, 0.5], reg_success_thresh_rot=5, reg_success_thresh_trans=2,
     ),
     # conf/qk_regtr_full_modelnet.yaml
@@ -67,6 +69,7 @@ CONFIGS = {
         first_feats_dim=512, conv_radius=2.75,
         architecture=['simple', 'resnetb', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb'],
         use_sinkhorn=False, sinkhorn_itr=1, slack=False, r_p=0.12, r_n=0.24,
+        num_refinement_steps=5, acceptance_radius=0.05,
     ),
 }
 

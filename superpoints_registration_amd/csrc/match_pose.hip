@@ -104,14 +104,15 @@ __global__ __launch_bounds__(1024) void k_match_cols(const float* __restrict__ m
                                                     const PairDesc* __restrict__ pd,
                                                     const float* __restrict__ row_lse,
                                                     const float* __restrict__ col_lse,
-                                                    float* __restrict__ val, int* __restrict__ ind) {
+                                                    float* __restrict__ val, int* __restrict__ ind,
+                                                    float* __restrict__ val2) {
   const PairDesc p = pd[blockIdx.y];
   if (!(p.n > p.m)) return;
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
-  __shared__ float sv[kColLanes][64];
+  __shared__ float sv[kColLanes][64], sv2[kColLanes][64];
   __shared__ int si[kColLanes][64];
-  float best = -1.f;
+  float best = -1.f, second = -1.f;   // second: runner-up value (Lowe ratio test, qk_regtr_full.py:370-384)
   int bi = 0;
   if (col < p.m) {
     const float cl_j = col_lse[p.tgt_beg + col];
@@ -119,60 +120,115 @@ __global__ __launch_bounds__(1024) void k_match_cols(const float* __restrict__ m
       const float c = mat[p.off + (size_t)i * p.m + col];
       const float a = expf(c - cl_j) * expf(c - row_lse[p.src_beg + i]);
       if (a > best) {
+        second = best;
         best = a;
         bi = i;
+      } else if (a > second) {
+        second = a;
       }
     }
   }
   sv[rl][cl] = best;
+  sv2[rl][cl] = second;
   si[rl][cl] = bi;
   __syncthreads();
   if (rl == 0 && col < p.m) {
     for (int k = 1; k < kColLanes; ++k) {
-      const float b = sv[k][cl];
+      const float b = sv[k][cl], b2 = sv2[k][cl];
       const int i = si[k][cl];
       if (b > best || (b == best && i < bi)) {
+        second = fmaxf(best, b2);
         best = b;
         bi = i;
+      } else {
+        second = fmaxf(second, b);
       }
     }
     val[p.tgt_beg + col] = best;
     ind[p.tgt_beg + col] = bi;
+    if (val2) val2[p.tgt_beg + col] = second;
   }
 }
 
 __global__ void k_match_rows(const float* __restrict__ mat, const PairDesc* __restrict__ pd,
                              const float* __restrict__ row_lse, const float* __restrict__ col_lse,
-                             float* __restrict__ val, int* __restrict__ ind) {
+                             float* __restrict__ val, int* __restrict__ ind, float* __restrict__ val2) {
   const PairDesc p = pd[blockIdx.y];
   if (p.n > p.m) return;
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (row >= p.n) return;
   const float rl_i = row_lse[p.src_beg + row];
-  float best = -1.f;
+  float best = -1.f, second = -1.f;
   int bj = 0;
   for (int j = lane; j < p.m; j += 64) {
     const float c = mat[p.off + (size_t)row * p.m + j];
     const float a = expf(c - col_lse[p.tgt_beg + j]) * expf(c - rl_i);
     if (a > best) {
+      second = best;
       best = a;
       bj = j;
+    } else if (a > second) {
+      second = a;
     }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const float b = __shfl_xor(best, o, 64);
+    const float b = __shfl_xor(best, o, 64), b2 = __shfl_xor(second, o, 64);
     const int j = __shfl_xor(bj, o, 64);
     if (b > best || (b == best && j < bj)) {
+      second = fmaxf(best, b2);
       best = b;
       bj = j;
+    } else {
+      second = fmaxf(second, b);
     }
   }
   if (lane == 0) {
     val[p.src_beg + row] = best;
     ind[p.src_beg + row] = bj;
+    if (val2) val2[p.src_beg + row] = second;
   }
+}
+
+// ---- residuals of pose hypotheses (LGR re-weighting, RANSAC scoring; qk_regtr_full.py:386-421) ----
+// res[i] = || b_i - (R_s a_i + t_s) ||  for the points of set s (pair_cu), one pose per set
+__global__ void k_pose_residuals(const float* __restrict__ pose, const float* __restrict__ a,
+                                 const float* __restrict__ b, const int* __restrict__ pair_cu, int npairs,
+                                 float* __restrict__ res) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = pair_cu[npairs];
+  if (i >= total) return;
+  const int s = find_segment(pair_cu, npairs, i);
+  const float* T = pose + 12 * (size_t)s;
+  const float x = a[3 * (size_t)i], y = a[3 * (size_t)i + 1], z = a[3 * (size_t)i + 2];
+  float d2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float v = b[3 * (size_t)i + r] - ((x * T[4 * r] + y * T[4 * r + 1] + z * T[4 * r + 2]) + T[4 * r + 3]);
+    d2 += v * v;
+  }
+  res[i] = sqrtf(d2);
+}
+// score[h] = mean_i || b_i - T_h a_i ||  over ONE point set for H hypotheses (one wave per hypothesis)
+__global__ void k_pose_scores(const float* __restrict__ poses, int nh, const float* __restrict__ a,
+                              const float* __restrict__ b, int n, float* __restrict__ score) {
+  const int h = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (h >= nh) return;
+  const float* T = poses + 12 * (size_t)h;
+  float s = 0.f;
+  for (int i = lane; i < n; i += 64) {
+    const float x = a[3 * (size_t)i], y = a[3 * (size_t)i + 1], z = a[3 * (size_t)i + 2];
+    float d2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const float v = b[3 * (size_t)i + r] - ((x * T[4 * r] + y * T[4 * r + 1] + z * T[4 * r + 2]) + T[4 * r + 3]);
+      d2 += v * v;
+    }
+    s += sqrtf(d2);
+  }
+  s = wave_sum(s);
+  if (lane == 0) score[h] = s / (float)n;
 }
 
 // ---- elementwise transforms of the score matrix -----------------------------
@@ -793,9 +849,9 @@ int correlate(const float* feat, int d, const int* cu_dev, const int* cu_host, i
 }
 }  // namespace
 
-extern "C" int spr_match_dualsoftmax(const float* feat, int d, const int* cu, const int* cu_host,
-                                     int npairs, float* match_val, int* match_ind, void* ws,
-                                     size_t ws_bytes, void* stream_) {
+extern "C" int spr_match_dualsoftmax2(const float* feat, int d, const int* cu, const int* cu_host,
+                                      int npairs, float* match_val, float* match_val2, int* match_ind, void* ws,
+                                      size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(npairs >= 1 && d % 32 == 0, "match: need npairs >= 1 and d %% 32 == 0");
   SPR_REQUIRE(ws_bytes >= match_ws_bytes(cu_host, npairs), "match: workspace too small");
@@ -817,9 +873,34 @@ extern "C" int spr_match_dualsoftmax(const float* feat, int d, const int* cu, co
   hipLaunchKernelGGL(k_col_lse, dim3(cdiv(max_m, 64), npairs), dim3(1024), 0, stream, mat, pd, col_lse,
                      (const float*)nullptr, 0);
   hipLaunchKernelGGL(k_match_cols, dim3(cdiv(max_m, 64), npairs), dim3(1024), 0, stream, mat, pd,
-                     row_lse, col_lse, match_val, match_ind);
+                     row_lse, col_lse, match_val, match_ind, match_val2);
   hipLaunchKernelGGL(k_match_rows, dim3(cdiv((long)max_n * 64, 256), npairs), dim3(256), 0, stream,
-                     mat, pd, row_lse, col_lse, match_val, match_ind);
+                     mat, pd, row_lse, col_lse, match_val, match_ind, match_val2);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_match_dualsoftmax(const float* feat, int d, const int* cu, const int* cu_host,
+                                     int npairs, float* match_val, int* match_ind, void* ws,
+                                     size_t ws_bytes, void* stream_) {
+  return spr_match_dualsoftmax2(feat, d, cu, cu_host, npairs, match_val, nullptr, match_ind, ws, ws_bytes, stream_);
+}
+
+extern "C" int spr_pose_residuals(const float* pose, const float* a, const float* b, const int* pair_cu,
+                                  int npairs, int total_host, float* res, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(npairs >= 1 && total_host >= 1 && pose && a && b && pair_cu && res, "pose_residuals: bad arguments");
+  hipLaunchKernelGGL(k_pose_residuals, dim3(cdiv(total_host, 256)), dim3(256), 0, stream, pose, a, b, pair_cu, npairs,
+                     res);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_pose_scores(const float* poses, int nh, const float* a, const float* b, int n, float* score,
+                               void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(nh >= 1 && n >= 1 && poses && a && b && score, "pose_scores: bad arguments");
+  hipLaunchKernelGGL(k_pose_scores, dim3(cdiv((long)nh * 64, 256)), dim3(256), 0, stream, poses, nh, a, b, n, score);
   SPR_LAUNCH_CHECK();
   return 0;
 }

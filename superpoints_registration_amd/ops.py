@@ -363,6 +363,48 @@ def match_dualsoftmax(feat, cu, cu_host: Sequence[int], npairs: int):
     return match_dualsoftmax_raw(feat, cu, cu_host, npairs)
 
 
+def match_dualsoftmax_top2(feat, cu, cu_host: Sequence[int], npairs: int):
+    """(val, val2, ind): the best and the runner-up dual-softmax value of every match (Lowe ratio
+    test of RegTR.ratio_test, qk_regtr_full.py:370-384).  Inference only."""
+    feat = _dev(feat, "feat", torch.float32)
+    cu = _dev(cu, "cu", torch.int32)
+    T, d = feat.shape
+    arr = _cu_host_arr(cu_host)
+    L = _lib.lib()
+    ws = _workspace(L.spr_match_workspace_bytes(arr, npairs), feat.device)
+    val = torch.zeros((T,), dtype=torch.float32, device=feat.device)
+    val2 = torch.zeros((T,), dtype=torch.float32, device=feat.device)
+    ind = torch.zeros((T,), dtype=torch.int32, device=feat.device)
+    _lib.check(L.spr_match_dualsoftmax2(_ptr(feat), d, _ptr(cu), arr, npairs, _ptr(val), _ptr(val2), _ptr(ind),
+                                        _ptr(ws), ws.numel(), _stream(feat)), "spr_match_dualsoftmax2")
+    return val, val2, ind
+
+
+def pose_residuals(pose, a, b, pair_cu) -> torch.Tensor:
+    """res[i] = ||b_i - T_s a_i|| with one pose [3,4] per set of pair_cu (LGR re-weighting,
+    qk_regtr_full.py:386-398)."""
+    a, b = _dev(a, "a", torch.float32), _dev(b, "b", torch.float32)
+    pose = _dev(pose, "pose", torch.float32)
+    pair_cu = _dev(pair_cu, "pair_cu", torch.int32)
+    n = a.shape[0]
+    res = torch.empty((n,), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().spr_pose_residuals(_ptr(pose), _ptr(a), _ptr(b), _ptr(pair_cu), pair_cu.numel() - 1, n,
+                                             _ptr(res), _stream(a)), "spr_pose_residuals")
+    return res
+
+
+def pose_scores(poses, a, b) -> torch.Tensor:
+    """score[h] = mean_i ||b_i - T_h a_i|| for H hypotheses [H,3,4] over one point set (RANSAC
+    scoring, qk_regtr_full.py:400-421)."""
+    a, b = _dev(a, "a", torch.float32), _dev(b, "b", torch.float32)
+    poses = _dev(poses, "poses", torch.float32)
+    h = poses.shape[0]
+    out = torch.empty((h,), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.lib().spr_pose_scores(_ptr(poses), h, _ptr(a), _ptr(b), a.shape[0], _ptr(out), _stream(a)),
+               "spr_pose_scores")
+    return out
+
+
 def match_dualsoftmax_raw(feat, cu, cu_host: Sequence[int], npairs: int):
     feat = _dev(feat, "feat", torch.float32)
     cu = _dev(cu, "cu", torch.int32)

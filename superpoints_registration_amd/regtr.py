@@ -9,8 +9,10 @@ Differences by design (documented in DESIGN.md):
     no per-pair Python loop in the matching head;
   * `attn` (the dense N x M dual-softmax matrices) is not materialised; the
     entry is a list of None unless `return_attn=True`;
-  * config-off refinements (LGR, RANSAC, ratio test, overlap weighting, top-k
-    pruning, attention/correlation affinity) raise NotImplementedError;
+  * the config-off refinements of softmax_correlation (ratio test, median threshold, overlap
+    weighting, top-k pruning, LGR, RANSAC -- qk_regtr_full.py:370-421, :465-556) are available
+    on the inference path (`_refined_pose`); the two dead "affinity" switches
+    (use_attn_affinity raises in the reference itself, use_corr_affinity) stay unsupported;
   * training: with gradients enabled every operator runs through its explicit HIP backward
     (autograd.py), so `compute_loss(model(batch), batch)['total'].backward()` fills the
     same parameter gradients as the reference's training_step (generic_reg_model.py:82-84);
@@ -35,9 +37,9 @@ class _BilinearW(nn.Module):
         nn.init.normal_(self.W, std=0.1)
 
 
-_UNSUPPORTED_FLAGS = ('use_lgr', 'use_ransac', 'use_ratio_test', 'threshold_corr',
-                      'remove_outliers_overlap', 'use_overlap_as_weights',
-                      'remove_points_from_val', 'use_attn_affinity', 'use_corr_affinity')
+_UNSUPPORTED_FLAGS = ('use_attn_affinity', 'use_corr_affinity')
+_REFINE_FLAGS = ('use_lgr', 'use_ransac', 'use_ratio_test', 'threshold_corr', 'remove_outliers_overlap',
+                 'use_overlap_as_weights', 'remove_points_from_val')
 
 
 class RegTR(nn.Module):
@@ -48,8 +50,8 @@ class RegTR(nn.Module):
         self.return_attn = return_attn
         for flag in _UNSUPPORTED_FLAGS:
             if cfg.get(flag, False):
-                raise NotImplementedError(f"cfg.{flag}=True is outside the hot-path scope "
-                                          "(off in all shipped configs)")
+                raise NotImplementedError(f"cfg.{flag}=True is not supported (use_attn_affinity raises "
+                                          "ValueError in the reference itself, qk_regtr_full.py:505-511)")
         if cfg.get('pos_emb_type', 'sine') != 'sine':
             raise NotImplementedError("only pos_emb_type='sine'")
 
@@ -115,10 +117,21 @@ class RegTR(nn.Module):
         cu_host = [0]
         for n in list(src_lens) + list(tgt_lens):
             cu_host.append(cu_host[-1] + int(n))
-        val, ind = ops.match_dualsoftmax(cond, cu, cu_host, B)
+        refine = any(cfg.get(f, False) for f in _REFINE_FLAGS)
+        if refine and torch.is_grad_enabled() and self.training:
+            raise NotImplementedError("the config-off refinements are inference-time options")
+        val2 = None
+        if cfg.get('use_ratio_test', False):
+            val, val2, ind = ops.match_dualsoftmax_top2(cond, cu, cu_host, B)
+        else:
+            val, ind = ops.match_dualsoftmax(cond, cu, cu_host, B)
         n_src = cu_host[B]
         src_xyz_all, tgt_xyz_all = xyz_c[:n_src], xyz_c[n_src:]
-        if cfg.use_sinkhorn:
+        refined = None
+        if refine:
+            refined = self._refined_pose(xyz_c, overlap, val, val2, ind, cu, cu_host, B, cond)
+            pose = refined['pose']
+        elif cfg.use_sinkhorn:
             w, t_hat = ops.sinkhorn_correspondences(cond, xyz_c, cu, cu_host, B,
                                                     self.alpha, self.beta,   # device scalars, no sync
                                                     int(cfg.sinkhorn_itr), bool(cfg.slack))
@@ -152,6 +165,8 @@ class RegTR(nn.Module):
                 v, i = val[sl], ind[sl].long()
                 s_pts = src_kp[b]
                 t_pts = tgt_kp[b] if cfg.use_sinkhorn else tgt_kp[b][i]
+            if refined is not None:
+                v, i, s_pts, t_pts = (refined[k][b] for k in ('val', 'ind', 'src_pts', 'tgt_pts'))
             vals.append(v)
             inds.append(i)
             src_corr.append(s_pts)
@@ -219,6 +234,82 @@ class RegTR(nn.Module):
             losses['T'] = ops.sum_scaled(torch.stack(t_l1), 1.0)                    # sum over pairs (:353)
         losses['total'] = losses['T'] + 0.1 * losses['feature'] + losses['overlap']
         return losses
+
+    def _refined_pose(self, xyz_c, overlap, val, val2, ind, cu, cu_host, B, cond):
+        """The config-off refinements of RegTR.softmax_correlation, pair by pair like the reference
+        (qk_regtr_full.py:445-668): Lowe ratio test (:370-384), median threshold (:471-473),
+        overlap weighting (:484-494), top-k pruning (:499-502), then the pose, then LGR
+        (:386-398) and RANSAC (:400-421).  Selection logic is index glue on per-pair vectors of
+        a few hundred entries; every pose solve, residual and score runs in the HIP library --
+        RANSAC's 500 hypotheses as ONE batched Procrustes launch + one scoring launch instead of
+        the reference's 500 sequential solves."""
+        cfg = self.cfg
+        dev = xyz_c.device
+        out = {k: [] for k in ('pose', 'val', 'ind', 'src_pts', 'tgt_pts')}
+        sk_pose = None
+        if cfg.use_sinkhorn:   # the Sinkhorn pose ignores the pruned correspondences (:525-536)
+            w, t_hat = ops.sinkhorn_correspondences(cond, xyz_c, cu, cu_host, B, self.alpha, self.beta,
+                                                    int(cfg.sinkhorn_itr), bool(cfg.slack))
+            sk_pose = ops.weighted_procrustes(xyz_c[:cu_host[B]], t_hat, w, cu[:B + 1].contiguous())
+        for b in range(B):
+            s0, s1, t0, t1 = cu_host[b], cu_host[b + 1], cu_host[B + b], cu_host[B + b + 1]
+            N, M = s1 - s0, t1 - t0
+            src_xyz, tgt_xyz = xyz_c[s0:s1], xyz_c[t0:t1]
+            ov_s, ov_t = overlap[s0:s1, 0], overlap[t0:t1, 0]
+            own = slice(t0, t1) if N > M else slice(s0, s1)
+            v, i = val[own].clone(), ind[own].long()
+            if cfg.get('use_ratio_test', False):
+                v = torch.where(val2[own] / v < cfg.lowe_thres, v, torch.zeros_like(v))
+            if cfg.get('threshold_corr', False):
+                v = torch.where(v > torch.median(v), v, torch.zeros_like(v))
+            if N > M:
+                src_pts = src_xyz if cfg.use_sinkhorn else src_xyz[i]
+                tgt_pts = tgt_xyz
+            else:
+                src_pts = src_xyz
+                tgt_pts = tgt_xyz if cfg.use_sinkhorn else tgt_xyz[i]
+            ov = None
+            if cfg.get('remove_outliers_overlap', False):
+                ov = (ov_s[i] * ov_t) if N > M else (ov_s * ov_t[i])
+                if not cfg.get('use_overlap_as_weights', False):
+                    v = v * ov
+            if cfg.get('remove_points_from_val', False):
+                k = int(cfg.val_threshold * (M if N > M else N))
+                v, i = torch.topk(v, k)
+                src_pts, tgt_pts = src_pts[i], tgt_pts[i]
+                if ov is not None:
+                    ov = ov[i]
+            one = torch.tensor([0, src_pts.shape[0]], dtype=torch.int32, device=dev)
+            if cfg.use_sinkhorn:
+                T = sk_pose[b]
+            else:
+                wts = ov if cfg.get('use_overlap_as_weights', False) else v
+                if wts is None:
+                    raise ValueError("use_overlap_as_weights needs remove_outliers_overlap (as in the reference)")
+                T = ops.weighted_procrustes(src_pts.contiguous(), tgt_pts.contiguous(), wts.contiguous(), one)[0]
+            if cfg.get('use_lgr', False):
+                wl = v
+                for _ in range(int(cfg.num_refinement_steps)):
+                    res = ops.pose_residuals(T[None].contiguous(), src_pts.contiguous(), tgt_pts.contiguous(), one)
+                    wl = wl * (res < cfg.acceptance_radius).float()
+                    T = ops.weighted_procrustes(src_pts.contiguous(), tgt_pts.contiguous(), wl.contiguous(), one)[0]
+            if cfg.get('use_ransac', False):
+                T = self._ransac(src_pts.contiguous(), tgt_pts.contiguous(), v.contiguous())
+            for k_, v_ in (('pose', T), ('val', v), ('ind', i), ('src_pts', src_pts), ('tgt_pts', tgt_pts)):
+                out[k_].append(v_)
+        out['pose'] = torch.stack(out['pose'])
+        return out
+
+    @staticmethod
+    def _ransac(src, tgt, weights, itr: int = 500, sample_size: int = 100, generator=None):
+        """qk_regtr_full.py:400-421 (500 random 100-point subsets with replacement, keep the
+        hypothesis with the lowest mean residual over ALL correspondences) as two launches."""
+        n = src.shape[0]
+        idx = torch.randint(0, n, (itr, sample_size), device=src.device, generator=generator).reshape(-1)
+        set_cu = torch.arange(itr + 1, dtype=torch.int32, device=src.device) * sample_size
+        poses = ops.weighted_procrustes(src[idx].contiguous(), tgt[idx].contiguous(), weights[idx].contiguous(), set_cu)
+        score = ops.pose_scores(poses, src, tgt)
+        return poses[torch.argmin(score)]          # first minimum, like the reference's strict '<'
 
     def _pose_from_matches(self, xyz_c, val, ind, cu, cu_host, B):
         """arg-max correspondences -> weighted Procrustes for all pairs in one

@@ -228,3 +228,67 @@ def test_degenerate_clouds_against_the_cpu_oracle(device, case):
         assert np.abs(moved(got) - moved(want)).max() < 1e-6
     else:
         assert err < 1e-4, f"pose error {err:.2e}"
+
+
+# ---- config-off refinements ----------------------------------------------------
+@pytest.mark.parametrize("case", ["ratio", "median", "overlap", "overlap_w", "topk", "lgr", "all"])
+def test_refinement_switches_match_the_reference(device, case):
+    """RegTR.softmax_correlation with the refinement switches the shipped configs leave off
+    (qk_regtr_full.py:370-398, :465-556), against reference forwards with the same switches
+    (tests/golden/refine_kitti_b2.npz).  Selections (ratio / median thresholds, top-k) are
+    discrete, so indices are compared as a match rate and poses at 1e-3."""
+    from oracle.gen_golden import REFINE_CASES
+    g = load_golden("refine_kitti_b2.npz")
+    B = int(g["B"])
+    cfg = get_config("kitti")
+    cfg.update(REFINE_CASES[case])
+    pairs, sizes = pairs_for("kitti", B)
+    model = RegTR(cfg)
+    synthetic.fill_parameters(model, seed=0)
+    model = model.to(device).eval()
+    out = model({"src_xyz": [torch.from_numpy(p[0][:n]).to(device) for p, (n, m) in zip(pairs, sizes)],
+                 "tgt_xyz": [torch.from_numpy(p[1][:m]).to(device) for p, (n, m) in zip(pairs, sizes)]})
+    for b in range(B):
+        val, ind = out["overlap_prob_list"][b].cpu().numpy(), out["ind_list"][b].cpu().numpy()
+        rv, ri = g[f"{case}.val{b}"], g[f"{case}.ind{b}"]
+        assert val.shape == rv.shape and ind.shape == ri.shape
+        live = rv > 0          # entries zeroed by a threshold tie arbitrarily inside torch.topk
+        assert (ind == ri)[live].mean() >= 0.98, f"{case} pair {b}: {(ind == ri)[live].mean():.3f} of the indices agree"
+        assert (val > 0).sum() == live.sum()
+        same = (ind == ri) & live
+        assert np.allclose(val[same], rv[same], rtol=5e-3, atol=1e-7)
+        err = np.linalg.norm(out["pose"][b].cpu().numpy() - g[f"{case}.pose"][b])
+        assert err < 1e-3, f"{case} pair {b}: pose error {err:.2e}"
+
+
+def test_ransac_is_the_best_of_its_hypotheses(device):
+    """RegTR._ransac (qk_regtr_full.py:400-421 as one batched solve): the returned pose is the
+    hypothesis with the lowest mean residual, reproducible under a seeded generator, and on
+    mostly clean correspondences close to the planted transform."""
+    from superpoints_registration_amd import ops as O_
+    g = torch.Generator().manual_seed(1)
+    n = 400
+    a = torch.randn((n, 3), generator=g)
+    q, _ = torch.linalg.qr(torch.randn((3, 3), generator=g))
+    if torch.det(q) < 0:
+        q[:, 0] *= -1
+    t = torch.tensor([0.3, -0.1, 0.2])
+    bpts = a @ q.t() + t + 0.002 * torch.randn((n, 3), generator=g)
+    bpts[:40] += torch.randn((40, 3), generator=g)          # 10 % gross outliers
+    w = torch.rand((n,), generator=g)
+    da, db, dw = a.to(device), bpts.to(device), w.to(device)
+    gen = torch.Generator(device=device).manual_seed(7)
+    T1 = RegTR._ransac(da, db, dw, generator=gen)
+    gen = torch.Generator(device=device).manual_seed(7)
+    T2 = RegTR._ransac(da, db, dw, generator=gen)
+    assert torch.equal(T1, T2)
+    gen = torch.Generator(device=device).manual_seed(7)
+    idx = torch.randint(0, n, (500, 100), device=device, generator=gen).reshape(-1)
+    cu = torch.arange(501, dtype=torch.int32, device=device) * 100
+    poses = O_.weighted_procrustes(da[idx].contiguous(), db[idx].contiguous(), dw[idx].contiguous(), cu)
+    scores = O_.pose_scores(poses, da, db)
+    ref_scores = torch.stack([(db - (da @ p[:, :3].t() + p[:, 3])).norm(dim=1).mean() for p in poses])
+    assert torch.allclose(scores, ref_scores, rtol=1e-5, atol=1e-6)
+    assert torch.equal(T1, poses[torch.argmin(scores)])
+    gt = torch.cat([q, t[:, None]], 1).to(device)
+    assert float((T1 - gt).norm()) < 0.1
