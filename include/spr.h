@@ -57,6 +57,16 @@ int spr_grid_subsample(const float* xyz, const int* cu, int n, int nb, float dl,
                        int max_p, int order_mode, float* out_xyz, int* out_lens,
                        int* out_total, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- voxel pre-downsampling, one point per voxel ------------
+ * Replaces voxel_down_sample of the KITTI loader (data_loaders/kitti_pred.py:12-14,
+ * :203-204 -> kiss_icp): voxel = trunc(p / voxel_size) per axis in float64, the first point of
+ * every voxel is kept.  out_idx [n] i32: the first out_count[0] entries = kept
+ * original indices, ascending; out_count[0] = -1 when a coordinate exceeds 2^20 voxels.
+ */
+size_t spr_voxel_downsample_workspace_bytes(int n);
+int spr_voxel_downsample(const float* xyz, int n, double voxel_size, int* out_idx,
+                         int* out_count, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- a2: batched fixed-radius neighbours ---------------------------------
  * Replaces radius_neighbors.batch_query(queries, supports, q_batches,
  * s_batches, radius=) (cpp_wrappers/cpp_neighbors/wrapper.cpp:58-75 ->

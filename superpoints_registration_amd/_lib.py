@@ -24,6 +24,8 @@ SIGNATURES = {
     "spr_last_error": (ctypes.c_char_p, []),
     "spr_grid_subsample_workspace_bytes": (_sz, [_i, _i]),
     "spr_grid_subsample": (_i, [_vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "spr_voxel_downsample_workspace_bytes": (_sz, [_i]),
+    "spr_voxel_downsample": (_i, [_vp, _i, ctypes.c_double, _vp, _vp, _vp, _sz, _vp]),
     "spr_radius_neighbors_workspace_bytes": (_sz, [_i, _i, _i]),
     "spr_radius_neighbors": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "spr_kpconv_workspace_bytes": (_sz, [_i, _i, _i, _i]),

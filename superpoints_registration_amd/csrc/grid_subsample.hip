@@ -501,3 +501,89 @@ extern "C" int spr_grid_subsample(const float* xyz, const int* cu, int n, int nb
   SPR_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- voxel pre-downsampling, one point per voxel -----------------------------------
+// Replaces the CPU voxel_down_sample of the KITTI loader (data_loaders/kitti_pred.py:12-14, :203-204,
+// kiss_icp: voxel = (p / voxel_size) truncated toward zero per axis; the FIRST point that falls
+// into a voxel is kept).  The kept SET of points is the reference's; they are emitted in
+// ascending original index (kiss_icp emits hash-map order, which nothing downstream depends on).
+namespace spr {
+namespace {
+__global__ void k_vox_keys(const float* __restrict__ xyz, int n, double voxel, unsigned long long* keys,
+                           int* vals, int* err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long k = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const double q = (double)xyz[3 * (size_t)i + d] / voxel;   // Eigen: (point / voxel_size).cast<int>()
+    const long long c = (long long)q;                                    // truncation toward zero
+    if (c < -(1ll << 20) || c >= (1ll << 20)) atomicExch(err, 1);
+    k = (k << 21) | (unsigned long long)((c + (1ll << 20)) & 0x1fffff);
+  }
+  keys[i] = k;
+  vals[i] = i;
+}
+__global__ void k_vox_heads(const unsigned long long* __restrict__ keys, const int* __restrict__ vals, int n,
+                            unsigned int* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // stable sort: the first entry of an equal-key run carries the smallest original index
+  const bool head = i == 0 || keys[i] != keys[i - 1];
+  out[i] = head ? (unsigned int)vals[i] : 0xffffffffu;
+}
+__global__ void k_vox_count(const unsigned int* __restrict__ sorted, int n, int* out_idx, int* count,
+                            const int* err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool ok = sorted[i] != 0xffffffffu;
+  out_idx[i] = ok ? (int)sorted[i] : -1;
+  if (ok && (i + 1 == n || sorted[i + 1] == 0xffffffffu)) count[0] = err[0] ? -1 : i + 1;
+}
+size_t vox_temp_bytes(int n) {
+  size_t a = 0, b = 0;
+  rocprim::radix_sort_pairs(nullptr, a, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (int*)nullptr,
+                            (int*)nullptr, (unsigned int)(n > 0 ? n : 1), 0, 63);
+  rocprim::radix_sort_keys(nullptr, b, (unsigned int*)nullptr, (unsigned int*)nullptr, (unsigned int)(n > 0 ? n : 1), 0,
+                           32);
+  return align_up(a > b ? a : b, 256);
+}
+}  // namespace
+}  // namespace spr
+
+extern "C" size_t spr_voxel_downsample_workspace_bytes(int n) {
+  const size_t N = (size_t)(n > 0 ? n : 1);
+  return 2 * align_up(8 * N, 256) + 4 * align_up(4 * N, 256) + 256 + spr::vox_temp_bytes(n);
+}
+
+// out_idx [n] i32: the first out_count[0] entries are the kept original indices (ascending);
+// out_count[0] = -1 if a coordinate exceeds +-2^20 voxels.
+extern "C" int spr_voxel_downsample(const float* xyz, int n, double voxel_size, int* out_idx, int* out_count, void* ws,
+                                    size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(n >= 1 && voxel_size > 0.0 && xyz && out_idx && out_count, "voxel_downsample: bad arguments");
+  SPR_REQUIRE(ws && ws_bytes >= spr_voxel_downsample_workspace_bytes(n), "voxel_downsample: workspace too small");
+  Workspace w(ws, ws_bytes);
+  unsigned long long* keys = w.take<unsigned long long>(n);
+  unsigned long long* keys2 = w.take<unsigned long long>(n);
+  int* vals = w.take<int>(n);
+  int* vals2 = w.take<int>(n);
+  unsigned int* sel = w.take<unsigned int>(n);
+  unsigned int* sel2 = w.take<unsigned int>(n);
+  int* err = w.take<int>(1);
+  const size_t temp_bytes = vox_temp_bytes(n);
+  void* temp = w.take<char>(temp_bytes);
+  SPR_REQUIRE(temp != nullptr, "voxel_downsample: workspace carve failed");
+  SPR_HIP_CHECK(hipMemsetAsync(err, 0, sizeof(int), stream));
+  SPR_HIP_CHECK(hipMemsetAsync(out_count, 0, sizeof(int), stream));
+  const int TBk = 256;
+  hipLaunchKernelGGL(k_vox_keys, dim3(cdiv(n, TBk)), dim3(TBk), 0, stream, xyz, n, voxel_size, keys, vals, err);
+  size_t tb = temp_bytes;
+  SPR_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, keys, keys2, vals, vals2, (unsigned int)n, 0, 63, stream));
+  hipLaunchKernelGGL(k_vox_heads, dim3(cdiv(n, TBk)), dim3(TBk), 0, stream, keys2, vals2, n, sel);
+  tb = temp_bytes;
+  SPR_HIP_CHECK(rocprim::radix_sort_keys(temp, tb, sel, sel2, (unsigned int)n, 0, 32, stream));
+  hipLaunchKernelGGL(k_vox_count, dim3(cdiv(n, TBk)), dim3(TBk), 0, stream, sel2, n, out_idx, out_count, err);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}

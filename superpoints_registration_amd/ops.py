@@ -88,6 +88,24 @@ def grid_subsample(points: torch.Tensor, cu: torch.Tensor, dl: float, max_p: int
     return out[:m], out_lens
 
 
+def voxel_downsample(points: torch.Tensor, voxel_size: float) -> torch.Tensor:
+    """One point per voxel (the first one, voxel = trunc(p / voxel_size)): the GPU counterpart of
+    the KITTI loader's kiss_icp pre-downsampling (kitti_pred.py:12-14, :203-204).  Returns the kept
+    points in ascending original index (one device->host read of the count)."""
+    points = _dev(points, "points", torch.float32)
+    n = points.shape[0]
+    L = _lib.lib()
+    ws = _workspace(L.spr_voxel_downsample_workspace_bytes(n), points.device)
+    idx = torch.empty((n,), dtype=torch.int32, device=points.device)
+    cnt = torch.empty((1,), dtype=torch.int32, device=points.device)
+    _lib.check(L.spr_voxel_downsample(_ptr(points), n, float(voxel_size), _ptr(idx), _ptr(cnt), _ptr(ws), ws.numel(),
+                                      _stream(points)), "spr_voxel_downsample")
+    m = int(cnt.item())
+    if m < 0:
+        raise RuntimeError("spr_voxel_downsample: coordinates exceed 2^20 voxels")
+    return points[idx[:m].long()]
+
+
 def radius_neighbors(queries: torch.Tensor, supports: torch.Tensor, q_cu: torch.Tensor,
                      s_cu: torch.Tensor, radius: float, limit: int,
                      exact_width: bool = True, algo: int = 0) -> Tuple[torch.Tensor, int]:

@@ -1,0 +1,92 @@
+"""CPU: on-disk formats around the path (formats.py).  The reference's evaluator
+cannot be executed in this image (benchmark_predator.py uses np.int / np.float, removed from
+numpy 2, and imports nibabel), so these are known-answer tests of the Redwood protocol it
+implements, plus an exact check of the est.log text layout of generic_reg_model.py:382-403."""
+import os
+
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation
+
+from superpoints_registration_amd import formats
+
+
+def _pose(rotvec, t):
+    T = np.eye(4)
+    T[:3, :3] = Rotation.from_rotvec(rotvec).as_matrix()
+    T[:3, 3] = t
+    return T
+
+
+def test_est_log_text_layout_and_round_trip(tmp_path):
+    poses = torch.tensor(np.stack([_pose([0.1, 0.2, -0.3], [0.5, -1.25, 2.0])[:3],
+                                   _pose([0.0, 0.0, 0.4], [1e-3, 0.0, -7.5])[:3]]), dtype=torch.float32)
+    batch = {'src_xyz': [None, None],
+             'src_path': ['test/7-scenes-redkitchen/cloud_bin_5.pth', 'test/7-scenes-redkitchen/cloud_bin_11.pth'],
+             'tgt_path': ['test/7-scenes-redkitchen/cloud_bin_0.pth', 'test/7-scenes-redkitchen/cloud_bin_3.pth']}
+    formats.write_est_log(str(tmp_path), '3DMatch', batch, {'pose': poses})
+    path = tmp_path / '3DMatch' / '7-scenes-redkitchen' / 'est.log'
+    lines = open(path).read().split('\n')
+    assert lines[0] == '0\t5\t-1' and lines[5] == '3\t11\t-1'          # 'tgt\tsrc\t-1' header per pair
+    p0 = np.concatenate([poses[0].numpy().astype(np.float64), [[0, 0, 0, 1]]])
+    assert lines[1] == '\t'.join('{0:.12f}'.format(v) for v in p0[0])
+    assert lines[4] == '0.000000000000\t0.000000000000\t0.000000000000\t1.000000000000'
+    # appending (the reference opens with 'a'), then reading back
+    formats.write_est_log(str(tmp_path), '3DMatch', batch, {'pose': poses[None]})   # (1,B,3,4) form: last entry
+    keys, traj = formats.read_trajectory(str(path))
+    assert keys.tolist() == [['0', '5', '-1'], ['3', '11', '-1']] * 2
+    assert traj.shape == (4, 4, 4) and np.allclose(traj[1, :3], poses[1].numpy(), atol=1e-7)
+
+
+def test_mat2quat_and_transformation_error():
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        R = Rotation.from_rotvec(rng.normal(size=3)).as_matrix()
+        q = formats._mat2quat(R)
+        ref = Rotation.from_matrix(R).as_quat()                       # (x, y, z, w)
+        ref = np.array([ref[3], ref[0], ref[1], ref[2]])
+        ref = -ref if ref[0] < 0 else ref
+        assert np.allclose(q, ref, atol=1e-9)
+    info = np.diag([4.0, 4.0, 4.0, 2.0, 2.0, 2.0])
+    T = _pose([0.0, 0.0, 0.2], [0.1, 0.0, -0.2])
+    q = formats._mat2quat(T[:3, :3])
+    expect = (4 * (0.1 ** 2 + 0.2 ** 2) + 2 * (q[1:] ** 2).sum()) / 4.0
+    assert abs(formats.compute_transformation_error(T, info) - expect) < 1e-12
+
+
+def _write_gt(folder, pairs, poses, n_frag, info):
+    os.makedirs(folder, exist_ok=True)
+    with open(os.path.join(folder, 'gt.log'), 'w') as f:
+        for (i, j), T in zip(pairs, poses):
+            f.write(f'{i}\t{j}\t{n_frag}\n')
+            for r in range(4):
+                f.write('\t'.join(f'{v:.8e}' for v in T[r]) + '\n')
+    with open(os.path.join(folder, 'gt.info'), 'w') as f:
+        for (i, j) in pairs:
+            f.write(f'{i}\t{j}\t{n_frag}\n')
+            for r in range(6):
+                f.write('\t'.join(f'{v:.8e}' for v in info[r]) + '\n')
+
+
+def test_registration_recall_protocol(tmp_path):
+    rng = np.random.default_rng(1)
+    pairs = [(0, 1), (0, 2), (1, 3), (2, 5), (0, 4)]                   # (0,1) is consecutive: not tested
+    gts = [_pose(rng.normal(size=3) * 0.3, rng.normal(size=3)) for _ in pairs]
+    info = np.diag([900.0] * 3 + [400.0] * 3)
+    gt_dir, est_dir = tmp_path / 'gt', tmp_path / 'est'
+    _write_gt(str(gt_dir / 'scene_a'), pairs, gts, 6, info)
+    # estimates: exact, small error (inside 0.2 m RMSE), large error, missing pair, consecutive pair
+    est = {(0, 2): gts[1], (1, 3): gts[2] @ _pose([0, 0, 0.01], [0.05, 0, 0]), (2, 5): gts[3] @ _pose([0, 0, 0.5], [0.5, 0, 0]),
+           (0, 1): gts[0]}
+    batch = {'src_xyz': [None] * len(est), 'src_path': [f'x/scene_a/cloud_bin_{j}.pth' for (_, j) in est],
+             'tgt_path': [f'x/scene_a/cloud_bin_{i}.pth' for (i, _) in est]}
+    # est.log stores T(src -> tgt) under the key (tgt, src)
+    formats.write_est_log(str(est_dir), '', batch, {'pose': torch.tensor(np.stack([T[:3] for T in est.values()]))})
+    report, recall = formats.benchmark(str(est_dir), str(gt_dir))
+    # 4 non-consecutive gt pairs; 2 of them recovered within the threshold
+    assert abs(recall - 2 / 4) < 1e-12
+    flags = np.load(est_dir / 'scene_a' / 'flag.npy').tolist()
+    assert flags == [0, 0, 1, 2]
+    errs = np.load(est_dir / 'scene_a' / 'errors.npy')
+    assert errs[0] < 1e-12 and 0 < errs[1] <= 0.04 < errs[2] and np.isnan(errs[3])
+    assert 'Mean precision: 0.667' in report and 'scene_a' not in report.split('\n')[0]

@@ -239,3 +239,18 @@ def test_effect_of_a_tie_straddling_the_cut_is_one_neighbour(gold, device):
 
 def gold_kpts():
     return load_golden("ops.npz")["kp.c32.kpts"] * np.float32(0.0625 / 0.125)
+
+
+@pytest.mark.parametrize("n,voxel,extent", [(120000, 0.3, 50.0), (5000, 0.05, 1.0), (7, 10.0, 1.0)])
+def test_voxel_downsample_keeps_the_first_point_of_every_voxel(device, n, voxel, extent):
+    """GPU counterpart of the KITTI loader's kiss_icp voxel_down_sample
+    (kitti_pred.py:12-14, :203-204): voxel = trunc(p / voxel_size) in float64 (negative
+    coordinates truncate toward zero), first point per voxel kept."""
+    rng = np.random.default_rng(n)
+    pts = rng.uniform(-extent, extent, (n, 3)).astype(np.float32)
+    pts[: n // 10] *= 0.01                                            # many points per voxel near the origin
+    out = ops.voxel_downsample(torch.from_numpy(pts).to(device), voxel).cpu().numpy()
+    vox = np.trunc(pts.astype(np.float64) / voxel).astype(np.int64)
+    _, first = np.unique(vox, axis=0, return_index=True)
+    ref = pts[np.sort(first)]
+    assert out.shape == ref.shape and np.array_equal(out.view(np.uint32), ref.view(np.uint32))
