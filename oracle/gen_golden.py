@@ -424,6 +424,47 @@ def gen_refine(cfg_tag='kitti', B=2):
     print(os.path.basename(path), os.path.getsize(path) // 1024, 'KB')
 
 
+def sized_inputs(case):
+    """BASELINE.json configs[2..4] at (close to) full size: seeded generators only."""
+    if case == 'c2':     # 3DMatch-shaped indoor pair, ~20 k points per cloud
+        return '3dmatch', [synthetic.make_pair(20000, seed=10)]
+    if case == 'c3':     # KITTI-shaped outdoor pair: 120 k raw LiDAR-like points, pre-voxelised at 0.3 m
+        return 'kitti', [synthetic.make_lidar_pair(120000, seed=3)]
+    return 'modelnet', [synthetic.make_sphere_pair(1024, seed=100 + i) for i in range(8)]   # c4
+
+
+def gen_sized(case):
+    """Reference forward at full size; only small summaries are stored (pose, level sizes, statistics
+    and the first rows of the conditioned features, match weights)."""
+    tag, pairs = sized_inputs(case)
+    model, cfg = ref_harness.make_model(f'qk_regtr_full_{tag}.yaml', seed=0)
+    synthetic.fill_parameters(model, seed=0)
+    B = len(pairs)
+    batch = {'src_xyz': [torch.from_numpy(p[0]) for p in pairs], 'tgt_xyz': [torch.from_numpy(p[1]) for p in pairs],
+             'pose': torch.eye(4)[None, :3].repeat(B, 1, 1)}
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        out = model(batch)
+    meta = batch['kpconv_meta']
+    fx = {'B': np.int32(B), 'pose': out['pose'].numpy(),
+          'level_sizes': np.array([int(p.shape[0]) for p in meta['points']], np.int64),
+          'widths': np.array([int(n.shape[1]) for n in meta['neighbors']], np.int64)}
+    for b in range(B):
+        for side in ('src', 'tgt'):
+            f = out[f'{side}_feat'][b][0]
+            fx[f'{side}_feat_stats{b}'] = np.array([f.mean(), f.abs().mean(), f.abs().max(), f.shape[0]], np.float64)
+            fx[f'{side}_feat_head{b}'] = f[:16].numpy()
+            fx[f'{side}_overlap_head{b}'] = out[f'{side}_overlap'][b][0, :64, 0].numpy()
+        v = out['overlap_prob_list'][b]
+        fx[f'val_stats{b}'] = np.array([v.mean(), v.max(), v.shape[0]], np.float64)
+        fx[f'ind_head{b}'] = out['ind_list'][b][:256].numpy().astype(np.int32)
+    path = os.path.join(OUT, f'sized_{case}.npz')
+    np.savez_compressed(path, **fx)
+    print(os.path.basename(path), os.path.getsize(path) // 1024, 'KB', fx['level_sizes'], fx['widths'],
+          f'{time.time() - t0:.0f} s', out['pose'][0, :, 3].numpy())
+
+
 def main():
     assert ref_harness.available(), "needs /root/reference (dev container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -449,6 +490,9 @@ def main():
             gen_train('3dmatch', 2, 2)
         if 'refine' in what:
             gen_refine('kitti', 2)
+        for case in ('c2', 'c3', 'c4'):
+            if f'sized_{case}' in what or 'sized' in what:
+                gen_sized(case)
     finally:
         os.chdir(cwd)
 

@@ -63,6 +63,52 @@ def _seed_of(name: str, seed: int) -> int:
     return int.from_bytes(h[:8], "little") % (2 ** 63 - 1)
 
 
+def voxel_first_point(points: np.ndarray, voxel: float) -> np.ndarray:
+    """numpy statement of the KITTI loader's pre-downsampling (kitti_pred.py:12-14: kiss_icp keeps the
+    first point of every voxel, voxel = trunc(p / voxel) in float64); kept points in original order."""
+    vox = np.trunc(points.astype(np.float64) / voxel).astype(np.int64)
+    _, first = np.unique(vox, axis=0, return_index=True)
+    return points[np.sort(first)]
+
+
+def make_lidar_pair(n: int = 120000, seed: int = 0, r_max: float = 26.0, voxel: float = 0.3):
+    """KITTI-odometry-shaped pair (SURVEY.md 8d cfg 4): a rotating-LiDAR-like scan -- radial point
+    density ~ 1/r on a ground plane out to r_max with 0.3 m height noise, plus building-like
+    vertical faces and a few poles -- seen from two poses ~1.5 m apart, each pre-voxelised at
+    `voxel` like the reference loader.  Returns (src, tgt, pose_gt [3,4]) float32; tuned so that
+    the KITTI config ends with ~1-2 k superpoints per cloud."""
+    rng = np.random.default_rng(seed)
+
+    def scan():
+        n_g = int(0.62 * n)
+        r = rng.uniform(2.5, r_max, n_g)                      # area density ~ 1/r
+        th = rng.uniform(0, 2 * np.pi, n_g)
+        ground = np.stack([r * np.cos(th), r * np.sin(th), rng.normal(0.0, 0.3, n_g) - 1.7], 1)
+        walls = []
+        n_w = n - n_g
+        for k in range(24):                                   # facades between 6 m and r_max - 3 m, 2..6 m tall
+            m = n_w // 24
+            ang = rng.uniform(0, 2 * np.pi)
+            dist = rng.uniform(6, r_max - 3)
+            length, height = rng.uniform(5, 14), rng.uniform(2, 6)
+            u = rng.uniform(-0.5, 0.5, m) * length
+            h = rng.uniform(0, 1, m) ** 1.5 * height - 1.7
+            c, s_ = np.cos(ang), np.sin(ang)
+            base = np.array([dist * c, dist * s_])
+            tangent = np.array([-s_, c])
+            xy = base[None] + u[:, None] * tangent[None] + rng.normal(0, 0.03, (m, 2))
+            walls.append(np.concatenate([xy, h[:, None]], 1))
+        return np.concatenate([ground] + walls)
+    world = scan()
+    R = rotation_z(0.035)
+    t = np.array([1.45, -0.3, 0.02])
+    src = world + rng.normal(0, 0.02, world.shape)
+    tgt = (world[rng.permutation(len(world))] + rng.normal(0, 0.02, world.shape)) @ R.T + t
+    pose = np.concatenate([R, t[:, None]], 1)
+    return (voxel_first_point(src.astype(np.float32), voxel), voxel_first_point(tgt.astype(np.float32), voxel),
+            pose.astype(np.float32))
+
+
 @torch.no_grad()
 def fill_parameters(model: torch.nn.Module, seed: int = 0) -> None:
     """Overwrite every entry of model.state_dict() with values drawn from a

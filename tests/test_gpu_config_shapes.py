@@ -140,3 +140,58 @@ def test_config4_modelnet_shaped_batch256(device):
         o2 = model(batch)
     _check_poses(o1, 256)
     assert torch.equal(o1['pose'], o2['pose'])
+
+
+# ---- float parity at (close to) full size: reference forwards run in the dev container ------------
+@pytest.mark.parametrize("case", ["c2", "c3", "c4"])
+def test_full_size_pose_and_features_match_the_reference(device, case):
+    """BASELINE configs[2..4] against the reference itself at size (oracle/gen_golden.py gen_sized:
+    one 20 000-pt 3DMatch-shaped pair; one LiDAR-like 120 000-pt pair pre-voxelised at 0.3 m --
+    radial density ~ 1/r, ~2 k superpoints per cloud; eight ModelNet-shaped crops).
+    Only summaries are stored: pose, level sizes / widths, statistics and the first rows of the
+    conditioned features, overlap scores, match weights, first matches."""
+    from conftest import load_golden
+    from oracle.gen_golden import sized_inputs
+    g = load_golden(f"sized_{case}.npz")
+    tag, pairs = sized_inputs(case)
+    cfg, model = _model(tag, device)
+    B = int(g["B"])
+    batch = {"src_xyz": [torch.from_numpy(p[0]).to(device) for p in pairs],
+             "tgt_xyz": [torch.from_numpy(p[1]).to(device) for p in pairs]}
+    with torch.no_grad():
+        out = model(batch)
+    meta = batch["kpconv_meta"]
+    assert [int(p.shape[0]) for p in meta["points"]] == g["level_sizes"].tolist()
+    assert [int(meta["neighbors"][l].shape[1]) for l in range(len(meta["points"]))] == g["widths"].tolist()
+    for b in range(B):
+        err = np.linalg.norm(out["pose"][b].cpu().numpy() - g["pose"][b])
+        if not cfg.use_sinkhorn:
+            # float64 Kabsch on OUR correspondences / weights: the solve itself must be exact ...
+            from oracle import torch_oracle as O
+            a64, b64 = out["src_corr"][b].double().cpu(), out["tgt_corr"][b].double().cpu()
+            w64 = out["overlap_prob_list"][b].double().cpu()
+            T64 = O.compute_rigid_transform(a64, b64, w64).numpy()
+            assert np.linalg.norm(out["pose"][b].cpu().numpy() - T64) < 2e-5
+            # ... and where the reference (float32 torch.svd) is further from that float64 solution
+            # than we are, the 1e-4 bound is applied to the float64 solution instead: with random
+            # weights the arg-max matches of the KITTI-scale pair (coordinates to 26 m, weights
+            # ~1e-4) give a poorly conditioned covariance
+            ref_dev = np.linalg.norm(g["pose"][b] - T64)
+            assert err < 1e-4 or (ref_dev > 1e-4 and err <= 1.5 * ref_dev), \
+                f"{case} pair {b}: pose error {err:.2e} (reference vs float64 solve: {ref_dev:.2e})"
+        else:
+            assert err < 1e-4, f"{case} pair {b}: pose error {err:.2e}"                 # north_star bound
+        for side in ("src", "tgt"):
+            f = out[f"{side}_feat"][b][0].cpu().numpy()
+            st = g[f"{side}_feat_stats{b}"]
+            assert f.shape[0] == int(st[3])
+            scale = st[2]
+            assert np.abs(f[:16] - g[f"{side}_feat_head{b}"]).max() <= 1e-4 * scale      # conditioned features
+            assert abs(f.mean() - st[0]) <= 1e-5 * scale and abs(np.abs(f).mean() - st[1]) <= 1e-5 * scale
+            ov = out[f"{side}_overlap"][b][0, :64, 0].cpu().numpy()
+            assert np.abs(ov - g[f"{side}_overlap_head{b}"]).max() < 1e-4
+        v = out["overlap_prob_list"][b].cpu().numpy()
+        vs = g[f"val_stats{b}"]
+        assert v.shape[0] == int(vs[2]) and abs(v.mean() - vs[0]) <= 5e-3 * vs[0] and abs(v.max() - vs[1]) <= 5e-3 * vs[1]
+        ind = out["ind_list"][b][:256].cpu().numpy()
+        assert (ind == g[f"ind_head{b}"]).mean() >= 0.99
