@@ -145,6 +145,32 @@ size_t spr_linear_workspace_bytes(void);
 int spr_linear(const float* x, int m, int k, const float* w, int n,
                const float* bias, const float* residual, int act, float* out,
                void* ws, size_t ws_bytes, void* stream);
+/* Operand-range hand-over.  The split-fp16 arithmetic scales every operand tensor by a power of
+ * two derived from max |x|; by default spr_linear measures it with a pass over x.  A producer
+ * that has just written x can publish the range instead, as an array of per-workgroup partial
+ * maxima in device memory (any count; their maximum must bound max |x| from above):
+ *   x_range / x_range_n     range of x (NULL: measure);
+ *   out_range (capacity out_range_cap floats): if the GEMM runs with <= out_range_cap
+ *     workgroups it writes one partial per workgroup and sets *out_range_n_host (a HOST int)
+ *     to their number, else 0 (nothing published).
+ * spr_layernorm_r publishes the ranges of its two outputs (spr_layernorm_range_count(m)
+ * partials each); spr_attn_inproj_varlen_fwd_r accepts the input ranges and publishes a bound of
+ * its output (1 float: the attention output is a convex combination of value rows). */
+int spr_linear_r(const float* x, int m, int k, const float* w, int n, const float* bias,
+                 const float* residual, int act, float* out, const float* x_range,
+                 int x_range_n, float* out_range, int out_range_cap, int* out_range_n_host,
+                 void* ws, size_t ws_bytes, void* stream);
+int spr_layernorm_range_count(int m);
+int spr_layernorm_r(const float* x, int m, int c, const float* gamma, const float* beta,
+                    float eps, const float* pos, float* out_norm, float* out_pos,
+                    float* range_norm, float* range_pos, void* stream);
+int spr_attn_inproj_varlen_fwd_r(const float* x_qk, const float* x_v, int t, const float* w_in,
+                                 const float* b_in, const int* cu, const int* kv_seg, int nseg,
+                                 int max_len_host, int nhead, int head_dim, float scale,
+                                 float* out, int o_stride, const float* xqk_range,
+                                 int xqk_range_n, const float* xv_range, int xv_range_n,
+                                 float* out_range, void* ws, size_t ws_bytes, void* stream);
+
 /* Arithmetic of spr_linear (and of the correlation GEMMs inside the matching
  * head):
  *   1 (default) = split-fp16 MFMA: each operand tensor is scaled by a power of

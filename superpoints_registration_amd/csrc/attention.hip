@@ -620,12 +620,13 @@ __global__ __launch_bounds__(256) void k_plane_scales(const float* __restrict__ 
                                                       const float* __restrict__ v_parts,
                                                       const float* __restrict__ rowl1,
                                                       const float* __restrict__ bias, int d, float qscale,
-                                                      float* __restrict__ scales) {
+                                                      float* __restrict__ scales, int nq_parts, int nk_parts,
+                                                      int nv_parts, float* __restrict__ out_range) {
   __shared__ float sh[17];
   __shared__ float blk[6];
-  float qb = block_absmax(q_parts, sh);
-  float kb = block_absmax(k_parts, sh);
-  float vb = block_absmax(v_parts, sh);
+  float qb = block_absmax(q_parts, sh, nq_parts);
+  float kb = block_absmax(k_parts, sh, nk_parts);
+  float vb = block_absmax(v_parts, sh, nv_parts);
   if (rowl1 != nullptr) {
     for (int b = 0; b < 3; ++b) {
       float l1 = 0.f, bm = 0.f;
@@ -666,6 +667,8 @@ __global__ __launch_bounds__(256) void k_plane_scales(const float* __restrict__ 
     scales[1] = pow2f(ek);
     scales[2] = pow2f(ev);
     scales[3] = pow2f(-ev);
+    // the attention output is a convex combination of value rows: |out| <= max |v| < 2^(15 - ev)
+    if (out_range) out_range[0] = pow2f(15 - ev);
   }
 }
 
@@ -753,7 +756,8 @@ extern "C" int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k,
   if (int rc = launch_absmax2(q, t, d_model, q_stride, sm.p0, k, t, d_model, k_stride, sm.p1, stream)) return rc;
   if (int rc = launch_absmax(v, t, d_model, v_stride, sm.p2, stream)) return rc;
   hipLaunchKernelGGL(k_plane_scales, dim3(1), dim3(256), 0, stream, sm.p0, sm.p1, sm.p2, (const float*)nullptr,
-                     (const float*)nullptr, d_model, scale * 1.4426950408889634f, sm.scales);
+                     (const float*)nullptr, d_model, scale * 1.4426950408889634f, sm.scales, kAmaxParts, kAmaxParts,
+                     kAmaxParts, (float*)nullptr);
   hipLaunchKernelGGL(k_attn_pack, dim3((unsigned)(tp / PT)), dim3(256), 0, stream, q, q_stride, k, k_stride,
                      v, v_stride, cu, nseg, d_model, t, (int)tp, sm.scales, pl.qh, pl.ql, pl.kh, pl.kl,
                      pl.vth, pl.vtl);
@@ -772,6 +776,16 @@ extern "C" int spr_attn_inproj_varlen_fwd(const float* x_qk, const float* x_v, i
                                           const float* b_in, const int* cu, const int* kv_seg, int nseg,
                                           int max_len_host, int nhead, int head_dim, float scale, float* out,
                                           int o_stride, void* ws, size_t ws_bytes, void* stream_) {
+  return spr_attn_inproj_varlen_fwd_r(x_qk, x_v, t, w_in, b_in, cu, kv_seg, nseg, max_len_host, nhead, head_dim, scale,
+                                      out, o_stride, nullptr, 0, nullptr, 0, nullptr, ws, ws_bytes, stream_);
+}
+
+extern "C" int spr_attn_inproj_varlen_fwd_r(const float* x_qk, const float* x_v, int t, const float* w_in,
+                                            const float* b_in, const int* cu, const int* kv_seg, int nseg,
+                                            int max_len_host, int nhead, int head_dim, float scale, float* out,
+                                            int o_stride, const float* xqk_range, int xqk_range_n,
+                                            const float* xv_range, int xv_range_n, float* out_range, void* ws,
+                                            size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(head_dim == HD, "attention: head_dim must be %d (got %d)", HD, head_dim);
   SPR_REQUIRE(nhead * head_dim == 256, "attention in-projection: d_model must be 256 (got %d)", nhead * head_dim);
@@ -789,6 +803,10 @@ extern "C" int spr_attn_inproj_varlen_fwd(const float* x_qk, const float* x_v, i
   if (int rc = carve(ws, planes_bytes, t, nseg, d, tp, pl, sm)) return rc;
   const bool gemm_split = gemm_mode() == 1;
   if (mode == 0 || t < 256 || !gemm_split) {
+    if (out_range != nullptr) {   // this route publishes no range: an infinite bound would be wrong, so measure later
+      SPR_REQUIRE(false, "attention in-projection: out_range is only available on the fused split-fp16 path "
+                         "(attn mode %d, gemm split %d, t=%d)", mode, (int)gemm_split, t);
+    }
     // exact-f32 mode (and tiny inputs): plain projection into the workspace, then the
     // unfused core -- same results as spr_linear + spr_attn_varlen_fwd
     float* qkv = (float*)((char*)ws + planes_bytes);
@@ -825,21 +843,39 @@ extern "C" int spr_attn_inproj_varlen_fwd(const float* x_qk, const float* x_v, i
   pl.tp = (int)tp;
   // operand ranges: max|x| (inputs), max|w| (the projection's own operand scale) and the plane
   // multipliers from the bounds max|x| * max row-L1(W block) + max|bias block|
-  if (int rc = launch_absmax2(x_qk, t, d, d, sm.p0, w_in, 3 * d, d, d, sm.p1, stream)) return rc;
-  const float* xvp = sm.p0;
+  // input ranges: published by the producer (LayerNorm) or measured here
+  const float* xqp = sm.p0;
+  int n_xq = kAmaxParts;
+  if (xqk_range != nullptr) {
+    SPR_REQUIRE(xqk_range_n >= 1, "attention in-projection: xqk_range needs a count");
+    xqp = xqk_range;
+    n_xq = xqk_range_n;
+    if (int rc = launch_absmax(w_in, 3 * d, d, d, sm.p1, stream)) return rc;
+  } else {
+    if (int rc = launch_absmax2(x_qk, t, d, d, sm.p0, w_in, 3 * d, d, d, sm.p1, stream)) return rc;
+  }
+  const float* xvp = xqp;
+  int n_xv = n_xq;
   if (x_v != x_qk) {
-    if (int rc = launch_absmax(x_v, t, d, d, sm.p2, stream)) return rc;
-    xvp = sm.p2;
+    if (xv_range != nullptr) {
+      SPR_REQUIRE(xv_range_n >= 1, "attention in-projection: xv_range needs a count");
+      xvp = xv_range;
+      n_xv = xv_range_n;
+    } else {
+      if (int rc = launch_absmax(x_v, t, d, d, sm.p2, stream)) return rc;
+      xvp = sm.p2;
+      n_xv = kAmaxParts;
+    }
   }
   hipLaunchKernelGGL(k_row_l1, dim3(cdiv((long)3 * d * 64, 256)), dim3(256), 0, stream, w_in, 3 * d, d, sm.rowl1);
-  hipLaunchKernelGGL(k_plane_scales, dim3(1), dim3(256), 0, stream, sm.p0, sm.p0, xvp, sm.rowl1, b_in, d,
-                     scale * 1.4426950408889634f, sm.scales);
+  hipLaunchKernelGGL(k_plane_scales, dim3(1), dim3(256), 0, stream, xqp, xqp, xvp, sm.rowl1, b_in, d,
+                     scale * 1.4426950408889634f, sm.scales, n_xq, n_xq, n_xv, out_range);
   hipLaunchKernelGGL(k_attn_zero_gaps, dim3(d), dim3(256), 0, stream, cu, nseg, (int)tp, pl.vth, pl.vtl);
   if (x_v == x_qk) {
-    if (int rc = launch_inproj_planes(x_qk, t, d, w_in, 3 * d, b_in, 0, pl, sm.p0, sm.p1, stream)) return rc;
+    if (int rc = launch_inproj_planes(x_qk, t, d, w_in, 3 * d, b_in, 0, pl, xqp, n_xq, sm.p1, stream)) return rc;
   } else {
-    if (int rc = launch_inproj_planes(x_qk, t, d, w_in, 2 * d, b_in, 0, pl, sm.p0, sm.p1, stream)) return rc;
-    if (int rc = launch_inproj_planes(x_v, t, d, w_in + (size_t)2 * d * d, d, b_in + 2 * d, 2 * d, pl, xvp, sm.p1,
+    if (int rc = launch_inproj_planes(x_qk, t, d, w_in, 2 * d, b_in, 0, pl, xqp, n_xq, sm.p1, stream)) return rc;
+    if (int rc = launch_inproj_planes(x_v, t, d, w_in + (size_t)2 * d * d, d, b_in + 2 * d, 2 * d, pl, xvp, n_xv, sm.p1,
                                       stream))
       return rc;
   }

@@ -25,7 +25,7 @@ struct AttnPlanes {
 // 512..767 = V; d_model = 256, head_dim = 32).  n and f0 are multiples of 256.
 // a_parts / w_parts: absmax partials of x and w (launch_absmax).
 int launch_inproj_planes(const float* x, int m, int k, const float* w, int n, const float* bias, int f0,
-                         const AttnPlanes& planes, const float* a_parts, const float* w_parts,
+                         const AttnPlanes& planes, const float* a_parts, int n_aparts, const float* w_parts,
                          hipStream_t stream);
 
 // Plain GEMM out = x w^T + bias with pre-measured operand ranges (nullptr in exact-f32 mode).

@@ -35,10 +35,11 @@ constexpr int LDSK = BK + 1;
 // compile-time so the 16 residual loads are issued back to back (one exposed
 // round trip per tile, not one per element) and no per-element branch remains.
 template <int ACT, bool RES>
-__device__ __forceinline__ void store_tile(const f32x16& acc, int row0, int col, int M, int N,
-                                           float bv, const float* __restrict__ residual,
-                                           float* __restrict__ out, int lh, float unscale = 1.0f) {
-  if (col >= N) return;
+__device__ __forceinline__ float store_tile(const f32x16& acc, int row0, int col, int M, int N,
+                                            float bv, const float* __restrict__ residual,
+                                            float* __restrict__ out, int lh, float unscale = 1.0f) {
+  if (col >= N) return 0.f;
+  float vmax = 0.f;
   float res[16];
   if (RES) {
 #pragma unroll
@@ -54,8 +55,12 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, int row0, int col,
     if (RES) v += res[r];
     if (ACT == SPR_ACT_RELU) v = fmaxf(v, 0.f);
     if (ACT == SPR_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-    if (row < M) out[(size_t)row * N + col] = v;
+    if (row < M) {
+      out[(size_t)row * N + col] = v;
+      vmax = fmaxf(vmax, fabsf(v));
+    }
   }
+  return vmax;
 }
 
 // WM x WN waves, each a 32x32 tile.  256 threads when WM*WN == 4.
@@ -193,8 +198,8 @@ template <int BM, int BN, int WM, int WN, int ACT, bool RES, bool PLANES = false
 __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
     const float* __restrict__ X, int M, int K, const float* __restrict__ Wt, int N,
     const float* __restrict__ bias, const float* __restrict__ residual,
-    float* __restrict__ out, AttnPlanes pl, int f0, const float* __restrict__ a_parts,
-    const float* __restrict__ w_parts) {
+    float* __restrict__ out, AttnPlanes pl, int f0, const float* __restrict__ a_parts, int n_aparts,
+    const float* __restrict__ w_parts, float* __restrict__ out_parts) {
   constexpr int NT = WM * WN * 64;      // threads (4 or 8 waves)
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);   // 32x32 sub-tiles per wave
   constexpr int A_F4 = BM * BK / 4, B_F4 = BN * BK / 4;
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
   float sa, sb, unscale;
   {
     float* shf = reinterpret_cast<float*>(gemm_smem);
-    const int ka = pow2_exp_for(block_absmax(a_parts, shf));
+    const int ka = pow2_exp_for(block_absmax(a_parts, shf, n_aparts));
     const int kb = pow2_exp_for(block_absmax(w_parts, shf));
     __syncthreads();   // shf aliases the operand tiles
     sa = pow2f(ka);
@@ -378,13 +383,28 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
     }
     return;
   }
+  float omax = 0.f;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + l31;
     const float bv = (bias && col < N) ? bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
-      store_tile<ACT, RES>(acc[i][j], m0 + (wm * TM + i) * 32, col, M, N, bv, residual, out, lh, unscale);
+      omax = fmaxf(omax, store_tile<ACT, RES>(acc[i][j], m0 + (wm * TM + i) * 32, col, M, N, bv, residual, out, lh,
+                                              unscale));
+  }
+  if (out_parts != nullptr) {
+    // publish max |out| of this tile: the consumer GEMM then needs no pass over `out` to scale it
+    float* shf = reinterpret_cast<float*>(gemm_smem);
+    omax = wave_max(omax);
+    __syncthreads();
+    if (lane == 0) shf[wave] = omax;
+    __syncthreads();
+    if (tid == 0) {
+      float t = shf[0];
+      for (int w_ = 1; w_ < WM * WN; ++w_) t = fmaxf(t, shf[w_]);
+      out_parts[blockIdx.x] = t;
+    }
   }
 }
 
@@ -415,10 +435,13 @@ template <int MAXV>
 __global__ void k_layernorm(const float* __restrict__ x, int m, int c,
                             const float* __restrict__ gamma, const float* __restrict__ beta,
                             float eps, const float* __restrict__ pos, float* __restrict__ out_norm,
-                            float* __restrict__ out_pos) {
+                            float* __restrict__ out_pos, float* __restrict__ range_norm,
+                            float* __restrict__ range_pos) {
+  __shared__ float shr[8];
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  if (row >= m) return;
+  float mxn = 0.f, mxp = 0.f;
+  if (row < m) {
   const int nv = c >> 6;
   float v[MAXV];
   float s = 0.f;
@@ -440,8 +463,27 @@ __global__ void k_layernorm(const float* __restrict__ x, int m, int c,
     if (i < nv) {
       const int ch = i * 64 + lane;
       const float y = (v[i] - mean) * rstd * gamma[ch] + beta[ch];
+      mxn = fmaxf(mxn, fabsf(y));
       if (out_norm) out_norm[(size_t)row * c + ch] = y;
-      if (out_pos) out_pos[(size_t)row * c + ch] = y + pos[(size_t)row * c + ch];
+      if (out_pos) {
+        const float yp = y + pos[(size_t)row * c + ch];
+        mxp = fmaxf(mxp, fabsf(yp));
+        out_pos[(size_t)row * c + ch] = yp;
+      }
+    }
+  }
+  }
+  if (range_norm || range_pos) {   // one partial per workgroup (4 rows): the consumer GEMM's operand range
+    mxn = wave_max(mxn);
+    mxp = wave_max(mxp);
+    if (lane == 0) {
+      shr[threadIdx.x >> 6] = mxn;
+      shr[4 + (threadIdx.x >> 6)] = mxp;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (range_norm) range_norm[blockIdx.x] = fmaxf(fmaxf(shr[0], shr[1]), fmaxf(shr[2], shr[3]));
+      if (range_pos) range_pos[blockIdx.x] = fmaxf(fmaxf(shr[4], shr[5]), fmaxf(shr[6], shr[7]));
     }
   }
 }
@@ -472,8 +514,9 @@ using namespace spr;
 namespace {
 template <int ACT, bool RES>
 int launch_gemm(const float* x, int m, int k, const float* w, int n, const float* bias,
-                const float* residual, float* out, const float* a_parts, const float* w_parts,
-                hipStream_t stream) {
+                const float* residual, float* out, const float* a_parts, int n_aparts, const float* w_parts,
+                float* out_parts, int out_cap, int* out_n, hipStream_t stream) {
+  if (out_n) *out_n = 0;
   if (spr::g_gemm_mode.load(std::memory_order_relaxed) == 1) {
     SPR_REQUIRE(a_parts != nullptr && w_parts != nullptr, "linear: split-fp16 mode needs the absmax partials");
     // LDS bytes of a BM x BN tile's slab (hi + lo planes of both operands)
@@ -483,16 +526,19 @@ int launch_gemm(const float* x, int m, int k, const float* w, int n, const float
       // L2 (the 128-wide tiles below need 2-4x the L2 traffic and are bound by it)
       auto kern = spr::k_gemm_nt_h3<256, 256, 4, 2, ACT, RES>;
       if (int rc = ensure_dyn_lds((const void*)kern, (int)lds(256, 256))) return rc;
-      hipLaunchKernelGGL(kern, dim3(cdiv(n, 256) * cdiv(m, 256)), dim3(512), lds(256, 256), stream, x, m, k,
-                         w, n, bias, residual, out, spr::AttnPlanes(), 0, a_parts, w_parts);
+      const int grid = cdiv(n, 256) * cdiv(m, 256);
+      float* op = (out_parts && grid <= out_cap) ? out_parts : nullptr;   // range published only if it fits
+      if (op && out_n) *out_n = grid;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds(256, 256), stream, x, m, k,
+                         w, n, bias, residual, out, spr::AttnPlanes(), 0, a_parts, n_aparts, w_parts, op);
     } else if (n > 32) {
       hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 64, 4, 1, ACT, RES>), dim3(cdiv(n, 64) * cdiv(m, 128)),
                          dim3(256), lds(128, 64), stream, x, m, k, w, n, bias, residual, out, spr::AttnPlanes(), 0,
-                         a_parts, w_parts);
+                         a_parts, n_aparts, w_parts, (float*)nullptr);
     } else {
       hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 32, 4, 1, ACT, RES>), dim3(cdiv(n, 32) * cdiv(m, 128)),
                          dim3(256), lds(128, 32), stream, x, m, k, w, n, bias, residual, out, spr::AttnPlanes(), 0,
-                         a_parts, w_parts);
+                         a_parts, n_aparts, w_parts, (float*)nullptr);
     }
   } else if (n % 64 == 0) {
     hipLaunchKernelGGL((spr::k_gemm_nt<2, 2, ACT, RES>), dim3((n / 64) * cdiv(m, 64)), dim3(256), 0, stream,
@@ -509,7 +555,7 @@ int launch_gemm(const float* x, int m, int k, const float* w, int n, const float
 int spr::gemm_mode() { return spr::g_gemm_mode.load(std::memory_order_relaxed); }
 
 int spr::launch_inproj_planes(const float* x, int m, int k, const float* w, int n, const float* bias, int f0,
-                              const AttnPlanes& planes, const float* a_parts, const float* w_parts,
+                              const AttnPlanes& planes, const float* a_parts, int n_aparts, const float* w_parts,
                               hipStream_t stream) {
   SPR_REQUIRE(n % 256 == 0 && f0 % 256 == 0 && k % BK == 0 && m >= 1 && bias != nullptr,
               "in-projection planes: bad shape (m=%d k=%d n=%d)", m, k, n);
@@ -518,7 +564,7 @@ int spr::launch_inproj_planes(const float* x, int m, int k, const float* w, int 
   const size_t lds = (size_t)(256 + 256) * spr::HS * 2 * sizeof(_Float16);
   if (int rc = ensure_dyn_lds((const void*)kern, (int)lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(cdiv(n, 256) * cdiv(m, 256)), dim3(512), lds, stream, x, m, k, w, n, bias,
-                     (const float*)nullptr, (float*)nullptr, planes, f0, a_parts, w_parts);
+                     (const float*)nullptr, (float*)nullptr, planes, f0, a_parts, n_aparts, w_parts, (float*)nullptr);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -528,17 +574,21 @@ int spr::launch_inproj_planes(const float* x, int m, int k, const float* w, int 
 // (which pass nullptr).
 int spr::launch_linear_ranged(const float* x, int m, int k, const float* w, int n, const float* bias,
                               float* out, const float* a_parts, const float* w_parts, hipStream_t stream) {
-  return launch_gemm<SPR_ACT_NONE, false>(x, m, k, w, n, bias, nullptr, out, a_parts, w_parts, stream);
+  return launch_gemm<SPR_ACT_NONE, false>(x, m, k, w, n, bias, nullptr, out, a_parts, kAmaxParts, w_parts, nullptr, 0,
+                                          nullptr, stream);
 }
 
 extern "C" size_t spr_linear_workspace_bytes(void) { return 2 * align_up(kAmaxParts * sizeof(float), 256); }
 
-extern "C" int spr_linear(const float* x, int m, int k, const float* w, int n, const float* bias,
-                          const float* residual, int act, float* out, void* ws, size_t ws_bytes,
-                          void* stream_) {
+extern "C" int spr_linear_r(const float* x, int m, int k, const float* w, int n, const float* bias,
+                            const float* residual, int act, float* out, const float* x_range, int x_range_n,
+                            float* out_range, int out_range_cap, int* out_range_n_host, void* ws, size_t ws_bytes,
+                            void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (out_range_n_host) *out_range_n_host = 0;
   SPR_REQUIRE(m > 0 && k > 0 && n > 0, "linear: bad sizes m=%d k=%d n=%d", m, k, n);
   SPR_REQUIRE(act >= 0 && act <= 2, "linear: unknown activation %d", act);
+  SPR_REQUIRE(x_range == nullptr || x_range_n >= 1, "linear: x_range needs a count");
   if (n < 16 || k % BK != 0) {
     SPR_REQUIRE(n <= 64 || k % BK == 0, "linear: k must be a multiple of %d for n > 64 (k=%d n=%d)", BK, k, n);
     const long waves = (long)m * n;
@@ -548,25 +598,41 @@ extern "C" int spr_linear(const float* x, int m, int k, const float* w, int n, c
     return 0;
   }
   const float *a_parts = nullptr, *w_parts = nullptr;
+  int n_ap = kAmaxParts;
   if (spr::gemm_mode() == 1) {
     SPR_REQUIRE(ws != nullptr && ws_bytes >= spr_linear_workspace_bytes(),
                 "linear: workspace too small (%zu bytes given, spr_linear_workspace_bytes() needed)", ws_bytes);
     Workspace wk(ws, ws_bytes);
     float* ap = wk.take<float>(kAmaxParts);
     float* wp = wk.take<float>(kAmaxParts);
-    if (int rc = launch_absmax2(x, m, k, k, ap, w, n, k, k, wp, stream)) return rc;
-    a_parts = ap;
+    if (x_range != nullptr) {   // the producer of x published its range: only the weights are measured
+      if (int rc = launch_absmax(w, n, k, k, wp, stream)) return rc;
+      a_parts = x_range;
+      n_ap = x_range_n;
+    } else {
+      if (int rc = launch_absmax2(x, m, k, k, ap, w, n, k, k, wp, stream)) return rc;
+      a_parts = ap;
+    }
     w_parts = wp;
   }
   const bool res = residual != nullptr;
+#define SPR_LG(A, R) launch_gemm<A, R>(x, m, k, w, n, bias, residual, out, a_parts, n_ap, w_parts, out_range, \
+                                       out_range_cap, out_range_n_host, stream)
   switch (act * 2 + (res ? 1 : 0)) {
-    case 0: return launch_gemm<SPR_ACT_NONE, false>(x, m, k, w, n, bias, residual, out, a_parts, w_parts, stream);
-    case 1: return launch_gemm<SPR_ACT_NONE, true>(x, m, k, w, n, bias, residual, out, a_parts, w_parts, stream);
-    case 2: return launch_gemm<SPR_ACT_RELU, false>(x, m, k, w, n, bias, residual, out, a_parts, w_parts, stream);
-    case 3: return launch_gemm<SPR_ACT_RELU, true>(x, m, k, w, n, bias, residual, out, a_parts, w_parts, stream);
-    case 4: return launch_gemm<SPR_ACT_SIGMOID, false>(x, m, k, w, n, bias, residual, out, a_parts, w_parts, stream);
-    default: return launch_gemm<SPR_ACT_SIGMOID, true>(x, m, k, w, n, bias, residual, out, a_parts, w_parts, stream);
+    case 0: return SPR_LG(SPR_ACT_NONE, false);
+    case 1: return SPR_LG(SPR_ACT_NONE, true);
+    case 2: return SPR_LG(SPR_ACT_RELU, false);
+    case 3: return SPR_LG(SPR_ACT_RELU, true);
+    case 4: return SPR_LG(SPR_ACT_SIGMOID, false);
+    default: return SPR_LG(SPR_ACT_SIGMOID, true);
   }
+#undef SPR_LG
+}
+
+extern "C" int spr_linear(const float* x, int m, int k, const float* w, int n, const float* bias,
+                          const float* residual, int act, float* out, void* ws, size_t ws_bytes,
+                          void* stream_) {
+  return spr_linear_r(x, m, k, w, n, bias, residual, act, out, nullptr, 0, nullptr, 0, nullptr, ws, ws_bytes, stream_);
 }
 
 extern "C" int spr_set_gemm_mode(int mode) {
@@ -575,21 +641,29 @@ extern "C" int spr_set_gemm_mode(int mode) {
   return 0;
 }
 
-extern "C" int spr_layernorm(const float* x, int m, int c, const float* gamma, const float* beta,
-                             float eps, const float* pos, float* out_norm, float* out_pos,
-                             void* stream_) {
+extern "C" int spr_layernorm_range_count(int m) { return cdiv((long)(m > 0 ? m : 1) * 64, 256); }
+
+extern "C" int spr_layernorm_r(const float* x, int m, int c, const float* gamma, const float* beta,
+                               float eps, const float* pos, float* out_norm, float* out_pos, float* range_norm,
+                               float* range_pos, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(m > 0 && c % 64 == 0 && c <= 1024, "layernorm: c must be a multiple of 64 and <= 1024 (c=%d)", c);
   SPR_REQUIRE(out_pos == nullptr || pos != nullptr, "layernorm: out_pos needs pos");
   const int grid = cdiv((long)m * 64, 256);
   if (c <= 256)
     hipLaunchKernelGGL(k_layernorm<4>, dim3(grid), dim3(256), 0, stream, x, m, c, gamma, beta, eps,
-                       pos, out_norm, out_pos);
+                       pos, out_norm, out_pos, range_norm, range_pos);
   else
     hipLaunchKernelGGL(k_layernorm<16>, dim3(grid), dim3(256), 0, stream, x, m, c, gamma, beta, eps,
-                       pos, out_norm, out_pos);
+                       pos, out_norm, out_pos, range_norm, range_pos);
   SPR_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int spr_layernorm(const float* x, int m, int c, const float* gamma, const float* beta,
+                             float eps, const float* pos, float* out_norm, float* out_pos,
+                             void* stream_) {
+  return spr_layernorm_r(x, m, c, gamma, beta, eps, pos, out_norm, out_pos, nullptr, nullptr, stream_);
 }
 
 extern "C" int spr_posemb_sine(const float* xyz, int n, int d_model, float scale, float temperature,

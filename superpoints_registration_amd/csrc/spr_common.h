@@ -203,9 +203,12 @@ __host__ __device__ __forceinline__ float pow2f(int k) {   // 2^k, |k| <= 126
 constexpr int kAmaxParts = 512;
 // Reduces parts[0..kAmaxParts) over the workgroup; `sh` = 17 floats of LDS.
 // Contains two __syncthreads().  Result returned to every thread.
-__device__ __forceinline__ float block_absmax(const float* __restrict__ parts, float* sh) {
+// n: number of partials (kAmaxParts for a measured range; producers that publish the range of
+// their own output -- LayerNorm, the ReLU GEMM, the attention core -- write one partial per
+// workgroup, or a single bound).
+__device__ __forceinline__ float block_absmax(const float* __restrict__ parts, float* sh, int n = kAmaxParts) {
   float m = 0.f;
-  for (int i = threadIdx.x; i < kAmaxParts; i += blockDim.x) m = fmaxf(m, parts[i]);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, parts[i]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;

@@ -38,6 +38,25 @@ def _dev(t: torch.Tensor, name: str, dtype=None) -> torch.Tensor:
 _ws_cache = {}
 
 
+# ---- operand-range hand-over (include/spr.h, "Operand-range hand-over") ------------------------
+# A producer kernel that has just written a tensor can publish max |x| as a few per-workgroup
+# partials; the consuming GEMM then scales its operand without a measuring pass over x.  The
+# range rides on the Python tensor object as an attribute and is honoured only while the tensor
+# is untouched (same storage pointer, same version counter): views, copies and in-place edits drop it.
+def _set_range(t: torch.Tensor, parts: torch.Tensor, n: int) -> None:
+    if n > 0:
+        t._spr_range = (parts, int(n), t._version, t.data_ptr())
+
+
+def _get_range(t):
+    r = getattr(t, '_spr_range', None)
+    if r is None or r[2] != t._version or r[3] != t.data_ptr():
+        return None, 0
+    return r[0], r[1]
+
+_RANGE_CAP = 4096   # partials a GEMM may publish (one per workgroup)
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only scratch buffer per device+stream (stream-ordered reuse)."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
@@ -258,14 +277,25 @@ def linear_raw(x, weight, bias=None, residual=None, act: int = ACT_NONE) -> torc
     out = torch.empty((m, n), dtype=torch.float32, device=x.device)
     L = _lib.lib()
     ws = _workspace(L.spr_linear_workspace_bytes(), x.device)
-    _lib.check(L.spr_linear(_ptr(x), m, k, _ptr(weight), n, _ptr(bias), _ptr(residual),
-                            int(act), _ptr(out), _ptr(ws), ws.numel(), _stream(x)), "spr_linear")
+    xr, xr_n = _get_range(x)
+    # outputs that go on into another GEMM (no residual: FFN hidden, projections) publish their range
+    orng = torch.empty((_RANGE_CAP,), dtype=torch.float32, device=x.device) if residual is None else None
+    on = ctypes.c_int(0)
+    _lib.check(L.spr_linear_r(_ptr(x), m, k, _ptr(weight), n, _ptr(bias), _ptr(residual), int(act), _ptr(out),
+                              _ptr(xr), int(xr_n), _ptr(orng), _RANGE_CAP if orng is not None else 0, ctypes.byref(on),
+                              _ptr(ws), ws.numel(), _stream(x)), "spr_linear_r")
+    if orng is not None:
+        _set_range(out, orng, on.value)
     return out
+
+
+_modes = {"gemm": 1, "attn": 1}   # host mirror of the library's arithmetic switches
 
 
 def set_gemm_mode(mode: int) -> None:
     """1 = split-fp16 MFMA (default), 0 = exact f32 MFMA."""
     _lib.check(_lib.lib().spr_set_gemm_mode(int(mode)), "spr_set_gemm_mode")
+    _modes["gemm"] = int(mode)
 
 
 def layernorm(x, gamma, beta, eps: float = 1e-5, pos=None, want_norm: bool = True):
@@ -286,9 +316,17 @@ def layernorm_raw(x, gamma, beta, eps: float = 1e-5, pos=None, want_norm: bool =
     if pos is not None:
         pos = _dev(pos, "pos", torch.float32)
         out_pos = torch.empty_like(x)
-    _lib.check(_lib.lib().spr_layernorm(_ptr(x), m, c, _ptr(_dev(gamma, "gamma", torch.float32)),
-                                        _ptr(_dev(beta, "beta", torch.float32)), float(eps), _ptr(pos),
-                                        _ptr(out_norm), _ptr(out_pos), _stream(x)), "spr_layernorm")
+    L = _lib.lib()
+    cnt = L.spr_layernorm_range_count(m)
+    rn = torch.empty((cnt,), dtype=torch.float32, device=x.device) if out_norm is not None else None
+    rp = torch.empty((cnt,), dtype=torch.float32, device=x.device) if out_pos is not None else None
+    _lib.check(L.spr_layernorm_r(_ptr(x), m, c, _ptr(_dev(gamma, "gamma", torch.float32)),
+                                 _ptr(_dev(beta, "beta", torch.float32)), float(eps), _ptr(pos),
+                                 _ptr(out_norm), _ptr(out_pos), _ptr(rn), _ptr(rp), _stream(x)), "spr_layernorm_r")
+    if out_norm is not None:
+        _set_range(out_norm, rn, cnt)
+    if out_pos is not None:
+        _set_range(out_pos, rp, cnt)
     return out_norm, out_pos
 
 
@@ -354,16 +392,24 @@ def attention_inproj(x_qk, x_v, w_in, b_in, cu, kv_seg, max_len: int, nhead: int
     out = torch.empty((T, d), dtype=torch.float32, device=x_qk.device)
     L = _lib.lib()
     ws = _workspace(L.spr_attn_inproj_workspace_bytes(T, nseg, nhead, hd), x_qk.device)
-    _lib.check(L.spr_attn_inproj_varlen_fwd(_ptr(x_qk), _ptr(x_v), T, _ptr(w_in), _ptr(b_in), _ptr(cu),
-                                            _ptr(kv_seg), nseg, int(max_len), nhead, hd, 1.0 / math.sqrt(hd),
-                                            _ptr(out), out.stride(0), _ptr(ws), ws.numel(), _stream(x_qk)),
-               "spr_attn_inproj_varlen_fwd")
+    fused = _modes["attn"] != 0 and _modes["gemm"] == 1 and T >= 256     # the route that can take / publish ranges
+    qr, qn = _get_range(x_qk) if fused else (None, 0)
+    vr, vn = (qr, qn) if x_v is x_qk else (_get_range(x_v) if fused else (None, 0))
+    orng = torch.empty((1,), dtype=torch.float32, device=x_qk.device) if fused else None
+    _lib.check(L.spr_attn_inproj_varlen_fwd_r(_ptr(x_qk), _ptr(x_v), T, _ptr(w_in), _ptr(b_in), _ptr(cu),
+                                              _ptr(kv_seg), nseg, int(max_len), nhead, hd, 1.0 / math.sqrt(hd),
+                                              _ptr(out), out.stride(0), _ptr(qr), int(qn), _ptr(vr), int(vn),
+                                              _ptr(orng), _ptr(ws), ws.numel(), _stream(x_qk)),
+               "spr_attn_inproj_varlen_fwd_r")
+    if orng is not None:
+        _set_range(out, orng, 1)
     return out
 
 
 def set_attn_mode(mode: int) -> None:
     """1 = split-fp16 MFMA (default), 0 = exact f32 MFMA, 2 = single-pass fp16 MFMA."""
     _lib.check(_lib.lib().spr_set_attn_mode(int(mode)), "spr_set_attn_mode")
+    _modes["attn"] = int(mode)
 
 
 def _cu_host_arr(cu_host: Sequence[int]):

@@ -281,3 +281,36 @@ def test_attention_deferred_max_recentring(device, mode, pattern):
         assert err <= max(tol * scale, 4 * err32), f"{pattern} mode {mode}: {err:.3e} (fp32 {err32:.3e}, scale {scale:.3e})"
     finally:
         ops.set_attn_mode(1)
+
+
+def test_published_ranges_replace_the_measuring_pass(device):
+    """Operand-range hand-over (spr.h): LayerNorm, the ReLU GEMM and the fused attention publish
+    the range of what they wrote, and the consuming GEMM must produce the same result as when it
+    measures the operand itself -- including for inputs far from unit scale."""
+    ops.set_gemm_mode(1)
+    ops.set_attn_mode(1)
+    for mag in (1.0, 1e-4, 3e3):
+        x = synthetic.rand((700, 256), 41, -2, 3) * mag
+        g, b = synthetic.rand((256,), 42, 0.5, 1.5) * mag, synthetic.rand((256,), 43) * mag
+        pos = synthetic.rand((700, 256), 44) * mag
+        w1, b1 = synthetic.rand((1024, 256), 45, -0.1, 0.1), synthetic.rand((1024,), 46) * mag
+        w2 = synthetic.rand((256, 1024), 47, -0.1, 0.1)
+        n, npos = ops.layernorm(x.to(device), g.to(device), b.to(device), 1e-5, pos=pos.to(device))
+        assert getattr(n, "_spr_range", None) is not None and getattr(npos, "_spr_range", None) is not None
+        h = ops.linear(n, w1.to(device), b1.to(device), act=ops.ACT_RELU)          # consumes n's range, publishes h's
+        assert ops._get_range(h)[1] > 0
+        y = ops.linear(h, w2.to(device))                                           # consumes h's range
+        # the same chain with every range dropped (clones are new tensors without the attribute)
+        h2 = ops.linear(n.clone(), w1.to(device), b1.to(device), act=ops.ACT_RELU)
+        y2 = ops.linear(h2.clone(), w2.to(device))
+        assert torch.equal(h, h2), mag           # same power-of-two scales -> bitwise the same GEMM
+        ref = torch.relu(n.double().cpu() @ w1.double().t() + b1.double()) @ w2.double().t()
+        assert float((y.double().cpu() - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
+        assert float((y2.double().cpu() - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
+    # a stale range must not be used: in-place modification bumps the version counter
+    n, _ = ops.layernorm(x.to(device), g.to(device), b.to(device), 1e-5)
+    n.mul_(1000.0)
+    assert ops._get_range(n) == (None, 0)
+    y = ops.linear(n, w1.to(device))
+    ref = n.double().cpu() @ w1.double().t()
+    assert torch.isfinite(y).all() and float((y.double().cpu() - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
