@@ -153,8 +153,9 @@ int spr_linear(const float* x, int m, int k, const float* w, int n,
  *   out_range (capacity out_range_cap floats): if the GEMM runs with <= out_range_cap
  *     workgroups it writes one partial per workgroup and sets *out_range_n_host (a HOST int)
  *     to their number, else 0 (nothing published).
- * spr_layernorm_r publishes the ranges of its two outputs (spr_layernorm_range_count(m)
- * partials each); spr_attn_inproj_varlen_fwd_r accepts the input ranges and publishes a bound of
+ * spr_layernorm_r publishes the ranges of its two outputs into spr_layernorm_range_count(m)
+ * slots each, which the CALLER MUST ZERO beforehand (the kernel combines its workgroups'
+ * maxima with atomic max); spr_attn_inproj_varlen_fwd_r accepts the input ranges and publishes a bound of
  * its output (1 float: the attention output is a convex combination of value rows). */
 int spr_linear_r(const float* x, int m, int k, const float* w, int n, const float* bias,
                  const float* residual, int act, float* out, const float* x_range,

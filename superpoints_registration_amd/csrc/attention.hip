@@ -625,8 +625,8 @@ __global__ __launch_bounds__(256) void k_plane_scales(const float* __restrict__ 
   __shared__ float sh[17];
   __shared__ float blk[6];
   float qb = block_absmax(q_parts, sh, nq_parts);
-  float kb = block_absmax(k_parts, sh, nk_parts);
-  float vb = block_absmax(v_parts, sh, nv_parts);
+  float kb = k_parts == q_parts ? qb : block_absmax(k_parts, sh, nk_parts);   // shared input: reduce once
+  float vb = v_parts == q_parts ? qb : block_absmax(v_parts, sh, nv_parts);
   if (rowl1 != nullptr) {
     for (int b = 0; b < 3; ++b) {
       float l1 = 0.f, bm = 0.f;

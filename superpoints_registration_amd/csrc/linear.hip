@@ -430,6 +430,7 @@ __global__ void k_gemv_rows(const float* __restrict__ X, int M, int K, const flo
   }
 }
 
+constexpr int kLnRangeSlots = 64;
 // One wave per row; c % 64 == 0, c <= 1024.
 template <int MAXV>
 __global__ void k_layernorm(const float* __restrict__ x, int m, int c,
@@ -473,7 +474,10 @@ __global__ void k_layernorm(const float* __restrict__ x, int m, int c,
     }
   }
   }
-  if (range_norm || range_pos) {   // one partial per workgroup (4 rows): the consumer GEMM's operand range
+  if (range_norm || range_pos) {
+    // the consumer GEMM's operand range: kLnRangeSlots partial maxima, combined with integer atomic
+    // max on the bit pattern (non-negative floats order like unsigned ints; order independent,
+    // hence deterministic).  The caller zero-initialises the slots.
     mxn = wave_max(mxn);
     mxp = wave_max(mxp);
     if (lane == 0) {
@@ -482,8 +486,13 @@ __global__ void k_layernorm(const float* __restrict__ x, int m, int c,
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      if (range_norm) range_norm[blockIdx.x] = fmaxf(fmaxf(shr[0], shr[1]), fmaxf(shr[2], shr[3]));
-      if (range_pos) range_pos[blockIdx.x] = fmaxf(fmaxf(shr[4], shr[5]), fmaxf(shr[6], shr[7]));
+      const int slot = blockIdx.x & (kLnRangeSlots - 1);
+      if (range_norm)
+        atomicMax(reinterpret_cast<unsigned int*>(range_norm) + slot,
+                  __float_as_uint(fmaxf(fmaxf(shr[0], shr[1]), fmaxf(shr[2], shr[3]))));
+      if (range_pos)
+        atomicMax(reinterpret_cast<unsigned int*>(range_pos) + slot,
+                  __float_as_uint(fmaxf(fmaxf(shr[4], shr[5]), fmaxf(shr[6], shr[7]))));
     }
   }
 }
@@ -641,7 +650,10 @@ extern "C" int spr_set_gemm_mode(int mode) {
   return 0;
 }
 
-extern "C" int spr_layernorm_range_count(int m) { return cdiv((long)(m > 0 ? m : 1) * 64, 256); }
+extern "C" int spr_layernorm_range_count(int m) {
+  (void)m;
+  return kLnRangeSlots;
+}
 
 extern "C" int spr_layernorm_r(const float* x, int m, int c, const float* gamma, const float* beta,
                                float eps, const float* pos, float* out_norm, float* out_pos, float* range_norm,

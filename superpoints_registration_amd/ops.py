@@ -6,6 +6,7 @@ tensors -- a CPU tensor raises, there is no fallback.
 """
 import ctypes
 import math
+import os
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -48,13 +49,32 @@ def _set_range(t: torch.Tensor, parts: torch.Tensor, n: int) -> None:
         t._spr_range = (parts, int(n), t._version, t.data_ptr())
 
 
+_HANDOVER = os.environ.get("SPR_NO_RANGE_HANDOVER", "0") != "1"   # experiment switch (A/B timing)
+
+
 def _get_range(t):
+    if not _HANDOVER:
+        return None, 0
     r = getattr(t, '_spr_range', None)
     if r is None or r[2] != t._version or r[3] != t.data_ptr():
         return None, 0
     return r[0], r[1]
 
 _RANGE_CAP = 4096   # partials a GEMM may publish (one per workgroup)
+_zero_pool = {}
+
+
+def _zero_slots(n: int, device) -> torch.Tensor:
+    """n zero-initialised floats from a per-(device, stream) pool: one memset per 64 K slots instead
+    of one per LayerNorm call (its range slots are combined with atomic max and must start at 0)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    pool = _zero_pool.get(key)
+    if pool is None or pool[1] + n > pool[0].numel():
+        pool = [torch.zeros(65536, dtype=torch.float32, device=device), 0]
+        _zero_pool[key] = pool
+    out = pool[0][pool[1]:pool[1] + n]
+    pool[1] += n
+    return out
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
@@ -318,8 +338,8 @@ def layernorm_raw(x, gamma, beta, eps: float = 1e-5, pos=None, want_norm: bool =
         out_pos = torch.empty_like(x)
     L = _lib.lib()
     cnt = L.spr_layernorm_range_count(m)
-    rn = torch.empty((cnt,), dtype=torch.float32, device=x.device) if out_norm is not None else None
-    rp = torch.empty((cnt,), dtype=torch.float32, device=x.device) if out_pos is not None else None
+    rn = _zero_slots(cnt, x.device) if out_norm is not None else None
+    rp = _zero_slots(cnt, x.device) if out_pos is not None else None
     _lib.check(L.spr_layernorm_r(_ptr(x), m, c, _ptr(_dev(gamma, "gamma", torch.float32)),
                                  _ptr(_dev(beta, "beta", torch.float32)), float(eps), _ptr(pos),
                                  _ptr(out_norm), _ptr(out_pos), _ptr(rn), _ptr(rp), _stream(x)), "spr_layernorm_r")
