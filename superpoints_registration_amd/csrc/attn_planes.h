@@ -33,4 +33,15 @@ int launch_linear_ranged(const float* x, int m, int k, const float* w, int n, co
                          const float* a_parts, const float* w_parts, hipStream_t stream);
 int gemm_mode();   // 1 = split-fp16, 0 = exact f32
 
+// One problem of a grouped NT GEMM (linear.hip, launch_gemm_grouped): element offsets into the
+// shared A / B / C bases, sizes, and the running tile count (exclusive end) of the 1-D grid.
+struct GemmGroup {
+  long long a_off, b_off, c_off;
+  int m, n, tile_end, pad;
+};
+void gemm_group_tile(int max_n, int* bm, int* bn);
+int launch_gemm_grouped(const float* a, int k, const float* b, float* c, const GemmGroup* groups_dev,
+                        int total_tiles, int max_n, const float* a_parts, const float* w_parts,
+                        hipStream_t stream);
+
 }  // namespace spr

@@ -196,11 +196,30 @@ constexpr int HS = 40;                 // LDS row stride in halves (BK = 32 + 8 
 
 template <int BM, int BN, int WM, int WN, int ACT, bool RES, bool PLANES = false>
 __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
-    const float* __restrict__ X, int M, int K, const float* __restrict__ Wt, int N,
+    const float* __restrict__ Xp, int Mp, int K, const float* __restrict__ Wp, int Np,
     const float* __restrict__ bias, const float* __restrict__ residual,
-    float* __restrict__ out, AttnPlanes pl, int f0, const float* __restrict__ a_parts, int n_aparts,
-    const float* __restrict__ w_parts, float* __restrict__ out_parts) {
+    float* __restrict__ outp, AttnPlanes pl, int f0, const float* __restrict__ a_parts, int n_aparts,
+    const float* __restrict__ w_parts, float* __restrict__ out_parts,
+    const GemmGroup* __restrict__ groups) {
   constexpr int NT = WM * WN * 64;      // threads (4 or 8 waves)
+  // grouped launch (groups != nullptr): the grid is the concatenation of the tile grids of
+  // independent problems X_g [m_g, K] x W_g [n_g, K]^T that share K and the operand scales
+  // (the per-pair correlation GEMMs of the matching head: one launch instead of one per pair)
+  const float* __restrict__ X = Xp;
+  const float* __restrict__ Wt = Wp;
+  float* __restrict__ out = outp;
+  int M = Mp, N = Np, bid = blockIdx.x, nblk = gridDim.x;
+  if (groups != nullptr) {
+    int g = 0, beg = 0;
+    while (bid >= groups[g].tile_end) beg = groups[g++].tile_end;
+    X += groups[g].a_off;
+    Wt += groups[g].b_off;
+    out += groups[g].c_off;
+    M = groups[g].m;
+    N = groups[g].n;
+    nblk = groups[g].tile_end - beg;
+    bid -= beg;
+  }
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);   // 32x32 sub-tiles per wave
   constexpr int A_F4 = BM * BK / 4, B_F4 = BN * BK / 4;
   constexpr int A_PT = A_F4 / NT, B_PT = B_F4 / NT;
@@ -214,7 +233,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
   const int wm = wave / WN, wn = wave % WN;
   // 1-D grid, XCD-swizzled: the column tiles of one row panel share an L2
   const int gx = (N + BN - 1) / BN;
-  const int lid = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int lid = groups != nullptr ? bid : xcd_swizzle(bid, nblk);
   const int m0 = (lid / gx) * BM, n0 = (lid % gx) * BN;
   const int l31 = lane & 31, lh = lane >> 5;
 
@@ -539,15 +558,15 @@ int launch_gemm(const float* x, int m, int k, const float* w, int n, const float
       float* op = (out_parts && grid <= out_cap) ? out_parts : nullptr;   // range published only if it fits
       if (op && out_n) *out_n = grid;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds(256, 256), stream, x, m, k,
-                         w, n, bias, residual, out, spr::AttnPlanes(), 0, a_parts, n_aparts, w_parts, op);
+                         w, n, bias, residual, out, spr::AttnPlanes(), 0, a_parts, n_aparts, w_parts, op, (const spr::GemmGroup*)nullptr);
     } else if (n > 32) {
       hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 64, 4, 1, ACT, RES>), dim3(cdiv(n, 64) * cdiv(m, 128)),
                          dim3(256), lds(128, 64), stream, x, m, k, w, n, bias, residual, out, spr::AttnPlanes(), 0,
-                         a_parts, n_aparts, w_parts, (float*)nullptr);
+                         a_parts, n_aparts, w_parts, (float*)nullptr, (const spr::GemmGroup*)nullptr);
     } else {
       hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 32, 4, 1, ACT, RES>), dim3(cdiv(n, 32) * cdiv(m, 128)),
                          dim3(256), lds(128, 32), stream, x, m, k, w, n, bias, residual, out, spr::AttnPlanes(), 0,
-                         a_parts, n_aparts, w_parts, (float*)nullptr);
+                         a_parts, n_aparts, w_parts, (float*)nullptr, (const spr::GemmGroup*)nullptr);
     }
   } else if (n % 64 == 0) {
     hipLaunchKernelGGL((spr::k_gemm_nt<2, 2, ACT, RES>), dim3((n / 64) * cdiv(m, 64)), dim3(256), 0, stream,
@@ -573,7 +592,7 @@ int spr::launch_inproj_planes(const float* x, int m, int k, const float* w, int 
   const size_t lds = (size_t)(256 + 256) * spr::HS * 2 * sizeof(_Float16);
   if (int rc = ensure_dyn_lds((const void*)kern, (int)lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(cdiv(n, 256) * cdiv(m, 256)), dim3(512), lds, stream, x, m, k, w, n, bias,
-                     (const float*)nullptr, (float*)nullptr, planes, f0, a_parts, n_aparts, w_parts, (float*)nullptr);
+                     (const float*)nullptr, (float*)nullptr, planes, f0, a_parts, n_aparts, w_parts, (float*)nullptr, (const spr::GemmGroup*)nullptr);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -585,6 +604,43 @@ int spr::launch_linear_ranged(const float* x, int m, int k, const float* w, int 
                               float* out, const float* a_parts, const float* w_parts, hipStream_t stream) {
   return launch_gemm<SPR_ACT_NONE, false>(x, m, k, w, n, bias, nullptr, out, a_parts, kAmaxParts, w_parts, nullptr, 0,
                                           nullptr, stream);
+}
+
+// Grouped NT GEMM, split-fp16 mode only: problem g is A_g = a + groups[g].a_off [m_g, k],
+// B_g = b + groups[g].b_off [n_g, k], C_g = c + groups[g].c_off [m_g, n_g] (row-major, ld = n_g);
+// groups[g].tile_end = running total of cdiv(m_g, bm) * cdiv(n_g, bn) with (bm, bn) =
+// gemm_group_tile(max n_g).  One launch for all of them.
+void spr::gemm_group_tile(int max_n, int* bm, int* bn) {
+  if (max_n >= 256) { *bm = 256; *bn = 256; }
+  else if (max_n > 32) { *bm = 128; *bn = 64; }
+  else { *bm = 128; *bn = 32; }
+}
+
+int spr::launch_gemm_grouped(const float* a, int k, const float* b, float* c, const GemmGroup* groups_dev,
+                             int total_tiles, int max_n, const float* a_parts, const float* w_parts,
+                             hipStream_t stream) {
+  SPR_REQUIRE(spr::gemm_mode() == 1 && a_parts && w_parts && groups_dev && total_tiles >= 1 && k % BK == 0,
+              "grouped gemm: bad arguments");
+  auto lds = [](int bm, int bn) { return (size_t)(bm + bn) * spr::HS * 2 * sizeof(_Float16); };
+  int bm, bn;
+  gemm_group_tile(max_n, &bm, &bn);
+  if (bn == 256) {
+    auto kern = spr::k_gemm_nt_h3<256, 256, 4, 2, SPR_ACT_NONE, false>;
+    if (int rc = ensure_dyn_lds((const void*)kern, (int)lds(256, 256))) return rc;
+    hipLaunchKernelGGL(kern, dim3(total_tiles), dim3(512), lds(256, 256), stream, a, 0, k, b, 0,
+                       (const float*)nullptr, (const float*)nullptr, c, spr::AttnPlanes(), 0, a_parts, kAmaxParts,
+                       w_parts, (float*)nullptr, groups_dev);
+  } else if (bn == 64) {
+    hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 64, 4, 1, SPR_ACT_NONE, false>), dim3(total_tiles), dim3(256),
+                       lds(128, 64), stream, a, 0, k, b, 0, (const float*)nullptr, (const float*)nullptr, c,
+                       spr::AttnPlanes(), 0, a_parts, kAmaxParts, w_parts, (float*)nullptr, groups_dev);
+  } else {
+    hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 32, 4, 1, SPR_ACT_NONE, false>), dim3(total_tiles), dim3(256),
+                       lds(128, 32), stream, a, 0, k, b, 0, (const float*)nullptr, (const float*)nullptr, c,
+                       spr::AttnPlanes(), 0, a_parts, kAmaxParts, w_parts, (float*)nullptr, groups_dev);
+  }
+  SPR_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" size_t spr_linear_workspace_bytes(void) { return 2 * align_up(kAmaxParts * sizeof(float), 256); }

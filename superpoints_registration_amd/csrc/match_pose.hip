@@ -777,7 +777,7 @@ size_t match_ws_bytes(const int* cu_host, int npairs) {
     off = (off + 63) / 64 * 64;
   }
   return align_up((size_t)off * 4, 256) + align_up(sizeof(PairDesc) * npairs, 256) +
-         4 * align_up((size_t)tmax * 4, 256) + 2 * align_up(kAmaxParts * sizeof(float), 256) + 1024;
+         align_up(sizeof(GemmGroup) * npairs, 256) + 4 * align_up((size_t)tmax * 4, 256) + 2 * align_up(kAmaxParts * sizeof(float), 256) + 1024;
 }
 
 }  // namespace
@@ -795,9 +795,11 @@ extern "C" size_t spr_sinkhorn_workspace_bytes(const int* cu_host, int npairs) {
 namespace {
 // Fills the scratch with raw correlations F_s F_t^T (unscaled), one MFMA GEMM
 // per pair; uploads the pair descriptors.
-__global__ void k_build_pairs(const int* __restrict__ cu, int npairs, PairDesc* pd) {
+__global__ void k_build_pairs(const int* __restrict__ cu, int npairs, PairDesc* pd, GemmGroup* gg, int d,
+                              int bm, int bn) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   long long off = 0;
+  int tiles = 0;
   for (int b = 0; b < npairs; ++b) {
     PairDesc p;
     p.src_beg = cu[b];
@@ -805,6 +807,18 @@ __global__ void k_build_pairs(const int* __restrict__ cu, int npairs, PairDesc* 
     p.tgt_beg = cu[npairs + b];
     p.m = cu[npairs + b + 1] - cu[npairs + b];
     p.off = off;
+    if (gg != nullptr) {   // the pair's correlation GEMM as one group of the grouped launch
+      GemmGroup g;
+      g.a_off = (long long)p.src_beg * d;
+      g.b_off = (long long)p.tgt_beg * d;
+      g.c_off = off;
+      g.m = p.n;
+      g.n = p.m;
+      tiles += ((p.n + bm - 1) / bm) * ((p.m + bn - 1) / bn);
+      g.tile_end = tiles;
+      g.pad = 0;
+      gg[b] = g;
+    }
     off += (long long)p.n * p.m;
     off = (off + 63) / 64 * 64;
     pd[b] = p;
@@ -820,9 +834,23 @@ int correlate(const float* feat, int d, const int* cu_dev, const int* cu_host, i
   PairDesc* pd = w.take<PairDesc>(npairs);
   SPR_REQUIRE(mat && pd, "match: workspace carve failed");
   // descriptors are rebuilt on the device from cu (no pageable host copy)
-  hipLaunchKernelGGL(k_build_pairs, dim3(1), dim3(64), 0, stream, cu_dev, npairs, pd);
   *max_n = 0;
   *max_m = 0;
+  for (int b = 0; b < npairs; ++b) {
+    SPR_REQUIRE(h[b].n > 0 && h[b].m > 0, "match: empty cloud in pair %d", b);
+    *max_n = h[b].n > *max_n ? h[b].n : *max_n;
+    *max_m = h[b].m > *max_m ? h[b].m : *max_m;
+  }
+  const bool grouped = gemm_mode() == 1 && d % 32 == 0;
+  GemmGroup* gg = nullptr;
+  int bm = 1, bn = 1, total_tiles = 0;
+  if (grouped) {
+    gg = w.take<GemmGroup>(npairs);
+    SPR_REQUIRE(gg != nullptr, "match: workspace carve failed");
+    gemm_group_tile(*max_m, &bm, &bn);
+    for (int b = 0; b < npairs; ++b) total_tiles += cdiv(h[b].n, bm) * cdiv(h[b].m, bn);
+  }
+  hipLaunchKernelGGL(k_build_pairs, dim3(1), dim3(64), 0, stream, cu_dev, npairs, pd, gg, d, bm, bn);
   // two range measurements serve every pair: all src tokens (A operands), all tgt tokens (B)
   const float *sparts = nullptr, *tparts = nullptr;
   if (gemm_mode() == 1) {
@@ -835,13 +863,15 @@ int correlate(const float* feat, int d, const int* cu_dev, const int* cu_host, i
     sparts = ps;
     tparts = pt;
   }
-  for (int b = 0; b < npairs; ++b) {
-    SPR_REQUIRE(h[b].n > 0 && h[b].m > 0, "match: empty cloud in pair %d", b);
-    if (launch_linear_ranged(feat + (size_t)h[b].src_beg * d, h[b].n, d, feat + (size_t)h[b].tgt_beg * d,
-                             h[b].m, nullptr, mat + h[b].off, sparts, tparts, stream))
-      return 1;
-    *max_n = h[b].n > *max_n ? h[b].n : *max_n;
-    *max_m = h[b].m > *max_m ? h[b].m : *max_m;
+  if (grouped) {
+    // one launch for all pairs: a 1 930 x 1 930 x 256 product alone is 64 tiles of 256 x 256,
+    // a quarter of the chip, and pays the full pipeline latency of a tile
+    if (launch_gemm_grouped(feat, d, feat, mat, gg, total_tiles, *max_m, sparts, tparts, stream)) return 1;
+  } else {
+    for (int b = 0; b < npairs; ++b)
+      if (launch_linear_ranged(feat + (size_t)h[b].src_beg * d, h[b].n, d, feat + (size_t)h[b].tgt_beg * d,
+                               h[b].m, nullptr, mat + h[b].off, sparts, tparts, stream))
+        return 1;
   }
   *mat_out = mat;
   *pd_out = pd;
