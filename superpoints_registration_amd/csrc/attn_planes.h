@@ -40,8 +40,10 @@ struct GemmGroup {
   int m, n, tile_end, pad;
 };
 void gemm_group_tile(int max_n, int* bm, int* bn);
+// epilogue codes of the grouped GEMM (continue the SPR_ACT_* numbering of spr.h)
+constexpr int kEpiScale = 3, kEpiAffinity = 4;
 int launch_gemm_grouped(const float* a, int k, const float* b, float* c, const GemmGroup* groups_dev,
-                        int total_tiles, int max_n, const float* a_parts, const float* w_parts,
-                        hipStream_t stream);
+                        int total_tiles, int max_n, const float* a_parts, const float* w_parts, int epi_mode,
+                        const float* epi, hipStream_t stream);
 
 }  // namespace spr

@@ -37,7 +37,8 @@ constexpr int LDSK = BK + 1;
 template <int ACT, bool RES>
 __device__ __forceinline__ float store_tile(const f32x16& acc, int row0, int col, int M, int N,
                                             float bv, const float* __restrict__ residual,
-                                            float* __restrict__ out, int lh, float unscale = 1.0f) {
+                                            float* __restrict__ out, int lh, float unscale = 1.0f,
+                                            const float* __restrict__ epi = nullptr) {
   if (col >= N) return 0.f;
   float vmax = 0.f;
   float res[16];
@@ -55,6 +56,13 @@ __device__ __forceinline__ float store_tile(const f32x16& acc, int row0, int col
     if (RES) v += res[r];
     if (ACT == SPR_ACT_RELU) v = fmaxf(v, 0.f);
     if (ACT == SPR_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+    // matching-head epilogues (match_pose.hip): same float operations, in the same order, as
+    // the separate k_scale / k_affinity passes over the score matrix they replace
+    if (ACT == kEpiScale) v = v * epi[0];
+    if (ACT == kEpiAffinity) {
+      const float sc = fmaxf(v * epi[0], 0.f);
+      v = -(sc - epi[1]) * epi[2];
+    }
     if (row < M) {
       out[(size_t)row * N + col] = v;
       vmax = fmaxf(vmax, fabsf(v));
@@ -406,11 +414,11 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + l31;
-    const float bv = (bias && col < N) ? bias[col] : 0.f;
+    const float bv = (ACT < kEpiScale && bias && col < N) ? bias[col] : 0.f;   // epilogue modes: `bias` = parameters
 #pragma unroll
     for (int i = 0; i < TM; ++i)
       omax = fmaxf(omax, store_tile<ACT, RES>(acc[i][j], m0 + (wm * TM + i) * 32, col, M, N, bv, residual, out, lh,
-                                              unscale));
+                                              unscale, ACT >= kEpiScale ? bias : nullptr));
   }
   if (out_parts != nullptr) {
     // publish max |out| of this tile: the consumer GEMM then needs no pass over `out` to scale it
@@ -497,6 +505,65 @@ __global__ void k_layernorm(const float* __restrict__ x, int m, int c,
     // the consumer GEMM's operand range: kLnRangeSlots partial maxima, combined with integer atomic
     // max on the bit pattern (non-negative floats order like unsigned ints; order independent,
     // hence deterministic).  The caller zero-initialises the slots.
+    mxn = wave_max(mxn);
+    mxp = wave_max(mxp);
+    if (lane == 0) {
+      shr[threadIdx.x >> 6] = mxn;
+      shr[4 + (threadIdx.x >> 6)] = mxp;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int slot = blockIdx.x & (kLnRangeSlots - 1);
+      if (range_norm)
+        atomicMax(reinterpret_cast<unsigned int*>(range_norm) + slot,
+                  __float_as_uint(fmaxf(fmaxf(shr[0], shr[1]), fmaxf(shr[2], shr[3]))));
+      if (range_pos)
+        atomicMax(reinterpret_cast<unsigned int*>(range_pos) + slot,
+                  __float_as_uint(fmaxf(fmaxf(shr[4], shr[5]), fmaxf(shr[6], shr[7]))));
+    }
+  }
+}
+
+// c == 256 (d_model of every shipped config): one wave per row, one float4 per lane and tensor --
+// 1 KiB per wave load / store instead of four 256-byte ones.
+__global__ __launch_bounds__(256) void k_layernorm256(const float* __restrict__ x, int m,
+                                                      const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps,
+                                                      const float* __restrict__ pos, float* __restrict__ out_norm,
+                                                      float* __restrict__ out_pos, float* __restrict__ range_norm,
+                                                      float* __restrict__ range_pos) {
+  __shared__ float shr[8];
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  float mxn = 0.f, mxp = 0.f;
+  if (row < m) {
+    const size_t o = (size_t)row * 256 + 4 * lane;
+    const float4 v = *reinterpret_cast<const float4*>(x + o);
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (out_pos) pv = *reinterpret_cast<const float4*>(pos + o);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * lane);
+    const float4 b = *reinterpret_cast<const float4*>(beta + 4 * lane);
+    const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) / 256.0f;
+    const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+    const float rstd = 1.0f / sqrtf(wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) / 256.0f + eps);
+    float4 y;
+    y.x = dx * rstd * g.x + b.x;
+    y.y = dy * rstd * g.y + b.y;
+    y.z = dz * rstd * g.z + b.z;
+    y.w = dw * rstd * g.w + b.w;
+    mxn = fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)));
+    if (out_norm) *reinterpret_cast<float4*>(out_norm + o) = y;
+    if (out_pos) {
+      float4 yp;
+      yp.x = y.x + pv.x;
+      yp.y = y.y + pv.y;
+      yp.z = y.z + pv.z;
+      yp.w = y.w + pv.w;
+      mxp = fmaxf(fmaxf(fabsf(yp.x), fabsf(yp.y)), fmaxf(fabsf(yp.z), fabsf(yp.w)));
+      *reinterpret_cast<float4*>(out_pos + o) = yp;
+    }
+  }
+  if (range_norm || range_pos) {   // same hand-over as k_layernorm
     mxn = wave_max(mxn);
     mxp = wave_max(mxp);
     if (lane == 0) {
@@ -616,31 +683,52 @@ void spr::gemm_group_tile(int max_n, int* bm, int* bn) {
   else { *bm = 128; *bn = 32; }
 }
 
-int spr::launch_gemm_grouped(const float* a, int k, const float* b, float* c, const GemmGroup* groups_dev,
-                             int total_tiles, int max_n, const float* a_parts, const float* w_parts,
-                             hipStream_t stream) {
-  SPR_REQUIRE(spr::gemm_mode() == 1 && a_parts && w_parts && groups_dev && total_tiles >= 1 && k % BK == 0,
-              "grouped gemm: bad arguments");
+namespace {
+template <int ACT>
+int launch_grouped_act(const float* a, int k, const float* b, float* c, const spr::GemmGroup* groups_dev,
+                       int total_tiles, int max_n, const float* a_parts, const float* w_parts, const float* epi,
+                       hipStream_t stream) {
   auto lds = [](int bm, int bn) { return (size_t)(bm + bn) * spr::HS * 2 * sizeof(_Float16); };
   int bm, bn;
-  gemm_group_tile(max_n, &bm, &bn);
+  spr::gemm_group_tile(max_n, &bm, &bn);
   if (bn == 256) {
-    auto kern = spr::k_gemm_nt_h3<256, 256, 4, 2, SPR_ACT_NONE, false>;
+    auto kern = spr::k_gemm_nt_h3<256, 256, 4, 2, ACT, false>;
     if (int rc = ensure_dyn_lds((const void*)kern, (int)lds(256, 256))) return rc;
-    hipLaunchKernelGGL(kern, dim3(total_tiles), dim3(512), lds(256, 256), stream, a, 0, k, b, 0,
-                       (const float*)nullptr, (const float*)nullptr, c, spr::AttnPlanes(), 0, a_parts, kAmaxParts,
-                       w_parts, (float*)nullptr, groups_dev);
+    hipLaunchKernelGGL(kern, dim3(total_tiles), dim3(512), lds(256, 256), stream, a, 0, k, b, 0, epi,
+                       (const float*)nullptr, c, spr::AttnPlanes(), 0, a_parts, kAmaxParts, w_parts,
+                       (float*)nullptr, groups_dev);
   } else if (bn == 64) {
-    hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 64, 4, 1, SPR_ACT_NONE, false>), dim3(total_tiles), dim3(256),
-                       lds(128, 64), stream, a, 0, k, b, 0, (const float*)nullptr, (const float*)nullptr, c,
-                       spr::AttnPlanes(), 0, a_parts, kAmaxParts, w_parts, (float*)nullptr, groups_dev);
+    hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 64, 4, 1, ACT, false>), dim3(total_tiles), dim3(256),
+                       lds(128, 64), stream, a, 0, k, b, 0, epi, (const float*)nullptr, c, spr::AttnPlanes(), 0,
+                       a_parts, kAmaxParts, w_parts, (float*)nullptr, groups_dev);
   } else {
-    hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 32, 4, 1, SPR_ACT_NONE, false>), dim3(total_tiles), dim3(256),
-                       lds(128, 32), stream, a, 0, k, b, 0, (const float*)nullptr, (const float*)nullptr, c,
-                       spr::AttnPlanes(), 0, a_parts, kAmaxParts, w_parts, (float*)nullptr, groups_dev);
+    hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 32, 4, 1, ACT, false>), dim3(total_tiles), dim3(256),
+                       lds(128, 32), stream, a, 0, k, b, 0, epi, (const float*)nullptr, c, spr::AttnPlanes(), 0,
+                       a_parts, kAmaxParts, w_parts, (float*)nullptr, groups_dev);
   }
   SPR_LAUNCH_CHECK();
   return 0;
+}
+}  // namespace
+
+// epi_mode: 0 none, kEpiScale (out = v * epi[0]), kEpiAffinity (out = -(max(v epi[0], 0) - epi[1]) epi[2]);
+// epi = device parameters of the epilogue.
+int spr::launch_gemm_grouped(const float* a, int k, const float* b, float* c, const GemmGroup* groups_dev,
+                             int total_tiles, int max_n, const float* a_parts, const float* w_parts,
+                             int epi_mode, const float* epi, hipStream_t stream) {
+  SPR_REQUIRE(spr::gemm_mode() == 1 && a_parts && w_parts && groups_dev && total_tiles >= 1 && k % BK == 0,
+              "grouped gemm: bad arguments");
+  SPR_REQUIRE(epi_mode == 0 || epi != nullptr, "grouped gemm: epilogue parameters missing");
+  switch (epi_mode) {
+    case 0: return launch_grouped_act<SPR_ACT_NONE>(a, k, b, c, groups_dev, total_tiles, max_n, a_parts, w_parts,
+                                                    nullptr, stream);
+    case kEpiScale: return launch_grouped_act<kEpiScale>(a, k, b, c, groups_dev, total_tiles, max_n, a_parts,
+                                                         w_parts, epi, stream);
+    case kEpiAffinity: return launch_grouped_act<kEpiAffinity>(a, k, b, c, groups_dev, total_tiles, max_n, a_parts,
+                                                               w_parts, epi, stream);
+  }
+  SPR_REQUIRE(false, "grouped gemm: unknown epilogue %d", epi_mode);
+  return 1;
 }
 
 extern "C" size_t spr_linear_workspace_bytes(void) { return 2 * align_up(kAmaxParts * sizeof(float), 256); }
@@ -718,7 +806,10 @@ extern "C" int spr_layernorm_r(const float* x, int m, int c, const float* gamma,
   SPR_REQUIRE(m > 0 && c % 64 == 0 && c <= 1024, "layernorm: c must be a multiple of 64 and <= 1024 (c=%d)", c);
   SPR_REQUIRE(out_pos == nullptr || pos != nullptr, "layernorm: out_pos needs pos");
   const int grid = cdiv((long)m * 64, 256);
-  if (c <= 256)
+  if (c == 256)
+    hipLaunchKernelGGL(k_layernorm256, dim3(grid), dim3(256), 0, stream, x, m, gamma, beta, eps, pos, out_norm,
+                       out_pos, range_norm, range_pos);
+  else if (c <= 256)
     hipLaunchKernelGGL(k_layernorm<4>, dim3(grid), dim3(256), 0, stream, x, m, c, gamma, beta, eps,
                        pos, out_norm, out_pos, range_norm, range_pos);
   else

@@ -239,6 +239,19 @@ __global__ void k_scale(float* __restrict__ mat, long long total, float s) {
 // affinity = -(max(c*scale, 0) - sp_alpha) * inv_den      (qk_regtr_full.py:532-535)
 // alpha, beta: the model's learnable scalars, read from DEVICE memory (no host round trip);
 // softplus with threshold 20 like torch.nn.Softplus, evaluated in float64.
+// parameters of the fused epilogues: [0] = scale, [1] = softplus(alpha), [2] = 1 / (exp(beta) + 0.02)
+// (the same double-precision expressions as k_affinity)
+__global__ void k_epi_params(float scale, const float* __restrict__ alpha_p, const float* __restrict__ beta_p,
+                             float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  out[0] = scale;
+  if (alpha_p != nullptr) {
+    const float alpha = alpha_p[0], beta = beta_p[0];
+    out[1] = (float)(alpha > 20.f ? (double)alpha : log1p(exp((double)alpha)));
+    out[2] = (float)(1.0 / (exp((double)beta) + 0.02));
+  }
+}
+
 __global__ void k_affinity(float* __restrict__ mat, long long total, float scale,
                            const float* __restrict__ alpha_p, const float* __restrict__ beta_p) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -777,7 +790,7 @@ size_t match_ws_bytes(const int* cu_host, int npairs) {
     off = (off + 63) / 64 * 64;
   }
   return align_up((size_t)off * 4, 256) + align_up(sizeof(PairDesc) * npairs, 256) +
-         align_up(sizeof(GemmGroup) * npairs, 256) + 4 * align_up((size_t)tmax * 4, 256) + 2 * align_up(kAmaxParts * sizeof(float), 256) + 1024;
+         align_up(sizeof(GemmGroup) * npairs, 256) + 4 * align_up((size_t)tmax * 4, 256) + 2 * align_up(kAmaxParts * sizeof(float), 256) + 2048;
 }
 
 }  // namespace
@@ -825,9 +838,14 @@ __global__ void k_build_pairs(const int* __restrict__ cu, int npairs, PairDesc* 
   }
 }
 
+// epi_mode / epi: optional elementwise epilogue of the grouped GEMM (kEpiScale, kEpiAffinity;
+// parameters on the device); *epi_applied tells the caller whether it ran (split-fp16 mode) or
+// the separate pass over the matrix is still needed (exact-f32 mode: one GEMM per pair).
 int correlate(const float* feat, int d, const int* cu_dev, const int* cu_host, int npairs, Workspace& w,
               float** mat_out, PairDesc** pd_out, std::vector<PairDesc>& h, long long* total,
-              int* max_n, int* max_m, hipStream_t stream) {
+              int* max_n, int* max_m, hipStream_t stream, int epi_mode = 0, const float* epi = nullptr,
+              bool* epi_applied = nullptr) {
+  if (epi_applied) *epi_applied = false;
   h.resize(npairs);
   build_pairs(cu_host, npairs, h.data(), total);
   float* mat = w.take<float>((size_t)*total);
@@ -866,7 +884,9 @@ int correlate(const float* feat, int d, const int* cu_dev, const int* cu_host, i
   if (grouped) {
     // one launch for all pairs: a 1 930 x 1 930 x 256 product alone is 64 tiles of 256 x 256,
     // a quarter of the chip, and pays the full pipeline latency of a tile
-    if (launch_gemm_grouped(feat, d, feat, mat, gg, total_tiles, *max_m, sparts, tparts, stream)) return 1;
+    if (launch_gemm_grouped(feat, d, feat, mat, gg, total_tiles, *max_m, sparts, tparts, epi_mode, epi, stream))
+      return 1;
+    if (epi_applied) *epi_applied = epi_mode != 0;
   } else {
     for (int b = 0; b < npairs; ++b)
       if (launch_linear_ranged(feat + (size_t)h[b].src_beg * d, h[b].n, d, feat + (size_t)h[b].tgt_beg * d,
@@ -891,13 +911,20 @@ extern "C" int spr_match_dualsoftmax2(const float* feat, int d, const int* cu, c
   std::vector<PairDesc> h;
   long long total;
   int max_n, max_m;
-  if (correlate(feat, d, cu, cu_host, npairs, w, &mat, &pd, h, &total, &max_n, &max_m, stream)) return 1;
+  const float scale = 1.0f / sqrtf((float)d);
+  float* epi = w.take<float>(4);
+  SPR_REQUIRE(epi != nullptr, "match: workspace carve failed");
+  hipLaunchKernelGGL(k_epi_params, dim3(1), dim3(64), 0, stream, scale, (const float*)nullptr,
+                     (const float*)nullptr, epi);
+  bool scaled = false;
+  if (correlate(feat, d, cu, cu_host, npairs, w, &mat, &pd, h, &total, &max_n, &max_m, stream, kEpiScale, epi,
+                &scaled))
+    return 1;
   const int T = cu_host[2 * npairs];
   float* row_lse = w.take<float>(T);
   float* col_lse = w.take<float>(T);
   SPR_REQUIRE(col_lse != nullptr, "match: workspace carve failed");
-  const float scale = 1.0f / sqrtf((float)d);
-  hipLaunchKernelGGL(k_scale, dim3(cdiv(total, 256)), dim3(256), 0, stream, mat, total, scale);
+  if (!scaled) hipLaunchKernelGGL(k_scale, dim3(cdiv(total, 256)), dim3(256), 0, stream, mat, total, scale);
   hipLaunchKernelGGL(k_row_lse, dim3(cdiv((long)max_n * 64, 256), npairs), dim3(256), 0, stream, mat,
                      pd, row_lse, (const float*)nullptr, 0);
   hipLaunchKernelGGL(k_col_lse, dim3(cdiv(max_m, 64), npairs), dim3(1024), 0, stream, mat, pd, col_lse,
@@ -950,14 +977,21 @@ extern "C" int spr_sinkhorn_correspondences(const float* feat, int d, const floa
   std::vector<PairDesc> h;
   long long total;
   int max_n, max_m;
-  if (correlate(feat, d, cu, cu_host, npairs, w, &mat, &pd, h, &total, &max_n, &max_m, stream)) return 1;
+  const float scale = 1.0f / sqrtf((float)d);
+  SPR_REQUIRE(alpha != nullptr && beta != nullptr, "sinkhorn: alpha / beta must be device pointers");
+  float* epi = w.take<float>(4);
+  SPR_REQUIRE(epi != nullptr, "sinkhorn: workspace carve failed");
+  hipLaunchKernelGGL(k_epi_params, dim3(1), dim3(64), 0, stream, scale, alpha, beta, epi);
+  bool fused = false;
+  if (correlate(feat, d, cu, cu_host, npairs, w, &mat, &pd, h, &total, &max_n, &max_m, stream, kEpiAffinity, epi,
+                &fused))
+    return 1;
   const int T = cu_host[2 * npairs];
   float* u = w.take<float>(T);
   float* v = w.take<float>(T);
   SPR_REQUIRE(v != nullptr, "sinkhorn: workspace carve failed");
-  const float scale = 1.0f / sqrtf((float)d);
-  SPR_REQUIRE(alpha != nullptr && beta != nullptr, "sinkhorn: alpha / beta must be device pointers");
-  hipLaunchKernelGGL(k_affinity, dim3(cdiv(total, 256)), dim3(256), 0, stream, mat, total, scale, alpha, beta);
+  if (!fused)
+    hipLaunchKernelGGL(k_affinity, dim3(cdiv(total, 256)), dim3(256), 0, stream, mat, total, scale, alpha, beta);
   SPR_HIP_CHECK(hipMemsetAsync(u, 0, sizeof(float) * T, stream));
   SPR_HIP_CHECK(hipMemsetAsync(v, 0, sizeof(float) * T, stream));
   for (int it = 0; it < n_iters; ++it) {

@@ -221,9 +221,29 @@ __global__ void k_maxpool(const float* __restrict__ x, int ns, int c, const int*
   const int row = (int)(gid / c4), q = (int)(gid % c4);
   float4 m = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
   const int* ir = idx + (size_t)row * idx_stride;
-  for (int j = 0; j < k; ++j) {
+  int j = 0;
+  // four gathers in flight per thread (the serial one-load-per-iteration loop was latency bound)
+  for (; j + 4 <= k; j += 4) {
+    int id[4];
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) id[u] = ir[j + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);    // shadow row (kpconv_blocks.py:136)
+      if (id[u] >= 0 && id[u] < ns) v[u] = reinterpret_cast<const float4*>(x + (size_t)id[u] * c)[q];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      m.x = fmaxf(m.x, v[u].x);
+      m.y = fmaxf(m.y, v[u].y);
+      m.z = fmaxf(m.z, v[u].z);
+      m.w = fmaxf(m.w, v[u].w);
+    }
+  }
+  for (; j < k; ++j) {
     const int id = ir[j];
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);  // shadow row (kpconv_blocks.py:136)
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (id >= 0 && id < ns) v = reinterpret_cast<const float4*>(x + (size_t)id * c)[q];
     m.x = fmaxf(m.x, v.x);
     m.y = fmaxf(m.y, v.y);
