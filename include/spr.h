@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPR_VERSION 2
+#define SPR_VERSION 3
 
 /* activation codes for spr_linear / spr_instnorm */
 #define SPR_ACT_NONE 0
@@ -150,17 +150,34 @@ int spr_linear(const float* x, int m, int k, const float* w, int n,
  * that has just written x can publish the range instead, as an array of per-workgroup partial
  * maxima in device memory (any count; their maximum must bound max |x| from above):
  *   x_range / x_range_n     range of x (NULL: measure);
+ *   w_range / w_range_n     range of the weights (NULL: measure).  Weights do not change between
+ *     inference calls: measure them once with spr_absmax (spr_range_parts() floats) and pass
+ *     the result on every call; with both ranges handed in the call has no pre-pass at all;
  *   out_range (capacity out_range_cap floats): if the GEMM runs with <= out_range_cap
  *     workgroups it writes one partial per workgroup and sets *out_range_n_host (a HOST int)
  *     to their number, else 0 (nothing published).
  * spr_layernorm_r publishes the ranges of its two outputs into spr_layernorm_range_count(m)
  * slots each, which the CALLER MUST ZERO beforehand (the kernel combines its workgroups'
  * maxima with atomic max); spr_attn_inproj_varlen_fwd_r accepts the input ranges and publishes a bound of
- * its output (1 float: the attention output is a convex combination of value rows). */
+ * its output (1 float: the attention output is a convex combination of value rows).
+ * spr_instnorm_r and spr_maxpool_gather_r publish |out| the same way as spr_layernorm_r
+ * (out_range_n zeroed slots, a power of two chosen by the caller); spr_kpconv_fwd_r accepts x_range / w_range. */
+int spr_range_parts(void);
+int spr_absmax(const float* x, long rows, int cols, long stride, float* parts, void* stream);
 int spr_linear_r(const float* x, int m, int k, const float* w, int n, const float* bias,
                  const float* residual, int act, float* out, const float* x_range,
-                 int x_range_n, float* out_range, int out_range_cap, int* out_range_n_host,
-                 void* ws, size_t ws_bytes, void* stream);
+                 int x_range_n, const float* w_range, int w_range_n, float* out_range,
+                 int out_range_cap, int* out_range_n_host, void* ws, size_t ws_bytes, void* stream);
+int spr_kpconv_fwd_r(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
+                     int nbr_stride, int kmax, int rows_sorted, const float* x, int cin,
+                     const float* weights, int cout, const float* kernel_points, int n_kp,
+                     float kp_extent, float* out, int impl, const float* x_range, int x_range_n,
+                     const float* w_range, int w_range_n, void* ws, size_t ws_bytes, void* stream);
+int spr_instnorm_r(const float* x, const int* cu, int n, int nb, int max_len_host, int c,
+                   float eps, int norm, const float* add, float slope, float* out,
+                   float* out_range, int out_range_n, void* ws, size_t ws_bytes, void* stream);
+int spr_maxpool_gather_r(const float* x, int ns, int c, const int* idx, int nq, int idx_stride,
+                         int k, float* out, float* out_range, int out_range_n, void* stream);
 int spr_layernorm_range_count(int m);
 int spr_layernorm_r(const float* x, int m, int c, const float* gamma, const float* beta,
                     float eps, const float* pos, float* out_norm, float* out_pos,

@@ -36,7 +36,13 @@ SIGNATURES = {
     "spr_maxpool_gather": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "spr_linear_workspace_bytes": (_sz, []),
     "spr_linear": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
-    "spr_linear_r": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "spr_linear_r": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _sz, _vp]),
+    "spr_range_parts": (_i, []),
+    "spr_absmax": (_i, [_vp, _l, _i, _l, _vp, _vp]),
+    "spr_kpconv_fwd_r": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp,
+                              _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "spr_instnorm_r": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _f, _vp, _vp, _i, _vp, _sz, _vp]),
+    "spr_maxpool_gather_r": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "spr_layernorm_range_count": (_i, [_i]),
     "spr_layernorm_r": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spr_attn_inproj_varlen_fwd_r": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp,

@@ -179,6 +179,14 @@ int spr::launch_absmax2(const float* x0, long rows0, int cols0, long stride0, fl
   return 0;
 }
 
+// Range of a tensor that does not change between calls (weights): measured once by the caller
+// and handed to spr_linear_r / spr_kpconv_fwd_r as w_range (spr_range_parts() floats).
+extern "C" int spr_range_parts(void) { return spr::kAmaxParts; }
+extern "C" int spr_absmax(const float* x, long rows, int cols, long stride, float* parts, void* stream_) {
+  SPR_REQUIRE(x != nullptr && parts != nullptr && rows >= 1 && cols >= 1 && stride >= cols, "absmax: bad arguments");
+  return spr::launch_absmax(x, rows, cols, stride, parts, (hipStream_t)stream_);
+}
+
 extern "C" int spr_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (auto& r : g_prof) {

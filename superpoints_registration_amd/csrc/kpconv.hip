@@ -171,10 +171,10 @@ __global__ __launch_bounds__(256) void k_kpconv_cin1(
 // The weights are multiplied by the power of two that brings max |w| into [2^14, 2^15)
 // (w_parts: launch_absmax partials) before the split -- see split_pk_s, spr_common.h.
 __global__ __launch_bounds__(256) void k_w_prep(const float* __restrict__ W, int cin, int cout, int cc,
-                                                const float* __restrict__ w_parts,
+                                                const float* __restrict__ w_parts, int n_wparts,
                                                 _Float16* __restrict__ Wh, _Float16* __restrict__ Wl) {
   __shared__ float sh[17];
-  const float sb = pow2f(pow2_exp_for(block_absmax(w_parts, sh)));
+  const float sb = pow2f(pow2_exp_for(block_absmax(w_parts, sh, n_wparts)));
   const int total = kKP * cin * cout;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64 * P1W) void k_kpconv_mfma(
     const float* __restrict__ x, int cin, const _Float16* __restrict__ Wh,
     const _Float16* __restrict__ Wl, int cout, const float* __restrict__ kpts, float inv_extent,
     const float4* __restrict__ sxf, const float* __restrict__ x_parts,
-    const float* __restrict__ w_parts, float* __restrict__ out) {
+    const float* __restrict__ w_parts, int n_xparts, int n_wparts, float* __restrict__ out) {
   constexpr int NTC = CC / 16;
   constexpr int MT = TQ / 16;
   constexpr int KW = kKP * CC;       // phase-2 K per chunk
@@ -292,8 +292,8 @@ __global__ __launch_bounds__(64 * P1W) void k_kpconv_mfma(
   float sa, unscale;
   {
     float* shf = reinterpret_cast<float*>(lds_raw);
-    const int ka = pow2_exp_for(block_absmax(x_parts, shf) * (float)kmax);
-    const int kb = pow2_exp_for(block_absmax(w_parts, shf));
+    const int ka = pow2_exp_for(block_absmax(x_parts, shf, n_xparts) * (float)kmax);
+    const int kb = pow2_exp_for(block_absmax(w_parts, shf, n_wparts));
     __syncthreads();
     sa = pow2f(ka);
     unscale = pow2f(-ka - kb);
@@ -557,8 +557,8 @@ template <int CC, int TQ, int NTW, int NW, int SK, int P1W = NW>
 int launch_mfma(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
                 int nbr_stride, int kmax, int rows_sorted, const float* x, int cin,
                 const _Float16* Wh, const _Float16* Wl, int cout, const float* kpts,
-                float inv_extent, const float4* sxf, const float* x_parts, const float* w_parts, float* out,
-                hipStream_t stream) {
+                float inv_extent, const float4* sxf, const float* x_parts, const float* w_parts, int n_xparts,
+                int n_wparts, float* out, hipStream_t stream) {
   constexpr int SH = kKP * CC + 16;
   constexpr int QPW = TQ / P1W;
   const int nblk = (kmax + 15) / 16;
@@ -575,7 +575,7 @@ int launch_mfma(const float* q_xyz, int nq, const float* s_xyz, int ns, const in
   const int grid = ntiles < n_cu * per_cu ? ntiles : n_cu * per_cu;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * P1W), lds, stream, q_xyz, nq, s_xyz, ns,
                      nbr, nbr_stride, kmax, rows_sorted, x, cin, Wh, Wl, cout, kpts, inv_extent,
-                     sxf, x_parts, w_parts, out);
+                     sxf, x_parts, w_parts, n_xparts, n_wparts, out);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -600,7 +600,20 @@ extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, in
                               const float* kernel_points, int n_kp, float kp_extent,
                               float* out, int impl, void* ws, size_t ws_bytes,
                               void* stream_) {
+  return spr_kpconv_fwd_r(q_xyz, nq, s_xyz, ns, nbr, nbr_stride, kmax, rows_sorted, x, cin, weights, cout, kernel_points,
+                          n_kp, kp_extent, out, impl, nullptr, 0, nullptr, 0, ws, ws_bytes, stream_);
+}
+
+// x_range / w_range: operand ranges handed in (see spr_linear_r); NULL = measured here.
+extern "C" int spr_kpconv_fwd_r(const float* q_xyz, int nq, const float* s_xyz, int ns,
+                                const int* nbr, int nbr_stride, int kmax, int rows_sorted,
+                                const float* x, int cin, const float* weights, int cout,
+                                const float* kernel_points, int n_kp, float kp_extent,
+                                float* out, int impl, const float* x_range, int x_range_n, const float* w_range,
+                                int w_range_n, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE((x_range == nullptr || x_range_n >= 1) && (w_range == nullptr || w_range_n >= 1),
+              "kpconv: a range needs a count");
   SPR_REQUIRE(nq > 0 && ns > 0, "kpconv: empty input");
   SPR_REQUIRE(kmax >= 1 && kmax <= nbr_stride, "kpconv: bad kmax=%d stride=%d", kmax, nbr_stride);
   SPR_REQUIRE(cin >= 1 && cout >= 1 && n_kp >= 1 && n_kp <= 32, "kpconv: bad dims");
@@ -628,12 +641,21 @@ extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, in
 
   if (impl == 0 && n_kp == kKP && cin % 32 == 0 && cout % 32 == 0 && cout <= 256) {
     const int ktot = n_kp * cin;
-    if (int rc = launch_absmax2(x, ns, cin, cin, x_parts, weights, ktot, cout, cout, w_parts, stream)) return rc;
+    const float* xp = x_range != nullptr ? x_range : x_parts;
+    const float* wp = w_range != nullptr ? w_range : w_parts;
+    const int n_xp = x_range != nullptr ? x_range_n : kAmaxParts, n_wp = w_range != nullptr ? w_range_n : kAmaxParts;
+    if (x_range == nullptr && w_range == nullptr) {
+      if (int rc = launch_absmax2(x, ns, cin, cin, x_parts, weights, ktot, cout, cout, w_parts, stream)) return rc;
+    } else if (x_range == nullptr) {
+      if (int rc = launch_absmax(x, ns, cin, cin, x_parts, stream)) return rc;
+    } else if (w_range == nullptr) {
+      if (int rc = launch_absmax(weights, ktot, cout, cout, w_parts, stream)) return rc;
+    }
     hipLaunchKernelGGL(k_w_prep, dim3(cdiv((long)ktot * cout, 256)), dim3(256), 0, stream, weights, cin, cout,
-                       cin % 64 == 0 ? 64 : 32, w_parts, wh, wl);
+                       cin % 64 == 0 ? 64 : 32, wp, n_wp, wh, wl);
 #define SPR_KP_ARGS                                                                         \
   q_xyz, nq, s_xyz, ns, nbr, nbr_stride, kmax, rows_sorted, x, cin, wh, wl, cout,           \
-      kernel_points, inv_extent, sxf, x_parts, w_parts, out, stream
+      kernel_points, inv_extent, sxf, xp, wp, n_xp, n_wp, out, stream
     if (cin % 64 == 0) {
       // TQ = 32 (MT = 2), 8 waves: 4 n-groups x 2 k-halves, every wave both m-tiles
       if (cout == 64) return launch_mfma<64, 32, 1, 8, 2>(SPR_KP_ARGS);

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
     const float* __restrict__ bias, const float* __restrict__ residual,
     float* __restrict__ outp, AttnPlanes pl, int f0, const float* __restrict__ a_parts, int n_aparts,
     const float* __restrict__ w_parts, float* __restrict__ out_parts,
-    const GemmGroup* __restrict__ groups) {
+    const GemmGroup* __restrict__ groups, int n_wparts) {
   constexpr int NT = WM * WN * 64;      // threads (4 or 8 waves)
   // grouped launch (groups != nullptr): the grid is the concatenation of the tile grids of
   // independent problems X_g [m_g, K] x W_g [n_g, K]^T that share K and the operand scales
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
   {
     float* shf = reinterpret_cast<float*>(gemm_smem);
     const int ka = pow2_exp_for(block_absmax(a_parts, shf, n_aparts));
-    const int kb = pow2_exp_for(block_absmax(w_parts, shf));
+    const int kb = pow2_exp_for(block_absmax(w_parts, shf, n_wparts));
     __syncthreads();   // shf aliases the operand tiles
     sa = pow2f(ka);
     sb = pow2f(kb);
@@ -457,7 +457,7 @@ __global__ void k_gemv_rows(const float* __restrict__ X, int M, int K, const flo
   }
 }
 
-constexpr int kLnRangeSlots = 64;
+constexpr int kLnRangeSlots = kRangeSlots;
 // One wave per row; c % 64 == 0, c <= 1024.
 template <int MAXV>
 __global__ void k_layernorm(const float* __restrict__ x, int m, int c,
@@ -524,8 +524,9 @@ __global__ void k_layernorm(const float* __restrict__ x, int m, int c,
   }
 }
 
-// c == 256 (d_model of every shipped config): one wave per row, one float4 per lane and tensor --
-// 1 KiB per wave load / store instead of four 256-byte ones.
+// c == 256 (d_model of every shipped config): one float4 per lane and tensor (1 KiB per wave
+// load / store), kLnRows consecutive rows per wave with all their loads issued up front.
+constexpr int kLnRows = 4;
 __global__ __launch_bounds__(256) void k_layernorm256(const float* __restrict__ x, int m,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float eps,
@@ -533,33 +534,41 @@ __global__ __launch_bounds__(256) void k_layernorm256(const float* __restrict__ 
                                                       float* __restrict__ out_pos, float* __restrict__ range_norm,
                                                       float* __restrict__ range_pos) {
   __shared__ float shr[8];
-  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int row0 = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * kLnRows;
   const int lane = threadIdx.x & 63;
   float mxn = 0.f, mxp = 0.f;
-  if (row < m) {
-    const size_t o = (size_t)row * 256 + 4 * lane;
-    const float4 v = *reinterpret_cast<const float4*>(x + o);
-    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (out_pos) pv = *reinterpret_cast<const float4*>(pos + o);
-    const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * lane);
-    const float4 b = *reinterpret_cast<const float4*>(beta + 4 * lane);
-    const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) / 256.0f;
-    const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+  float4 v[kLnRows], pv[kLnRows];
+#pragma unroll
+  for (int r = 0; r < kLnRows; ++r) {
+    if (row0 + r < m) {
+      const size_t o = (size_t)(row0 + r) * 256 + 4 * lane;
+      v[r] = *reinterpret_cast<const float4*>(x + o);
+      if (out_pos) pv[r] = *reinterpret_cast<const float4*>(pos + o);
+    }
+  }
+  const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * lane);
+  const float4 b = *reinterpret_cast<const float4*>(beta + 4 * lane);
+#pragma unroll
+  for (int r = 0; r < kLnRows; ++r) {
+    if (row0 + r >= m) continue;
+    const size_t o = (size_t)(row0 + r) * 256 + 4 * lane;
+    const float mean = wave_sum((v[r].x + v[r].y) + (v[r].z + v[r].w)) / 256.0f;
+    const float dx = v[r].x - mean, dy = v[r].y - mean, dz = v[r].z - mean, dw = v[r].w - mean;
     const float rstd = 1.0f / sqrtf(wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) / 256.0f + eps);
     float4 y;
     y.x = dx * rstd * g.x + b.x;
     y.y = dy * rstd * g.y + b.y;
     y.z = dz * rstd * g.z + b.z;
     y.w = dw * rstd * g.w + b.w;
-    mxn = fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)));
+    mxn = fmaxf(mxn, fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w))));
     if (out_norm) *reinterpret_cast<float4*>(out_norm + o) = y;
     if (out_pos) {
       float4 yp;
-      yp.x = y.x + pv.x;
-      yp.y = y.y + pv.y;
-      yp.z = y.z + pv.z;
-      yp.w = y.w + pv.w;
-      mxp = fmaxf(fmaxf(fabsf(yp.x), fabsf(yp.y)), fmaxf(fabsf(yp.z), fabsf(yp.w)));
+      yp.x = y.x + pv[r].x;
+      yp.y = y.y + pv[r].y;
+      yp.z = y.z + pv[r].z;
+      yp.w = y.w + pv[r].w;
+      mxp = fmaxf(mxp, fmaxf(fmaxf(fabsf(yp.x), fabsf(yp.y)), fmaxf(fabsf(yp.z), fabsf(yp.w))));
       *reinterpret_cast<float4*>(out_pos + o) = yp;
     }
   }
@@ -610,7 +619,7 @@ namespace {
 template <int ACT, bool RES>
 int launch_gemm(const float* x, int m, int k, const float* w, int n, const float* bias,
                 const float* residual, float* out, const float* a_parts, int n_aparts, const float* w_parts,
-                float* out_parts, int out_cap, int* out_n, hipStream_t stream) {
+                int n_wparts, float* out_parts, int out_cap, int* out_n, hipStream_t stream) {
   if (out_n) *out_n = 0;
   if (spr::g_gemm_mode.load(std::memory_order_relaxed) == 1) {
     SPR_REQUIRE(a_parts != nullptr && w_parts != nullptr, "linear: split-fp16 mode needs the absmax partials");
@@ -625,15 +634,15 @@ int launch_gemm(const float* x, int m, int k, const float* w, int n, const float
       float* op = (out_parts && grid <= out_cap) ? out_parts : nullptr;   // range published only if it fits
       if (op && out_n) *out_n = grid;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds(256, 256), stream, x, m, k,
-                         w, n, bias, residual, out, spr::AttnPlanes(), 0, a_parts, n_aparts, w_parts, op, (const spr::GemmGroup*)nullptr);
+                         w, n, bias, residual, out, spr::AttnPlanes(), 0, a_parts, n_aparts, w_parts, op, (const spr::GemmGroup*)nullptr, n_wparts);
     } else if (n > 32) {
       hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 64, 4, 1, ACT, RES>), dim3(cdiv(n, 64) * cdiv(m, 128)),
                          dim3(256), lds(128, 64), stream, x, m, k, w, n, bias, residual, out, spr::AttnPlanes(), 0,
-                         a_parts, n_aparts, w_parts, (float*)nullptr, (const spr::GemmGroup*)nullptr);
+                         a_parts, n_aparts, w_parts, (float*)nullptr, (const spr::GemmGroup*)nullptr, n_wparts);
     } else {
       hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 32, 4, 1, ACT, RES>), dim3(cdiv(n, 32) * cdiv(m, 128)),
                          dim3(256), lds(128, 32), stream, x, m, k, w, n, bias, residual, out, spr::AttnPlanes(), 0,
-                         a_parts, n_aparts, w_parts, (float*)nullptr, (const spr::GemmGroup*)nullptr);
+                         a_parts, n_aparts, w_parts, (float*)nullptr, (const spr::GemmGroup*)nullptr, n_wparts);
     }
   } else if (n % 64 == 0) {
     hipLaunchKernelGGL((spr::k_gemm_nt<2, 2, ACT, RES>), dim3((n / 64) * cdiv(m, 64)), dim3(256), 0, stream,
@@ -659,7 +668,8 @@ int spr::launch_inproj_planes(const float* x, int m, int k, const float* w, int 
   const size_t lds = (size_t)(256 + 256) * spr::HS * 2 * sizeof(_Float16);
   if (int rc = ensure_dyn_lds((const void*)kern, (int)lds)) return rc;
   hipLaunchKernelGGL(kern, dim3(cdiv(n, 256) * cdiv(m, 256)), dim3(512), lds, stream, x, m, k, w, n, bias,
-                     (const float*)nullptr, (float*)nullptr, planes, f0, a_parts, n_aparts, w_parts, (float*)nullptr, (const spr::GemmGroup*)nullptr);
+                     (const float*)nullptr, (float*)nullptr, planes, f0, a_parts, n_aparts, w_parts, (float*)nullptr,
+                     (const spr::GemmGroup*)nullptr, kAmaxParts);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -669,8 +679,8 @@ int spr::launch_inproj_planes(const float* x, int m, int k, const float* w, int 
 // (which pass nullptr).
 int spr::launch_linear_ranged(const float* x, int m, int k, const float* w, int n, const float* bias,
                               float* out, const float* a_parts, const float* w_parts, hipStream_t stream) {
-  return launch_gemm<SPR_ACT_NONE, false>(x, m, k, w, n, bias, nullptr, out, a_parts, kAmaxParts, w_parts, nullptr, 0,
-                                          nullptr, stream);
+  return launch_gemm<SPR_ACT_NONE, false>(x, m, k, w, n, bias, nullptr, out, a_parts, kAmaxParts, w_parts, kAmaxParts,
+                                          nullptr, 0, nullptr, stream);
 }
 
 // Grouped NT GEMM, split-fp16 mode only: problem g is A_g = a + groups[g].a_off [m_g, k],
@@ -696,15 +706,15 @@ int launch_grouped_act(const float* a, int k, const float* b, float* c, const sp
     if (int rc = ensure_dyn_lds((const void*)kern, (int)lds(256, 256))) return rc;
     hipLaunchKernelGGL(kern, dim3(total_tiles), dim3(512), lds(256, 256), stream, a, 0, k, b, 0, epi,
                        (const float*)nullptr, c, spr::AttnPlanes(), 0, a_parts, kAmaxParts, w_parts,
-                       (float*)nullptr, groups_dev);
+                       (float*)nullptr, groups_dev, kAmaxParts);
   } else if (bn == 64) {
     hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 64, 4, 1, ACT, false>), dim3(total_tiles), dim3(256),
                        lds(128, 64), stream, a, 0, k, b, 0, epi, (const float*)nullptr, c, spr::AttnPlanes(), 0,
-                       a_parts, kAmaxParts, w_parts, (float*)nullptr, groups_dev);
+                       a_parts, kAmaxParts, w_parts, (float*)nullptr, groups_dev, kAmaxParts);
   } else {
     hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 32, 4, 1, ACT, false>), dim3(total_tiles), dim3(256),
                        lds(128, 32), stream, a, 0, k, b, 0, epi, (const float*)nullptr, c, spr::AttnPlanes(), 0,
-                       a_parts, kAmaxParts, w_parts, (float*)nullptr, groups_dev);
+                       a_parts, kAmaxParts, w_parts, (float*)nullptr, groups_dev, kAmaxParts);
   }
   SPR_LAUNCH_CHECK();
   return 0;
@@ -735,13 +745,14 @@ extern "C" size_t spr_linear_workspace_bytes(void) { return 2 * align_up(kAmaxPa
 
 extern "C" int spr_linear_r(const float* x, int m, int k, const float* w, int n, const float* bias,
                             const float* residual, int act, float* out, const float* x_range, int x_range_n,
-                            float* out_range, int out_range_cap, int* out_range_n_host, void* ws, size_t ws_bytes,
-                            void* stream_) {
+                            const float* w_range, int w_range_n, float* out_range, int out_range_cap,
+                            int* out_range_n_host, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (out_range_n_host) *out_range_n_host = 0;
   SPR_REQUIRE(m > 0 && k > 0 && n > 0, "linear: bad sizes m=%d k=%d n=%d", m, k, n);
   SPR_REQUIRE(act >= 0 && act <= 2, "linear: unknown activation %d", act);
   SPR_REQUIRE(x_range == nullptr || x_range_n >= 1, "linear: x_range needs a count");
+  SPR_REQUIRE(w_range == nullptr || w_range_n >= 1, "linear: w_range needs a count");
   if (n < 16 || k % BK != 0) {
     SPR_REQUIRE(n <= 64 || k % BK == 0, "linear: k must be a multiple of %d for n > 64 (k=%d n=%d)", BK, k, n);
     const long waves = (long)m * n;
@@ -751,25 +762,29 @@ extern "C" int spr_linear_r(const float* x, int m, int k, const float* w, int n,
     return 0;
   }
   const float *a_parts = nullptr, *w_parts = nullptr;
-  int n_ap = kAmaxParts;
+  int n_ap = kAmaxParts, n_wp = kAmaxParts;
   if (spr::gemm_mode() == 1) {
     SPR_REQUIRE(ws != nullptr && ws_bytes >= spr_linear_workspace_bytes(),
                 "linear: workspace too small (%zu bytes given, spr_linear_workspace_bytes() needed)", ws_bytes);
     Workspace wk(ws, ws_bytes);
     float* ap = wk.take<float>(kAmaxParts);
     float* wp = wk.take<float>(kAmaxParts);
-    if (x_range != nullptr) {   // the producer of x published its range: only the weights are measured
-      if (int rc = launch_absmax(w, n, k, k, wp, stream)) return rc;
-      a_parts = x_range;
-      n_ap = x_range_n;
-    } else {
+    // ranges handed in (x: published by its producer; w: measured once per weight version by
+    // the caller, spr_absmax) are not measured again -- with both there is no pre-pass at all
+    a_parts = x_range != nullptr ? x_range : ap;
+    w_parts = w_range != nullptr ? w_range : wp;
+    if (x_range != nullptr) n_ap = x_range_n;
+    if (w_range != nullptr) n_wp = w_range_n;
+    if (x_range == nullptr && w_range == nullptr) {
       if (int rc = launch_absmax2(x, m, k, k, ap, w, n, k, k, wp, stream)) return rc;
-      a_parts = ap;
+    } else if (x_range == nullptr) {
+      if (int rc = launch_absmax(x, m, k, k, ap, stream)) return rc;
+    } else if (w_range == nullptr) {
+      if (int rc = launch_absmax(w, n, k, k, wp, stream)) return rc;
     }
-    w_parts = wp;
   }
   const bool res = residual != nullptr;
-#define SPR_LG(A, R) launch_gemm<A, R>(x, m, k, w, n, bias, residual, out, a_parts, n_ap, w_parts, out_range, \
+#define SPR_LG(A, R) launch_gemm<A, R>(x, m, k, w, n, bias, residual, out, a_parts, n_ap, w_parts, n_wp, out_range, \
                                        out_range_cap, out_range_n_host, stream)
   switch (act * 2 + (res ? 1 : 0)) {
     case 0: return SPR_LG(SPR_ACT_NONE, false);
@@ -785,7 +800,8 @@ extern "C" int spr_linear_r(const float* x, int m, int k, const float* w, int n,
 extern "C" int spr_linear(const float* x, int m, int k, const float* w, int n, const float* bias,
                           const float* residual, int act, float* out, void* ws, size_t ws_bytes,
                           void* stream_) {
-  return spr_linear_r(x, m, k, w, n, bias, residual, act, out, nullptr, 0, nullptr, 0, nullptr, ws, ws_bytes, stream_);
+  return spr_linear_r(x, m, k, w, n, bias, residual, act, out, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, ws, ws_bytes,
+                      stream_);
 }
 
 extern "C" int spr_set_gemm_mode(int mode) {
@@ -807,7 +823,7 @@ extern "C" int spr_layernorm_r(const float* x, int m, int c, const float* gamma,
   SPR_REQUIRE(out_pos == nullptr || pos != nullptr, "layernorm: out_pos needs pos");
   const int grid = cdiv((long)m * 64, 256);
   if (c == 256)
-    hipLaunchKernelGGL(k_layernorm256, dim3(grid), dim3(256), 0, stream, x, m, gamma, beta, eps, pos, out_norm,
+    hipLaunchKernelGGL(k_layernorm256, dim3(cdiv((long)cdiv(m, kLnRows) * 64, 256)), dim3(256), 0, stream, x, m, gamma, beta, eps, pos, out_norm,
                        out_pos, range_norm, range_pos);
   else if (c <= 256)
     hipLaunchKernelGGL(k_layernorm<4>, dim3(grid), dim3(256), 0, stream, x, m, c, gamma, beta, eps,

@@ -876,8 +876,8 @@ int correlate(const float* feat, int d, const int* cu_dev, const int* cu_host, i
     float* pt = w.take<float>(kAmaxParts);
     SPR_REQUIRE(pt != nullptr, "match: workspace carve failed");
     const int nsrc = cu_host[npairs], ntot = cu_host[2 * npairs];
-    if (int rc = launch_absmax(feat, nsrc, d, d, ps, stream)) return rc;
-    if (int rc = launch_absmax(feat + (size_t)nsrc * d, ntot - nsrc, d, d, pt, stream)) return rc;
+    if (int rc = launch_absmax2(feat, nsrc, d, d, ps, feat + (size_t)nsrc * d, ntot - nsrc, d, d, pt, stream))
+      return rc;
     sparts = ps;
     tparts = pt;
   }

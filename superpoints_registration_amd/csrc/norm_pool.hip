@@ -114,37 +114,72 @@ __global__ void k_in_final(const double* __restrict__ part, const int* __restric
   rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-// One thread per 4 channels of one row.
-__global__ void k_in_apply(const float* __restrict__ x, const int* __restrict__ cu, int n, int nb,
-                           int c, int norm, const float* __restrict__ mean,
-                           const float* __restrict__ rstd, const float* __restrict__ add,
-                           float slope, float* __restrict__ out) {
+// Operand-range hand-over (spr.h): the workgroup's max |out| joins one of kRangeSlots slots by
+// integer atomic max on the bit pattern (non-negative floats order like unsigned ints; the result
+// does not depend on the order of arrival).  The caller zero-initialises the slots.  Called by
+// every thread of a 256-thread block.
+__device__ __forceinline__ void publish_range(float mx, float* __restrict__ slots, int nslots) {
+  __shared__ float shr[4];
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) shr[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(reinterpret_cast<unsigned int*>(slots) + (blockIdx.x & (nslots - 1)),
+              __float_as_uint(fmaxf(fmaxf(shr[0], shr[1]), fmaxf(shr[2], shr[3]))));
+}
+
+// Streaming pass, one float4 (4 channels of one row) per thread and step; every thread takes
+// kInApplyUnroll steps a whole grid apart (all loads of a thread issued up front), so that a
+// workgroup publishes its range once per kInApplyUnroll * 256 float4s.
+constexpr int kInApplyUnroll = 4;
+__global__ __launch_bounds__(256) void k_in_apply(const float* __restrict__ x, const int* __restrict__ cu, int n,
+                                                  int nb, int c, int norm, const float* __restrict__ mean,
+                                                  const float* __restrict__ rstd, const float* __restrict__ add,
+                                                  float slope, float* __restrict__ out,
+                                                  float* __restrict__ out_range, int nslots) {
   const int c4 = c >> 2;
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long)n * c4) return;
-  const int row = (int)(gid / c4), q = (int)(gid % c4);
-  float4 v = reinterpret_cast<const float4*>(x)[gid];
-  if (norm) {
-    const int cloud = find_segment(cu, nb, row);
-    const float4 m = reinterpret_cast<const float4*>(mean + (size_t)cloud * c)[q];
-    const float4 r = reinterpret_cast<const float4*>(rstd + (size_t)cloud * c)[q];
-    v.x = (v.x - m.x) * r.x;
-    v.y = (v.y - m.y) * r.y;
-    v.z = (v.z - m.z) * r.z;
-    v.w = (v.w - m.w) * r.w;
+  const long total = (long)n * c4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long g0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float4 v[kInApplyUnroll], a[kInApplyUnroll];
+#pragma unroll
+  for (int u = 0; u < kInApplyUnroll; ++u) {
+    const long gid = g0 + u * stride;
+    if (gid < total) {
+      v[u] = reinterpret_cast<const float4*>(x)[gid];
+      if (add) a[u] = reinterpret_cast<const float4*>(add)[gid];
+    }
   }
-  if (add) {
-    const float4 a = reinterpret_cast<const float4*>(add)[gid];
-    v.x += a.x;
-    v.y += a.y;
-    v.z += a.z;
-    v.w += a.w;
+  float mx = 0.f;
+#pragma unroll
+  for (int u = 0; u < kInApplyUnroll; ++u) {
+    const long gid = g0 + u * stride;
+    if (gid >= total) continue;
+    float4 w = v[u];
+    if (norm) {
+      const int row = (int)(gid / c4), q = (int)(gid % c4);
+      const int cloud = find_segment(cu, nb, row);
+      const float4 m = reinterpret_cast<const float4*>(mean + (size_t)cloud * c)[q];
+      const float4 r = reinterpret_cast<const float4*>(rstd + (size_t)cloud * c)[q];
+      w.x = (w.x - m.x) * r.x;
+      w.y = (w.y - m.y) * r.y;
+      w.z = (w.z - m.z) * r.z;
+      w.w = (w.w - m.w) * r.w;
+    }
+    if (add) {
+      w.x += a[u].x;
+      w.y += a[u].y;
+      w.z += a[u].z;
+      w.w += a[u].w;
+    }
+    w.x = w.x >= 0.f ? w.x : w.x * slope;
+    w.y = w.y >= 0.f ? w.y : w.y * slope;
+    w.z = w.z >= 0.f ? w.z : w.z * slope;
+    w.w = w.w >= 0.f ? w.w : w.w * slope;
+    reinterpret_cast<float4*>(out)[gid] = w;
+    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w))));
   }
-  v.x = v.x >= 0.f ? v.x : v.x * slope;
-  v.y = v.y >= 0.f ? v.y : v.y * slope;
-  v.z = v.z >= 0.f ? v.z : v.z * slope;
-  v.w = v.w >= 0.f ? v.w : v.w * slope;
-  reinterpret_cast<float4*>(out)[gid] = v;
+  if (out_range != nullptr) publish_range(mx, out_range, nslots);
 }
 
 // ---- backward of out = lrelu(IN(x) + add, slope) (kpconv_blocks.py:510-525, :553-561, :741) -----
@@ -214,10 +249,12 @@ __global__ void k_in_bwd_apply(const float* __restrict__ x, const float* __restr
 }
 
 __global__ void k_maxpool(const float* __restrict__ x, int ns, int c, const int* __restrict__ idx,
-                          int nq, int idx_stride, int k, float* __restrict__ out) {
+                          int nq, int idx_stride, int k, float* __restrict__ out, float* __restrict__ out_range,
+                          int nslots) {
   const int c4 = c >> 2;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long)nq * c4) return;
+  float mx = 0.f;
+  if (gid < (long)nq * c4) {
   const int row = (int)(gid / c4), q = (int)(gid % c4);
   float4 m = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
   const int* ir = idx + (size_t)row * idx_stride;
@@ -251,6 +288,9 @@ __global__ void k_maxpool(const float* __restrict__ x, int ns, int c, const int*
     m.w = fmaxf(m.w, v.w);
   }
   reinterpret_cast<float4*>(out)[gid] = m;
+  mx = fmaxf(fmaxf(fabsf(m.x), fabsf(m.y)), fmaxf(fabsf(m.z), fabsf(m.w)));
+  }
+  if (out_range != nullptr) publish_range(mx, out_range, nslots);
 }
 
 __global__ void k_gather_rows(const float* __restrict__ x, int n_src, int c,
@@ -276,7 +316,18 @@ extern "C" size_t spr_instnorm_workspace_bytes(int max_len, int nb, int c) {
 extern "C" int spr_instnorm(const float* x, const int* cu, int n, int nb, int max_len_host, int c,
                             float eps, int norm, const float* add, float slope, float* out,
                             void* ws, size_t ws_bytes, void* stream_) {
+  return spr_instnorm_r(x, cu, n, nb, max_len_host, c, eps, norm, add, slope, out, nullptr, 0, ws, ws_bytes, stream_);
+}
+
+// out_range: NULL, or out_range_n (a power of two) zero-initialised floats that receive partial
+// maxima of |out| (operand-range hand-over to the consuming GEMM / KPConv); a few hundred slots
+// keep the atomic traffic per address low on the largest tensors.
+extern "C" int spr_instnorm_r(const float* x, const int* cu, int n, int nb, int max_len_host, int c,
+                              float eps, int norm, const float* add, float slope, float* out, float* out_range,
+                              int out_range_n, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(out_range == nullptr || (out_range_n >= 1 && (out_range_n & (out_range_n - 1)) == 0),
+              "instnorm: out_range_n must be a power of two");
   SPR_REQUIRE(n > 0 && nb >= 1 && c >= 4 && c % 4 == 0, "instnorm: need n>0 and c %% 4 == 0 (c=%d)", c);
   float* mean = nullptr;
   float* rstd = nullptr;
@@ -295,8 +346,8 @@ extern "C" int spr_instnorm(const float* x, const int* cu, int n, int nb, int ma
     SPR_LAUNCH_CHECK();
   }
   const long total = (long)n * (c / 4);
-  hipLaunchKernelGGL(k_in_apply, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, cu, n, nb, c,
-                     norm, mean, rstd, add, slope, out);
+  hipLaunchKernelGGL(k_in_apply, dim3(cdiv(total, 256 * kInApplyUnroll)), dim3(256), 0, stream, x, cu, n, nb, c,
+                     norm, mean, rstd, add, slope, out, out_range, out_range_n);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -343,11 +394,19 @@ extern "C" int spr_instnorm_bwd(const float* x, const float* out, const float* d
 
 extern "C" int spr_maxpool_gather(const float* x, int ns, int c, const int* idx, int nq,
                                   int idx_stride, int k, float* out, void* stream_) {
+  return spr_maxpool_gather_r(x, ns, c, idx, nq, idx_stride, k, out, nullptr, 0, stream_);
+}
+
+// out_range: as in spr_instnorm_r.
+extern "C" int spr_maxpool_gather_r(const float* x, int ns, int c, const int* idx, int nq, int idx_stride, int k,
+                                    float* out, float* out_range, int out_range_n, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(out_range == nullptr || (out_range_n >= 1 && (out_range_n & (out_range_n - 1)) == 0),
+              "maxpool: out_range_n must be a power of two");
   SPR_REQUIRE(nq > 0 && ns > 0 && c % 4 == 0 && k >= 1 && k <= idx_stride, "maxpool: bad arguments");
   const long total = (long)nq * (c / 4);
   hipLaunchKernelGGL(k_maxpool, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, ns, c, idx, nq,
-                     idx_stride, k, out);
+                     idx_stride, k, out, out_range, out_range_n);
   SPR_LAUNCH_CHECK();
   return 0;
 }

@@ -201,6 +201,8 @@ __host__ __device__ __forceinline__ float pow2f(int k) {   // 2^k, |k| <= 126
 // consumer kernel reduces them in its prologue with block_absmax -- no atomics,
 // no memset, no host round trip.
 constexpr int kAmaxParts = 512;
+// slots of a range published by a producer kernel (atomic max; LayerNorm, InstanceNorm, max-pool)
+constexpr int kRangeSlots = 64;
 // Reduces parts[0..kAmaxParts) over the workgroup; `sh` = 17 floats of LDS.
 // Contains two __syncthreads().  Result returned to every thread.
 // n: number of partials (kAmaxParts for a measured range; producers that publish the range of

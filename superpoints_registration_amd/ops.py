@@ -44,9 +44,19 @@ _ws_cache = {}
 # partials; the consuming GEMM then scales its operand without a measuring pass over x.  The
 # range rides on the Python tensor object as an attribute and is honoured only while the tensor
 # is untouched (same storage pointer, same version counter): views, copies and in-place edits drop it.
+_range_epoch = [0]
+
+
+def invalidate_ranges() -> None:
+    """Drops every cached / published operand range.  Needed only after mutating a tensor behind
+    autograd's back (`w.data.copy_(...)`, raw pointer writes): such edits do not move the version
+    counter the ranges are keyed on."""
+    _range_epoch[0] += 1
+
+
 def _set_range(t: torch.Tensor, parts: torch.Tensor, n: int) -> None:
     if n > 0:
-        t._spr_range = (parts, int(n), t._version, t.data_ptr())
+        t._spr_range = (parts, int(n), t._version, t.data_ptr(), _range_epoch[0])
 
 
 _HANDOVER = os.environ.get("SPR_NO_RANGE_HANDOVER", "0") != "1"   # experiment switch (A/B timing)
@@ -56,25 +66,45 @@ def _get_range(t):
     if not _HANDOVER:
         return None, 0
     r = getattr(t, '_spr_range', None)
-    if r is None or r[2] != t._version or r[3] != t.data_ptr():
+    if r is None or r[2] != t._version or r[3] != t.data_ptr() or r[4] != _range_epoch[0]:
         return None, 0
     return r[0], r[1]
 
 _RANGE_CAP = 4096   # partials a GEMM may publish (one per workgroup)
+_STREAM_SLOTS = 512  # atomic-max slots of the streaming producers (InstanceNorm apply, max-pool)
 _zero_pool = {}
 
 
 def _zero_slots(n: int, device) -> torch.Tensor:
-    """n zero-initialised floats from a per-(device, stream) pool: one memset per 64 K slots instead
+    """n zero-initialised floats from a per-(device, stream) pool: one memset per 256 K slots instead
     of one per LayerNorm call (its range slots are combined with atomic max and must start at 0)."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     pool = _zero_pool.get(key)
     if pool is None or pool[1] + n > pool[0].numel():
-        pool = [torch.zeros(65536, dtype=torch.float32, device=device), 0]
+        pool = [torch.zeros(1 << 18, dtype=torch.float32, device=device), 0]
         _zero_pool[key] = pool
     out = pool[0][pool[1]:pool[1] + n]
     pool[1] += n
     return out
+
+
+def _static_range(w: torch.Tensor):
+    """Range partials of a tensor that rarely changes (weights): measured once per (storage,
+    version) with spr_absmax and kept on the tensor like a published range -- an optimizer step
+    bumps the version counter and the next call measures again."""
+    if not _HANDOVER:
+        return None, 0
+    r, n = _get_range(w)
+    if r is not None:
+        return r, n
+    L = _lib.lib()
+    n = L.spr_range_parts()
+    flat = w.reshape(-1, w.shape[-1])
+    parts = torch.empty((n,), dtype=torch.float32, device=w.device)
+    _lib.check(L.spr_absmax(_ptr(flat), flat.shape[0], flat.shape[1], flat.shape[1], _ptr(parts), _stream(w)),
+               "spr_absmax")
+    _set_range(w, parts, n)
+    return parts, n
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
@@ -213,10 +243,13 @@ def kpconv_raw(q_pts, s_pts, nbr, x, weights, kernel_points, kp_extent: float, r
     L = _lib.lib()
     ws = _workspace(L.spr_kpconv_workspace_bytes(nq, ns, cin, cout), x.device)
     out = torch.empty((nq, cout), dtype=torch.float32, device=x.device)
-    _lib.check(L.spr_kpconv_fwd(_ptr(q_pts), nq, _ptr(s_pts), ns, _ptr(nbr), int(stride), kmax,
-                                int(bool(rows_sorted)), _ptr(x), cin, _ptr(weights), cout,
-                                _ptr(kernel_points), n_kp, float(kp_extent), _ptr(out), int(impl),
-                                _ptr(ws), ws.numel(), _stream(x)), "spr_kpconv_fwd")
+    xr, xr_n = _get_range(x)
+    wr, wr_n = _static_range(weights)
+    _lib.check(L.spr_kpconv_fwd_r(_ptr(q_pts), nq, _ptr(s_pts), ns, _ptr(nbr), int(stride), kmax,
+                                  int(bool(rows_sorted)), _ptr(x), cin, _ptr(weights), cout,
+                                  _ptr(kernel_points), n_kp, float(kp_extent), _ptr(out), int(impl),
+                                  _ptr(xr), int(xr_n), _ptr(wr), int(wr_n),
+                                  _ptr(ws), ws.numel(), _stream(x)), "spr_kpconv_fwd_r")
     return out
 
 
@@ -246,9 +279,13 @@ def instnorm_raw(x, cu, eps: float = 1e-5, norm: bool = True, add=None, slope: f
     L = _lib.lib()
     max_len = n if max_len is None else max(1, min(int(max_len), n))
     ws = _workspace(L.spr_instnorm_workspace_bytes(max_len, nb, c), x.device)
-    _lib.check(L.spr_instnorm(_ptr(x), _ptr(cu), n, nb, max_len, c, float(eps), int(bool(norm)), _ptr(add),
-                              float(slope), _ptr(out), _ptr(ws), ws.numel(), _stream(x)),
-               "spr_instnorm")
+    cnt = _STREAM_SLOTS
+    rng = _zero_slots(cnt, x.device) if _HANDOVER else None
+    _lib.check(L.spr_instnorm_r(_ptr(x), _ptr(cu), n, nb, max_len, c, float(eps), int(bool(norm)), _ptr(add),
+                                float(slope), _ptr(out), _ptr(rng), cnt, _ptr(ws), ws.numel(), _stream(x)),
+               "spr_instnorm_r")
+    if rng is not None:
+        _set_range(out, rng, cnt)
     return out
 
 
@@ -270,8 +307,13 @@ def maxpool_raw(x, idx) -> torch.Tensor:
     ns, c = x.shape
     nq, k = idx.shape
     out = torch.empty((nq, c), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().spr_maxpool_gather(_ptr(x), ns, c, _ptr(idx), nq, int(stride), k, _ptr(out),
-                                             _stream(x)), "spr_maxpool_gather")
+    L = _lib.lib()
+    cnt = _STREAM_SLOTS
+    rng = _zero_slots(cnt, x.device) if _HANDOVER else None
+    _lib.check(L.spr_maxpool_gather_r(_ptr(x), ns, c, _ptr(idx), nq, int(stride), k, _ptr(out), _ptr(rng), cnt,
+                                      _stream(x)), "spr_maxpool_gather_r")
+    if rng is not None:
+        _set_range(out, rng, cnt)
     return out
 
 
@@ -298,11 +340,13 @@ def linear_raw(x, weight, bias=None, residual=None, act: int = ACT_NONE) -> torc
     L = _lib.lib()
     ws = _workspace(L.spr_linear_workspace_bytes(), x.device)
     xr, xr_n = _get_range(x)
+    wr, wr_n = _static_range(weight)
     # outputs that go on into another GEMM (no residual: FFN hidden, projections) publish their range
     orng = torch.empty((_RANGE_CAP,), dtype=torch.float32, device=x.device) if residual is None else None
     on = ctypes.c_int(0)
     _lib.check(L.spr_linear_r(_ptr(x), m, k, _ptr(weight), n, _ptr(bias), _ptr(residual), int(act), _ptr(out),
-                              _ptr(xr), int(xr_n), _ptr(orng), _RANGE_CAP if orng is not None else 0, ctypes.byref(on),
+                              _ptr(xr), int(xr_n), _ptr(wr), int(wr_n), _ptr(orng),
+                              _RANGE_CAP if orng is not None else 0, ctypes.byref(on),
                               _ptr(ws), ws.numel(), _stream(x)), "spr_linear_r")
     if orng is not None:
         _set_range(out, orng, on.value)

@@ -314,3 +314,28 @@ def test_published_ranges_replace_the_measuring_pass(device):
     y = ops.linear(n, w1.to(device))
     ref = n.double().cpu() @ w1.double().t()
     assert torch.isfinite(y).all() and float((y.double().cpu() - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
+
+
+def test_weight_ranges_are_cached_per_version_and_follow_in_place_updates(device):
+    """ops.linear keeps the measured range of a weight tensor on the tensor (no pre-pass on later
+    calls); an in-place update moves the version counter and must trigger a new measurement --
+    otherwise a grown weight would overflow the fp16 planes."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(300, 64, generator=g).to(device)
+    w = (torch.randn(96, 64, generator=g) * 0.05).to(device)
+    y0 = ops.linear(x, w)
+    assert getattr(w, '_spr_range', None) is not None
+    first = w._spr_range[0]
+    ops.linear(x, w)
+    assert w._spr_range[0] is first                       # cached: same partials object
+    with torch.no_grad():
+        w.mul_(4096.0)                                    # far beyond the one bit of headroom
+    y1 = ops.linear(x, w)
+    assert w._spr_range[0] is not first
+    ref = x.double() @ w.double().t()
+    assert torch.isfinite(y1).all()
+    assert (y1.double() - ref).abs().max() <= 2e-6 * ref.abs().max()
+    assert (y0.double() * 4096.0 - ref).abs().max() <= 4e-6 * ref.abs().max()
+    ops.invalidate_ranges()
+    ops.linear(x, w)
+    assert w._spr_range[4] == ops._range_epoch[0]
