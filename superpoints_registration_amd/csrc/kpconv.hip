@@ -37,11 +37,60 @@ constexpr int kKP = 15;  // kernel points handled by the MFMA path (padded to 16
 // Per support point: flag = (sum of its features > 0) (the reference's neighbour
 // count, kpconv_blocks.py:399-404) and one 16-byte record {x, y, z, flag} so
 // that the fused kernel fetches a neighbour's position and flag with ONE load.
-__global__ void k_rowflag(const float* __restrict__ x, const float* __restrict__ s_xyz, int ns,
-                          int cin, unsigned char* __restrict__ flag, float4* __restrict__ sxf) {
-  // one wave per row
-  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__global__ __launch_bounds__(256) void k_rowflag(const float* __restrict__ x, const float* __restrict__ s_xyz,
+                                                 int ns, int cin, unsigned char* __restrict__ flag,
+                                                 float4* __restrict__ sxf) {
+  const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
+  const int c4 = cin >> 2;
+  if ((cin & 3) == 0 && c4 <= 64 && (c4 & (c4 - 1)) == 0) {
+    // float4 per lane; a wave load covers 64 / c4 whole rows (1 KiB), kRfSteps loads in flight
+    constexpr int kRfSteps = 4;
+    const int rpl = 64 / c4;                       // rows per wave load
+    const int sub = lane / c4, chunk = lane % c4;
+    const int row0 = wid * rpl * kRfSteps + sub;
+    float4 v[kRfSteps];
+#pragma unroll
+    for (int r = 0; r < kRfSteps; ++r) {
+      const int row = row0 + r * rpl;
+      v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < ns) v[r] = reinterpret_cast<const float4*>(x + (size_t)row * cin)[chunk];
+    }
+#pragma unroll
+    for (int r = 0; r < kRfSteps; ++r) {
+      const int row = row0 + r * rpl;
+      // The flag is the SIGN of a float sum, so the summation order is part of the result (rows
+      // of normalised features sum to ~0).  Keep the order of the one-wave-per-row form this
+      // replaces (the generic path below): channel-index bits >= 6 ascending, then a butterfly
+      // over bits 5..0 from the top -- here bits >= 2 live in the lane index (chunk), bits 1..0
+      // inside the float4.
+      float c[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = c[e];
+        if (c4 == 64) {
+          const int b = lane & 15;
+          const float a0 = __shfl(t, b, 64), a1 = __shfl(t, b | 16, 64), a2 = __shfl(t, b | 32, 64),
+                      a3 = __shfl(t, b | 48, 64);
+          t = ((a0 + a1) + a2) + a3;
+        } else if (c4 == 32) {
+          t += __shfl_xor(t, 16, 64);
+        }
+        for (int o = (c4 < 16 ? c4 : 16) >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        c[e] = t;
+      }
+      const float t = (c[0] + c[2]) + (c[1] + c[3]);
+      if (chunk == 0 && row < ns) {
+        const int f = t > 0.f ? 1 : 0;
+        flag[row] = (unsigned char)f;
+        sxf[row] = make_float4(s_xyz[3 * (size_t)row], s_xyz[3 * (size_t)row + 1],
+                               s_xyz[3 * (size_t)row + 2], __int_as_float(f));
+      }
+    }
+    return;
+  }
+  // generic: one wave per row
+  const int row = wid;
   if (row >= ns) return;
   float s = 0.f;
   for (int c = lane; c < cin; c += 64) s += x[(size_t)row * cin + c];
@@ -635,8 +684,12 @@ extern "C" int spr_kpconv_fwd_r(const float* q_xyz, int nq, const float* s_xyz, 
     return 0;
   }
 
-  hipLaunchKernelGGL(k_rowflag, dim3(cdiv((long)ns * 64, 256)), dim3(256), 0, stream, x, s_xyz, ns, cin,
-                     flag, sxf);
+  {
+    const int c4 = cin >> 2;
+    const bool wide = (cin & 3) == 0 && c4 <= 64 && (c4 & (c4 - 1)) == 0;
+    const long waves = wide ? cdiv(ns, (64 / c4) * 4) : (long)ns;     // matches k_rowflag's two layouts
+    hipLaunchKernelGGL(k_rowflag, dim3(cdiv(waves * 64, 256)), dim3(256), 0, stream, x, s_xyz, ns, cin, flag, sxf);
+  }
   SPR_LAUNCH_CHECK();
 
   if (impl == 0 && n_kp == kKP && cin % 32 == 0 && cout % 32 == 0 && cout <= 256) {

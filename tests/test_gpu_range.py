@@ -203,11 +203,19 @@ def test_end_to_end_with_small_weights(device):
     model = model.to(device).eval()
     out = model({"src_xyz": [T(src).to(device)], "tgt_xyz": [T(tgt).to(device)]})
     ref = O.regtr_forward(cfg, sd, [src], [tgt])
-    err = float(np.linalg.norm(out["pose"][0].cpu().numpy() - ref["pose"][0].numpy()))
-    assert err < 1e-4, f"pose error with 0.01x weights: {err:.3e}"
+    # With weights this small the soft assignment is flat and the pose solve is the
+    # ill-conditioned step: float32 rounding alone moves the reference's own pose by ~1e-4
+    # (measured below against the same graph in float64).  The criterion is therefore "as close
+    # to the float64 result as the float32 reference is", with 1e-4 as the floor.
+    ref64 = O.regtr_forward(cfg, {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, [src], [tgt])
+    p64 = ref64["pose"][0].numpy()
+    noise = float(np.linalg.norm(ref["pose"][0].numpy().astype(np.float64) - p64))
+    err = float(np.linalg.norm(out["pose"][0].cpu().numpy().astype(np.float64) - p64))
+    assert err < max(1e-4, 3.0 * noise), f"pose error with 0.01x weights: {err:.3e} (float32 reference: {noise:.3e})"
     sf = out["src_feat"][0][0].cpu().numpy()
-    rf = ref["cond"][0][0].numpy().reshape(sf.shape)
-    assert np.abs(sf - rf).max() <= 1e-4 * max(np.abs(rf).max(), 1e-30)
+    rf = ref64["cond"][0][0].numpy().reshape(sf.shape)
+    rn = np.abs(ref["cond"][0][0].numpy().reshape(sf.shape) - rf).max()
+    assert np.abs(sf - rf).max() <= max(1e-4 * max(np.abs(rf).max(), 1e-30), 3.0 * rn)
 
 
 @pytest.mark.parametrize("shared", [True, False])
