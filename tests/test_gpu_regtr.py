@@ -292,3 +292,69 @@ def test_ransac_is_the_best_of_its_hypotheses(device):
     assert torch.equal(T1, poses[torch.argmin(scores)])
     gt = torch.cat([q, t[:, None]], 1).to(device)
     assert float((T1 - gt).norm()) < 0.1
+
+
+@pytest.mark.parametrize("tag", ["3dmatch", "kitti", "modelnet"])
+def test_encoder_features_match_reference(device, tag):
+    """Stage gate between the pyramid and the transformer: the un-projected KPFEncoder output
+    (qk_regtr_full.py:157-166) against the reference's own tensor."""
+    g = load_golden(f"regtr_{tag}_b2.npz")
+    B = int(g["B"])
+    pairs, sizes = pairs_for(tag, B)
+    src = [torch.from_numpy(pairs[b][0][:sizes[b][0]]).to(device) for b in range(B)]
+    tgt = [torch.from_numpy(pairs[b][1][:sizes[b][1]]).to(device) for b in range(B)]
+    model = RegTR(get_config(tag))
+    synthetic.fill_parameters(model, seed=int(g["seed"]))
+    model = model.to(device).eval()
+    with torch.no_grad():
+        meta = model.preprocessor(src + tgt)
+        feats0 = torch.ones((meta['points'][0].shape[0], 1), dtype=torch.float32, device=device)
+        feats_un, _ = model.kpf_encoder(feats0, meta)
+    ref = g["feats_un"]
+    assert feats_un.shape == ref.shape
+    assert np.abs(feats_un.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_a_pair_does_not_depend_on_identical_batch_mates(device):
+    """The reference makes a pair depend on its batch mates through the neighbour-matrix width
+    (batch-wide max count) and max_pool's zero shadow row.  Here two rounding-level dependences
+    come on top: the per-tensor operand scale of the split-fp16 products (max |x| over the packed
+    tensor, or a published upper bound of it) and the choice of kernel route by total size (e.g.
+    fewer than 256 tokens take the unfused in-projection).  All of them vanish when the batch
+    mates are copies of the pair and the batches are on the same routes: everything else --
+    tiling, per-cloud statistics, varlen attention, the grouped correlation GEMM, Sinkhorn --
+    must then give every copy BITWISE the same result, whatever the batch size."""
+    g, two, _ = _run("3dmatch", device, which=[0, 0])
+    _, three, _ = _run("3dmatch", device, which=[0, 0, 0])
+    for b in range(3):
+        assert torch.equal(two["pose"][0], three["pose"][b])
+        for key in ("src_feat", "tgt_feat", "src_overlap", "tgt_overlap"):
+            assert torch.equal(two[key][0], three[key][b])
+        assert torch.equal(two["ind_list"][0], three["ind_list"][b])
+    assert torch.equal(two["pose"][0], two["pose"][1])
+    # and the copy-free single run agrees to rounding (different routes: T < 256 tokens)
+    _, alone, _ = _run("3dmatch", device, which=[0])
+    assert float((alone["pose"][0] - two["pose"][0]).norm()) < 1e-5
+    sf, rf = alone["src_feat"][0], two["src_feat"][0]
+    assert float((sf - rf).abs().max()) <= 2e-5 * float(rf.abs().max())
+
+
+def test_return_attn_is_the_dual_softmax_of_the_conditioned_features(device):
+    """return_attn=True (qk_regtr_full.py:453-463): dense [1, N, M] matrices; their arg-max is the
+    match index the forward reports."""
+    g = load_golden("regtr_modelnet_b2.npz")
+    B = int(g["B"])
+    pairs, sizes = pairs_for("modelnet", B)
+    src = [torch.from_numpy(pairs[b][0][:sizes[b][0]]).to(device) for b in range(B)]
+    tgt = [torch.from_numpy(pairs[b][1][:sizes[b][1]]).to(device) for b in range(B)]
+    model = RegTR(get_config("modelnet"), return_attn=True)
+    synthetic.fill_parameters(model, seed=int(g["seed"]))
+    model = model.to(device).eval()
+    out = model({"src_xyz": src, "tgt_xyz": tgt})
+    for b in range(B):
+        fs, ft = out["src_feat"][b][0].double().cpu(), out["tgt_feat"][b][0].double().cpu()
+        corr = fs @ ft.t() / fs.shape[1] ** 0.5
+        ref = torch.softmax(corr, 0) * torch.softmax(corr, 1)
+        a = out["attn"][b]
+        assert a.shape == (1,) + tuple(ref.shape)
+        assert (a[0].double().cpu() - ref).abs().max() <= 5e-5 * ref.abs().max()   # logits of O(10) at fp32 rounding
