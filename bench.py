@@ -271,6 +271,21 @@ def main():
         extra["fp16_attention"] = leg(args.gemm_mode, 2, n_leg)
         ops.set_gemm_mode(args.gemm_mode)
         ops.set_attn_mode(args.attn_mode)
+        if args.streams <= 1:
+            # deployment setting: two concurrent forwards of B pairs each on two HIP streams
+            # (streams.StreamedForward) -- hides the host round trips of the pyramid build
+            runner2 = StreamedForward(model, n_streams=2, device=dev)
+            batch2 = {"src_xyz": batch["src_xyz"] + batch["src_xyz"], "tgt_xyz": batch["tgt_xyz"] + batch["tgt_xyz"]}
+
+            def step2():
+                with torch.no_grad():
+                    return runner2(batch2)
+            step2()
+            torch.cuda.synchronize()
+            t2 = sharding.timed_steps(step2, n_leg, dist=None, sync=torch.cuda.synchronize, device=dev)
+            extra["two_streams"] = dict(value=round(sharding.throughput(2 * B, n_leg, 1, t2), 3), unit="pairs/s",
+                                        ms_per_step=round(1e3 * t2 / n_leg, 3), steps=n_leg, streams=2,
+                                        pairs_per_step=2 * B)
 
     if rank != 0:
         if dist is not None:
@@ -306,6 +321,7 @@ def main():
         "roofline_attention": roofline_attn,
         "exact_f32": extra.get("exact_f32"),
         "fp16_attention": extra.get("fp16_attention"),
+        "two_streams": extra.get("two_streams"),
     }
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, args.points)
