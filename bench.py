@@ -35,6 +35,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F16_PEAK_TFS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 MFMA
+MFMA_F32_PEAK_TFS = 157.0   # exact-f32 MFMA (v_mfma_f32_32x32x2_f32)
 
 
 def parse():
@@ -167,6 +168,7 @@ def main():
     # ---- roofline of the dominant kernel (rank 0) -----------------------------
     roofline = None
     roofline_attn = None
+    attn_flops_per_call = None
     if rank == 0:
         cap = 256 * max(args.steps, 1)
         codes = (ctypes.c_int * cap)()
@@ -198,6 +200,7 @@ def main():
                 cross_f = sum(4.0 * d_model * lens[b] * lens[Bm + b] * 2 for b in range(Bm))
                 flops_fwd.append((self_f, cross_f))
             avg_flops = sum(sf + cf for sf, cf in flops_fwd) / (2.0 * len(flops_fwd))   # per call
+            attn_flops_per_call = avg_flops
             avg_ms_attn = sum(attn_ms) / len(attn_ms)
             tfs = avg_flops / (avg_ms_attn * 1e-3) / 1e12
             roofline_attn = dict(bound="mfma", achieved=round(tfs, 2), peak=MFMA_F16_PEAK_TFS, unit="TFLOP/s",
@@ -263,9 +266,22 @@ def main():
             ops.set_attn_mode(am)
             step()
             torch.cuda.synchronize()
+            L.spr_prof_enable(1)
             t = sharding.timed_steps(step, steps, dist=None, sync=torch.cuda.synchronize, device=dev)
-            return dict(value=round(sharding.throughput(B, steps, 1, t), 3), unit="pairs/s",
-                        ms_per_step=round(1e3 * t / steps, 3), steps=steps, gemm_mode=gm, attn_mode=am)
+            cap_ = 256 * steps
+            c_, q_, m_ = (ctypes.c_int * cap_)(), (ctypes.c_int * cap_)(), (ctypes.c_float * cap_)()
+            n_ = L.spr_prof_read(cap_, c_, q_, m_)
+            L.spr_prof_enable(0)
+            res = dict(value=round(sharding.throughput(B, steps, 1, t), 3), unit="pairs/s",
+                       ms_per_step=round(1e3 * t / steps, 3), steps=steps, gemm_mode=gm, attn_mode=am)
+            a_ms = [m_[i] for i in range(n_) if c_[i] == -1]
+            if a_ms and attn_flops_per_call:
+                avg = sum(a_ms) / len(a_ms)
+                tfs = attn_flops_per_call / (avg * 1e-3) / 1e12
+                peak = MFMA_F16_PEAK_TFS if am != 0 else MFMA_F32_PEAK_TFS
+                res["attention_core"] = dict(avg_launch_ms=round(avg, 5), launches=len(a_ms), achieved=round(tfs, 2),
+                                             peak=peak, unit="TFLOP/s", frac=round(tfs / peak, 5))
+            return res
         n_leg = max(1, min(args.steps, 4))
         extra["exact_f32"] = leg(0, 0, n_leg)
         extra["fp16_attention"] = leg(args.gemm_mode, 2, n_leg)
