@@ -349,7 +349,7 @@ __device__ __forceinline__ float half_swap_max(float x) {
 }
 
 // H3 = true: split-fp16 (hi + lo planes, 3 MFMAs per product); false: hi planes only.
-template <bool H3>
+template <bool H3, bool LAZY = false>
 __global__ __launch_bounds__(256) void k_attn_h3(
     const _Float16* __restrict__ qh_g, const _Float16* __restrict__ ql_g,
     const _Float16* __restrict__ kh_g, const _Float16* __restrict__ kl_g,
@@ -405,11 +405,19 @@ __global__ __launch_bounds__(256) void k_attn_h3(
   f32x16 o[2];
   float m_run[2] = {-INFINITY, -INFINITY};
   f32x2 psum2[2];   // per-lane partial row sums; the two half-waves are joined at the end
+  // LAZY: the softmax reference m_ref of the lane's two queries rides into the score MFMAs as
+  // their C operand (all 16 registers = 4 - m_ref: scores come out as s - m_ref + 4, ready for
+  // exp2), and is moved -- with the accumulator rescale -- only on the first tile and when a score
+  // would push a scaled probability out of fp16's range; see tile().
+  f32x16 negm[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     psum2[h] = (f32x2){0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[h][r] = 0.f;
+    for (int r = 0; r < 16; ++r) {
+      o[h][r] = 0.f;
+      negm[h][r] = 0.f;
+    }
   }
 
   // staging roles: K -- key row tid>>2, 16-byte chunk tid&3; V^T -- feature row
@@ -456,8 +464,12 @@ __global__ __launch_bounds__(256) void k_attn_h3(
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
+        if constexpr (LAZY) {
+          sacc[h][kk] = negm[h];
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[h][kk][r] = 0.f;
+          for (int r = 0; r < 16; ++r) sacc[h][kk][r] = 0.f;
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           if constexpr (H3) {
@@ -501,6 +513,64 @@ __global__ __launch_bounds__(256) void k_attn_h3(
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sacc[h][0][r], sacc[h][1][r]));
       mx = half_swap_max(mx);
+      if constexpr (LAZY) {
+        // sacc = s - m_ref + kLazyOff.  Recentre (first tile: always; later: some query of the wave
+        // has a score more than 2^(15.5 - kLazyOff) above its reference -- the scaled probability
+        // would leave fp16's range): delta moves every lane's reference to its current maximum, like
+        // the eager form does on every tile.  kLazyOff = 4 (the eager form uses 10): probabilities
+        // below 2^-18 of the row maximum go subnormal in the hi plane, an absolute error of
+        // 2^-29 of the maximum -- and a reference has 11.5 octaves of headroom before it must move.
+        constexpr float kLazyOff = 4.0f;
+        const bool first = kt == 0;
+        if (first || __builtin_amdgcn_ballot_w64(mx > 15.5f) != 0) {
+          const float delta = first ? mx - kLazyOff : fmaxf(mx - kLazyOff, 0.f);
+          const float corr = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);   // o, psum are 0 on the first tile
+          psum2[h] *= (f32x2){corr, corr};
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            o[h][r] *= corr;
+            negm[h][r] -= delta;
+            sacc[h][0][r] -= delta;
+            sacc[h][1][r] -= delta;
+          }
+        }
+        unsigned int ph_u[2][8], pl_u[2][8];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            f32x2 pv;
+            pv[0] = __builtin_amdgcn_exp2f(sacc[h][kk][r]);
+            pv[1] = __builtin_amdgcn_exp2f(sacc[h][kk][r + 1]);
+            psum2[h] += pv;
+            const unsigned int hi_u =
+                __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(pv[0], pv[1]));
+            ph_u[kk][r >> 1] = hi_u;
+            if constexpr (H3) {
+              unsigned int lo_u;
+              asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+                  "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                  : "=&v"(lo_u)
+                  : "v"(hi_u), "v"(pv[0]), "v"(pv[1]));
+              pl_u[kk][r >> 1] = lo_u;
+            }
+          }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const u32x4 pa = {ph_u[kk][4 * s], ph_u[kk][4 * s + 1], ph_u[kk][4 * s + 2], ph_u[kk][4 * s + 3]};
+            const h16x8 pbh = __builtin_bit_cast(h16x8, pa);
+            if constexpr (H3) {
+              const u32x4 pb = {pl_u[kk][4 * s], pl_u[kk][4 * s + 1], pl_u[kk][4 * s + 2], pl_u[kk][4 * s + 3]};
+              const h16x8 pbl = __builtin_bit_cast(h16x8, pb);
+              o[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[kk][s], pbl, o[h], 0, 0, 0);
+              o[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[kk][s], pbh, o[h], 0, 0, 0);
+            }
+            o[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[kk][s], pbh, o[h], 0, 0, 0);
+          }
+        continue;
+      }
       const float m_new = fmaxf(m_run[h], mx);
       const float corr = __builtin_amdgcn_exp2f(m_run[h] - m_new);   // first tile: exp2(-inf) = 0
       m_run[h] = m_new;
@@ -715,6 +785,18 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
                 int max_len_host, int nhead, float* out, int o_stride, int mode, hipStream_t stream) {
   dim3 grid(cdiv(max_len_host, QB2) * nhead * nseg);
   ProfScope prof(stream, -1, t);
+  // lazy softmax reference (k_attn_h3<*, true>) unless SPR_ATTN_LAZY=0 (A/B timing against the eager form)
+  static const bool lazy = [] { const char* e = getenv("SPR_ATTN_LAZY"); return e == nullptr || e[0] != '0'; }();
+  if (lazy) {
+    if (mode == 2)
+      hipLaunchKernelGGL((k_attn_h3<false, true>), grid, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
+                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+    else
+      hipLaunchKernelGGL((k_attn_h3<true, true>), grid, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
+                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+    SPR_LAUNCH_CHECK();
+    return 0;
+  }
   if (mode == 2)
     hipLaunchKernelGGL(k_attn_h3<false>, grid, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth, pl.vtl,
                        t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
