@@ -242,7 +242,7 @@ def main():
                 except Exception:
                     traffic, traffic_src = None, None
             cin, cout = best['code'] // 100000, best['code'] % 100000
-            roofline = dict(bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+            roofline = dict(code=best['code'], bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                             kernel=f"k_kpconv_mfma (fused KPConv gather) cin={cin} cout={cout}",
                             avg_launch_ms=round(avg_ms, 5), launches=best['count'],
@@ -287,6 +287,26 @@ def main():
         extra["fp16_attention"] = leg(args.gemm_mode, 2, n_leg)
         ops.set_gemm_mode(args.gemm_mode)
         ops.set_attn_mode(args.attn_mode)
+        if roofline is not None:
+            # the roofline kernel WITHOUT the index work of the pyramid running beside it (the
+            # product default builds the pyramid on a side stream, regtr.py): same launches, one stream
+            from superpoints_registration_amd.regtr import no_side_stream
+            code = int(roofline["code"])
+            with no_side_stream():
+                step()
+                torch.cuda.synchronize()
+                L.spr_prof_enable(1)
+                sharding.timed_steps(step, n_leg, dist=None, sync=torch.cuda.synchronize, device=dev)
+                cap_ = 256 * n_leg
+                c_, q_, m_ = (ctypes.c_int * cap_)(), (ctypes.c_int * cap_)(), (ctypes.c_float * cap_)()
+                n_ = L.spr_prof_read(cap_, c_, q_, m_)
+                L.spr_prof_enable(0)
+            iso = [m_[i] for i in range(n_) if c_[i] == code]
+            if iso:
+                avg = sum(iso) / len(iso)
+                gbs = roofline["alg_bytes_per_launch"] / (avg * 1e-3) / 1e9
+                roofline["single_stream"] = dict(avg_launch_ms=round(avg, 5), launches=len(iso), achieved=round(gbs, 2),
+                                                 frac=round(gbs / HBM_PEAK_GBS, 5))
         if args.streams <= 1:
             # deployment setting: two concurrent forwards of B pairs each on two HIP streams
             # (streams.StreamedForward) -- hides the host round trips of the pyramid build

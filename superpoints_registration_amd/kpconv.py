@@ -91,6 +91,7 @@ class KPFEncoder(nn.Module):
         if not increase_channel_when_downsample:
             raise NotImplementedError("constant-width pyramids are not used by RegTR")
         blocks, _, final_dim = plan_pyramid(config)
+        self._plans = blocks
         self.encoder_blocks = nn.ModuleList(
             block_decider(b.name, b.radius, b.in_dim, b.out_dim, b.level, config) for b in blocks)
         # skip taps: the input of every strided block, plus the final features
@@ -106,6 +107,25 @@ class KPFEncoder(nn.Module):
                 skip_x.append(x)
             x = block(x, batch)
         return x, skip_x
+
+    def forward_streamed(self, x, stream):
+        """forward() driven by Preprocessor.stream(): every block is launched as soon as its part
+        of the pyramid exists.  Same kernels, same operands -> bitwise the result of
+        forward(x, meta).  Returns (x, skip_x, meta)."""
+        plans = self._plans
+        skip_x, i, meta = [], 0, None
+        for meta, kind, level in stream:
+            while i < len(self.encoder_blocks):
+                bp = plans[i]
+                ready = bp.level < level or (bp.level == level and (kind == 'down' or not bp.down))
+                if not ready:
+                    break
+                if i in self.encoder_skips:
+                    skip_x.append(x)
+                x = self.encoder_blocks[i](x, meta)
+                i += 1
+        assert i == len(self.encoder_blocks), "pyramid ended before the encoder"
+        return x, skip_x, meta
 
 
 # --------------------------------------------------------------------------- #
@@ -188,6 +208,20 @@ class Preprocessor(nn.Module):
         self.index_dtype = index_dtype
 
     def forward(self, pts: List[torch.Tensor]):
+        meta = None
+        for meta, _, _ in self.stream(pts):
+            pass
+        return meta
+
+    def stream(self, pts: List[torch.Tensor]):
+        """Generator form of forward(): yields (meta, 'conv' | 'down', level) as soon as what an
+        encoder block of that kind needs is in `meta` -- 'conv': points / lengths / conv
+        neighbours of the level; 'down': pools (and upsamples) of the level plus the points and
+        lengths of the next one.  RegTR runs it on a side stream and launches the encoder blocks
+        between the yields (KPFEncoder.forward_streamed): the index work -- small, latency-bound
+        kernels and one device->host read per subsampling and per neighbour matrix -- then runs
+        beside the convolutions instead of in front of them.  Exhausting the generator leaves
+        `meta` exactly as forward() returns it."""
         cfg = self.cfg
         _, levels, _ = plan_pyramid(cfg)
         device = pts[0].device
@@ -206,11 +240,20 @@ class Preprocessor(nn.Module):
             meta['_i32'][(key, level)] = idx
             meta[key].append(idx)                 # converted to index_dtype on first read
 
+        def open_level(l, points, lens_host, cu):
+            meta['points'].append(points)
+            meta['stack_lengths'].append(torch.tensor(lens_host, dtype=torch.int32, device=device))
+            meta['_cu'][l] = cu
+            meta['_lens_host'].append(lens_host)
+
+        cu = ops.lengths_to_cu(lens_host, device)
+        open_level(0, points, lens_host, cu)
         for l, lv in enumerate(levels):
-            cu = ops.lengths_to_cu(lens_host, device)
             conv = pool = up = None
             if lv.has_conv:
                 conv, _ = ops.radius_neighbors(points, points, cu, cu, lv.radius, lv.limit)
+            publish('neighbors', l, conv)
+            yield meta, 'conv', l
             if lv.down:
                 dl = 2 * lv.radius / cfg.conv_radius          # kpconv.py:367
                 sub_points, sub_lens = ops.grid_subsample(points, cu, dl, order=self.order)
@@ -220,16 +263,12 @@ class Preprocessor(nn.Module):
                 if self.compute_upsamples:
                     up, _ = ops.radius_neighbors(points, sub_points, cu, sub_cu, 2 * lv.radius,
                                                  lv.limit)
-            meta['points'].append(points)
-            meta['stack_lengths'].append(torch.tensor(lens_host, dtype=torch.int32, device=device))
-            meta['_cu'][l] = cu
-            meta['_lens_host'].append(lens_host)
-            publish('neighbors', l, conv)
             publish('pools', l, pool)
             publish('upsamples', l, up)
             if lv.down:
-                points, lens_host = sub_points, sub_lens_host
-        return meta
+                points, lens_host, cu = sub_points, sub_lens_host, sub_cu
+                open_level(l + 1, points, lens_host, cu)
+            yield meta, 'down', l
 
 
 PreprocessorGPU = Preprocessor  # kpconv.py:421

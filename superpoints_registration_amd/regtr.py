@@ -18,6 +18,9 @@ Differences by design (documented in DESIGN.md):
     same parameter gradients as the reference's training_step (generic_reg_model.py:82-84);
     under torch.no_grad() the forward is the plain inference path.
 """
+import os
+import threading
+
 import torch
 import torch.nn as nn
 
@@ -40,6 +43,43 @@ class _BilinearW(nn.Module):
 _UNSUPPORTED_FLAGS = ('use_attn_affinity', 'use_corr_affinity')
 _REFINE_FLAGS = ('use_lgr', 'use_ransac', 'use_ratio_test', 'threshold_corr', 'remove_outliers_overlap',
                  'use_overlap_as_weights', 'remove_points_from_val')
+
+
+_SIDE_STREAM = os.environ.get("SPR_NO_SIDE_STREAM", "0") != "1"
+_side_streams = {}
+_tls = threading.local()
+
+
+class no_side_stream:
+    """Context manager: forwards issued inside it (by this thread) build the pyramid on the
+    caller's stream.  streams.StreamedForward uses it -- its group forwards already run beside
+    each other, and four streams oversubscribe the chip (707 vs 786 pairs/s)."""
+
+    def __enter__(self):
+        self._prev = getattr(_tls, 'off', False)
+        _tls.off = True
+
+    def __exit__(self, *exc):
+        _tls.off = self._prev
+
+
+def _side_stream_of(main, device):
+    """One side stream per (device, caller's stream): StreamedForward's threads each get their own."""
+    key = (device, main.cuda_stream)
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[key] = st
+    return st
+
+
+def _meta_tensors(meta):
+    for v in meta.values():
+        # list.__iter__: the index lists convert to int64 when iterated through their own __iter__
+        items = v.values() if isinstance(v, dict) else (list.__iter__(v) if isinstance(v, list) else ())
+        for t in items:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                yield t
 
 
 class RegTR(nn.Module):
@@ -88,17 +128,43 @@ class RegTR(nn.Module):
     def _forward(self, batch):
         cfg = self.cfg
         B = len(batch['src_xyz'])
-        with torch.no_grad():   # index work: never differentiated (qk_regtr_full.py:152)
-            meta = self.preprocessor(list(batch['src_xyz']) + list(batch['tgt_xyz']))
+        # Pyramid (index work, never differentiated: qk_regtr_full.py:152) and KPConv encoder on a
+        # column of ones (:157-166).  The pyramid is built on a SIDE stream and the blocks of a
+        # level are launched on the caller's stream as soon as their part exists: the searches of
+        # the deeper levels -- small latency-bound kernels, each followed by a device->host read of
+        # a size -- run beside the big convolutions of the shallower ones instead of in front of
+        # them (SPR_NO_SIDE_STREAM=1: one stream, pyramid first).
+        clouds = list(batch['src_xyz']) + list(batch['tgt_xyz'])
+        device = clouds[0].device
+        feats0 = torch.ones((sum(int(c.shape[0]) for c in clouds), 1), dtype=torch.float32, device=device)
+        if _SIDE_STREAM and device.type == 'cuda' and not getattr(_tls, 'off', False):
+            main = torch.cuda.current_stream(device)
+            side = _side_stream_of(main, device)
+            side.wait_stream(main)                       # the clouds were produced on the caller's stream
+
+            def pyramid():
+                gen = self.preprocessor.stream(clouds)
+                while True:
+                    with torch.no_grad(), torch.cuda.stream(side):
+                        try:
+                            item = next(gen)             # host blocks on the side stream's reads only
+                        except StopIteration:
+                            return
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                    main.wait_event(ev)
+                    yield item
+            feats_un, _, meta = self.kpf_encoder.forward_streamed(feats0, pyramid())
+            for t in _meta_tensors(meta):                # allocated on the side stream, read on this one
+                t.record_stream(main)
+        else:
+            with torch.no_grad():
+                meta = self.preprocessor(clouds)
+            feats_un, _ = self.kpf_encoder(feats0, meta)
         batch['kpconv_meta'] = meta                      # qk_regtr_full.py:153
         lens_c = meta['_lens_host'][-1]
         src_lens, tgt_lens = lens_c[:B], lens_c[B:]
         xyz_c = meta['points'][-1]
-        device = xyz_c.device
-
-        # KPConv encoder on a column of ones (qk_regtr_full.py:157-166)
-        feats0 = torch.ones((meta['points'][0].shape[0], 1), dtype=torch.float32, device=device)
-        feats_un, _ = self.kpf_encoder(feats0, meta)
         tokens = ops.linear(feats_un, self.feat_proj.weight, self.feat_proj.bias)
 
         # superpoint attention on packed tokens (qk_regtr_full.py:199-230)

@@ -62,7 +62,8 @@ class StreamedForward:
     def _one(self, i: int, sub: Dict, ready: torch.cuda.Event):
         torch.cuda.set_device(self.device)
         s = self.streams[i]
-        with torch.cuda.stream(s), torch.no_grad():
+        from .regtr import no_side_stream
+        with torch.cuda.stream(s), torch.no_grad(), no_side_stream():
             s.wait_event(ready)
             out = self.model(sub)
             done = torch.cuda.Event()

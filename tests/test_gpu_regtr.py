@@ -358,3 +358,23 @@ def test_return_attn_is_the_dual_softmax_of_the_conditioned_features(device):
         a = out["attn"][b]
         assert a.shape == (1,) + tuple(ref.shape)
         assert (a[0].double().cpu() - ref).abs().max() <= 5e-5 * ref.abs().max()   # logits of O(10) at fp32 rounding
+
+
+def test_side_stream_pyramid_is_bitwise_the_single_stream_forward(device):
+    """The default forward builds the pyramid on a side stream and launches the encoder blocks of
+    a level while the deeper levels are still being searched (regtr.py, Preprocessor.stream,
+    KPFEncoder.forward_streamed).  Same kernels on the same operands: every output must be
+    bitwise what the one-stream, pyramid-first forward gives -- three times in a row (races between
+    the two streams would show as run-to-run differences)."""
+    from superpoints_registration_amd.regtr import no_side_stream
+    with no_side_stream():
+        g, ref, bref = _run("3dmatch", device)
+    for _ in range(3):
+        _, out, b = _run("3dmatch", device)
+        assert torch.equal(ref["pose"], out["pose"])
+        for key in ("src_feat", "tgt_feat", "src_overlap", "tgt_overlap", "ind_list", "overlap_prob_list"):
+            for x, y in zip(ref[key], out[key]):
+                assert torch.equal(x, y)
+        for l in range(len(bref["kpconv_meta"]["points"])):
+            assert torch.equal(bref["kpconv_meta"]["points"][l], b["kpconv_meta"]["points"][l])
+            assert torch.equal(bref["kpconv_meta"]["neighbors"][l], b["kpconv_meta"]["neighbors"][l])
