@@ -88,6 +88,12 @@ class RegTR(nn.Module):
         super().__init__()
         self.cfg = cfg
         self.return_attn = return_attn
+        # True = the caller guarantees that the input clouds are materialised in device memory when
+        # forward() is called (not the product of work still queued on the current stream): the
+        # pyramid of this call may then start on the side stream while the previous call's
+        # transformer / matching tail is still running on the caller's stream.  Default False:
+        # the side stream first waits for everything queued on the caller's stream.
+        self.inputs_resident = False
         for flag in _UNSUPPORTED_FLAGS:
             if cfg.get(flag, False):
                 raise NotImplementedError(f"cfg.{flag}=True is not supported (use_attn_affinity raises "
@@ -140,7 +146,8 @@ class RegTR(nn.Module):
         if _SIDE_STREAM and device.type == 'cuda' and not getattr(_tls, 'off', False):
             main = torch.cuda.current_stream(device)
             side = _side_stream_of(main, device)
-            side.wait_stream(main)                       # the clouds were produced on the caller's stream
+            if not self.inputs_resident:
+                side.wait_stream(main)                   # the clouds were produced on the caller's stream
 
             def pyramid():
                 gen = self.preprocessor.stream(clouds)
