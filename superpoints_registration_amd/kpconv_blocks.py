@@ -15,7 +15,7 @@ import torch.nn as nn
 from torch.nn.init import kaiming_uniform_
 from torch.nn.parameter import Parameter
 
-from . import ops
+from . import _concurrency, ops
 from .kernel_points import load_kernels
 
 
@@ -264,18 +264,40 @@ class ResnetBottleneckBlock(nn.Module):
             neighb_inds = _idx_of(batch, 'neighbors', li)
             stack_lengths_post, cu_post, ml_post = batch['stack_lengths'][li], _cu_of(batch, li), ml_pre
 
+        def shortcut_branch():
+            sc = max_pool(features, neighb_inds) if 'strided' in self.block_name else features
+            if isinstance(self.unary_shortcut, UnaryBlock):
+                sc = self.unary_shortcut(sc, stack_lengths_post, cu=cu_post, max_len=ml_post)
+            return sc
+
+        # The shortcut branch (max-pool gather, projection, norm) depends on the block input only:
+        # in inference it runs on its own stream beside unary1 -> KPConv -> norm and joins at unary2.
+        has_work = 'strided' in self.block_name or isinstance(self.unary_shortcut, UnaryBlock)
+        fork = (has_work and features.is_cuda and not torch.is_grad_enabled()
+                and _concurrency.active(features.device))
+        if fork:
+            main = torch.cuda.current_stream(features.device)
+            branch = _concurrency.aux_stream(main, features.device, 'shortcut')
+            ready = torch.cuda.Event()
+            ready.record(main)                    # block input (and, transitively, the pyramid level) is ready
+            branch.wait_event(ready)
+            with torch.cuda.stream(branch):
+                shortcut = shortcut_branch()
+                joined = torch.cuda.Event()
+                joined.record(branch)
+            features.record_stream(branch)
+
         x = self.unary1(features, stack_lengths_pre, cu=cu_pre, max_len=ml_pre) \
             if isinstance(self.unary1, UnaryBlock) else features
         self.KPConv.rows_sorted = bool(batch.get('_rows_sorted', False))
         x = self.KPConv(q_pts, s_pts, neighb_inds, x)
         x = self.batch_norm_conv(x, stack_lengths_post, cu=cu_post, slope=0.1, max_len=ml_post)
 
-        if 'strided' in self.block_name:
-            shortcut = max_pool(features, neighb_inds)
+        if fork:
+            main.wait_event(joined)
+            shortcut.record_stream(main)
         else:
-            shortcut = features
-        if isinstance(self.unary_shortcut, UnaryBlock):
-            shortcut = self.unary_shortcut(shortcut, stack_lengths_post, cu=cu_post, max_len=ml_post)
+            shortcut = shortcut_branch()
         # unary2 (no relu) + shortcut, then LeakyReLU: fused into unary2's norm pass
         return self.unary2(x, stack_lengths_post, cu=cu_post, add=shortcut, final_slope=0.1,
                            max_len=ml_post)

@@ -19,12 +19,11 @@ Differences by design (documented in DESIGN.md):
     under torch.no_grad() the forward is the plain inference path.
 """
 import os
-import threading
 
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _concurrency, ops
 from .kpconv import KPFEncoder, Preprocessor
 from .transformers import (PositionEmbeddingCoordsSine, TransformerCrossEncoder,
                            TransformerCrossEncoderLayer, make_segments)
@@ -45,32 +44,7 @@ _REFINE_FLAGS = ('use_lgr', 'use_ransac', 'use_ratio_test', 'threshold_corr', 'r
                  'use_overlap_as_weights', 'remove_points_from_val')
 
 
-_SIDE_STREAM = os.environ.get("SPR_NO_SIDE_STREAM", "0") != "1"
-_side_streams = {}
-_tls = threading.local()
-
-
-class no_side_stream:
-    """Context manager: forwards issued inside it (by this thread) build the pyramid on the
-    caller's stream.  streams.StreamedForward uses it -- its group forwards already run beside
-    each other, and four streams oversubscribe the chip (707 vs 786 pairs/s)."""
-
-    def __enter__(self):
-        self._prev = getattr(_tls, 'off', False)
-        _tls.off = True
-
-    def __exit__(self, *exc):
-        _tls.off = self._prev
-
-
-def _side_stream_of(main, device):
-    """One side stream per (device, caller's stream): StreamedForward's threads each get their own."""
-    key = (device, main.cuda_stream)
-    st = _side_streams.get(key)
-    if st is None:
-        st = torch.cuda.Stream(device=device)
-        _side_streams[key] = st
-    return st
+from ._concurrency import no_side_stream   # noqa: F401  (re-exported: streams.py, tests, bench.py)
 
 
 def _meta_tensors(meta):
@@ -143,9 +117,9 @@ class RegTR(nn.Module):
         clouds = list(batch['src_xyz']) + list(batch['tgt_xyz'])
         device = clouds[0].device
         feats0 = torch.ones((sum(int(c.shape[0]) for c in clouds), 1), dtype=torch.float32, device=device)
-        if _SIDE_STREAM and device.type == 'cuda' and not getattr(_tls, 'off', False):
+        if _concurrency.active(device):
             main = torch.cuda.current_stream(device)
-            side = _side_stream_of(main, device)
+            side = _concurrency.aux_stream(main, device, 'pyramid')
             if not self.inputs_resident:
                 side.wait_stream(main)                   # the clouds were produced on the caller's stream
 
