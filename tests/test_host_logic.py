@@ -110,3 +110,11 @@ def test_load_kernels_reproduces_the_reference_kernel_points():
     conv = KPConv(15, 3, 32, 32, 0.1, 0.125)
     assert np.array_equal(conv.kernel_points.detach().numpy().view(np.uint32), gold["kp.c32.kpts"].view(np.uint32))
     assert not conv.kernel_points.requires_grad
+
+
+def test_graft_entry_build_checks_the_header_version():
+    """build() compares the library's version with include/spr.h (a literal there once broke the
+    driver's build check after an ABI bump)."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "__graft_entry__.py")).read()
+    assert "SPR_VERSION" in src and re.search(r"spr_version\(\)\s*==\s*\d", src) is None
