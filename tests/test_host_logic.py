@@ -1,4 +1,6 @@
 """CPU: host-side logic of the package (no kernels)."""
+import os
+
 import numpy as np
 import torch
 
