@@ -20,6 +20,7 @@ Differences by design (documented in DESIGN.md):
 """
 import os
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -200,18 +201,23 @@ class RegTR(nn.Module):
         src_ov = [o.unsqueeze(0) for o in split(overlap, src_lens, 0)]
         tgt_ov = [o.unsqueeze(0) for o in split(overlap, tgt_lens, n_src)]
         vals, inds, src_corr, tgt_corr = [], [], [], []
+        ind_l = ind.long()                               # one conversion / one gather for all pairs
+        matched_pts = None
+        if not cfg.use_sinkhorn and refined is None:
+            off, _, _, _ = self._match_index_arrays(cu_host, B, device)
+            matched_pts = xyz_c[ind_l + off]             # partner point of every token
         for b in range(B):
             N, M = src_lens[b], tgt_lens[b]
             if N > M:   # one match per tgt point (qk_regtr_full.py:455-479)
                 sl = slice(cu_host[B + b], cu_host[B + b + 1])
-                v, i = val[sl], ind[sl].long()
-                s_pts = src_kp[b] if cfg.use_sinkhorn else src_kp[b][i]
+                v, i = val[sl], ind_l[sl]
+                s_pts = src_kp[b] if matched_pts is None else matched_pts[sl]
                 t_pts = tgt_kp[b]
             else:       # one match per src point (:563-588)
                 sl = slice(cu_host[b], cu_host[b + 1])
-                v, i = val[sl], ind[sl].long()
+                v, i = val[sl], ind_l[sl]
                 s_pts = src_kp[b]
-                t_pts = tgt_kp[b] if cfg.use_sinkhorn else tgt_kp[b][i]
+                t_pts = tgt_kp[b] if matched_pts is None else matched_pts[sl]
             if refined is not None:
                 v, i, s_pts, t_pts = (refined[k][b] for k in ('val', 'ind', 'src_pts', 'tgt_pts'))
             vals.append(v)
@@ -358,31 +364,42 @@ class RegTR(nn.Module):
         score = ops.pose_scores(poses, src, tgt)
         return poses[torch.argmin(score)]          # first minimum, like the reference's strict '<'
 
+    @staticmethod
+    def _match_index_arrays(cu_host, B, device):
+        """Index bookkeeping of the arg-max matches for ALL pairs, built once on the host and
+        uploaded in one copy (the per-pair device ops it replaces were 3 tiny kernels per pair):
+          off   [T]  what turns a token's match index (local to the partner cloud) into a global
+                     token index: tgt start of the pair for src tokens, src start for tgt tokens;
+          own   [S]  the tokens that carry a pair's matches: the tgt tokens when N_b > M_b, else the
+                     src tokens (qk_regtr_full.py:455-479, :563-588);
+          on_tgt[S]  1 where `own` is a tgt token;   set_cu [B+1]  prefix of the per-pair counts."""
+        cu = np.asarray(cu_host, dtype=np.int64)
+        n = cu[1:B + 1] - cu[:B]
+        m = cu[B + 1:2 * B + 1] - cu[B:2 * B]
+        off = np.concatenate([np.repeat(cu[B:2 * B], n), np.repeat(cu[:B], m)])
+        on_tgt_pair = n > m
+        starts = np.where(on_tgt_pair, cu[B:2 * B], cu[:B])
+        counts = np.where(on_tgt_pair, m, n)
+        set_cu = np.concatenate([[0], np.cumsum(counts)])
+        own = np.repeat(starts - set_cu[:-1], counts) + np.arange(set_cu[-1])
+        flag = np.repeat(on_tgt_pair.astype(np.int64), counts)
+        packed = torch.from_numpy(np.concatenate([off, own, flag, set_cu])).to(device)
+        T, S = off.shape[0], own.shape[0]
+        return packed[:T], packed[T:T + S], packed[T + S:T + 2 * S].bool(), packed[T + 2 * S:].to(torch.int32)
+
     def _pose_from_matches(self, xyz_c, val, ind, cu, cu_host, B):
         """arg-max correspondences -> weighted Procrustes for all pairs in one
         launch.  For pair b the matched set lives on the tgt tokens when
         N_b > M_b and on the src tokens otherwise; build packed (a, b, w) by
         index arithmetic on the device."""
-        device = xyz_c.device
-        a_idx, b_idx, w_idx, set_cu = [], [], [], [0]
-        for b in range(B):
-            s0, s1 = cu_host[b], cu_host[b + 1]
-            t0, t1 = cu_host[B + b], cu_host[B + b + 1]
-            if (s1 - s0) > (t1 - t0):
-                own = torch.arange(t0, t1, device=device)
-                a_idx.append(ind[t0:t1].long() + s0)   # matched src point
-                b_idx.append(own)                      # tgt point itself
-            else:
-                own = torch.arange(s0, s1, device=device)
-                a_idx.append(own)
-                b_idx.append(ind[s0:s1].long() + t0)
-            w_idx.append(own)
-            set_cu.append(set_cu[-1] + own.numel())
-        a_idx, b_idx, w_idx = torch.cat(a_idx), torch.cat(b_idx), torch.cat(w_idx)
+        off, own, on_tgt, set_cu = self._match_index_arrays(cu_host, B, xyz_c.device)
+        matched = (ind.long() + off)[own]                  # global index of every match
+        a_idx = torch.where(on_tgt, matched, own)          # src side
+        b_idx = torch.where(on_tgt, own, matched)          # tgt side
         a = ops.gather_rows(xyz_c, a_idx.to(torch.int32))
         bb = ops.gather_rows(xyz_c, b_idx.to(torch.int32))
-        w = val[w_idx]
-        return ops.weighted_procrustes(a, bb, w, torch.tensor(set_cu, dtype=torch.int32, device=device))
+        w = val[own]
+        return ops.weighted_procrustes(a, bb, w, set_cu)
 
     @staticmethod
     def _dense_attn(fs, ft):

@@ -120,3 +120,25 @@ def test_graft_entry_build_checks_the_header_version():
     import re
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "__graft_entry__.py")).read()
     assert "SPR_VERSION" in src and re.search(r"spr_version\(\)\s*==\s*\d", src) is None
+
+
+def test_match_index_arrays_follow_the_per_pair_rule():
+    """regtr._match_index_arrays: the arg-max matches of a pair live on its tgt tokens when
+    N > M and on its src tokens otherwise (qk_regtr_full.py:455-479, :563-588); the arrays built in
+    one go must equal the per-pair construction."""
+    from superpoints_registration_amd.regtr import RegTR
+    B, n, m = 4, [5, 2, 4, 7], [3, 6, 4, 1]
+    cu = [0]
+    for v in n + m:
+        cu.append(cu[-1] + v)
+    off, own, flag, set_cu = RegTR._match_index_arrays(cu, B, torch.device("cpu"))
+    exp_off = [cu[B + b] for b in range(B) for _ in range(n[b])] + [cu[b] for b in range(B) for _ in range(m[b])]
+    exp_own, exp_flag, sc = [], [], [0]
+    for b in range(B):
+        on_tgt = n[b] > m[b]
+        r = list(range(cu[B + b], cu[B + b + 1])) if on_tgt else list(range(cu[b], cu[b + 1]))
+        exp_own += r
+        exp_flag += [int(on_tgt)] * len(r)
+        sc.append(sc[-1] + len(r))
+    assert off.tolist() == exp_off and own.tolist() == exp_own
+    assert flag.long().tolist() == exp_flag and set_cu.tolist() == sc
