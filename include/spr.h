@@ -182,12 +182,16 @@ int spr_layernorm_range_count(int m);
 int spr_layernorm_r(const float* x, int m, int c, const float* gamma, const float* beta,
                     float eps, const float* pos, float* out_norm, float* out_pos,
                     float* range_norm, float* range_pos, void* stream);
+/* w_prep (or NULL): the weight-side inputs of the fused in-projection -- spr_range_parts() partial
+ * maxima of |w_in| followed by its 3 d row L1 norms -- from spr_attn_inproj_prepare, measured once
+ * per weight version. */
+int spr_attn_inproj_prepare(const float* w_in, int d, float* out, void* stream);
 int spr_attn_inproj_varlen_fwd_r(const float* x_qk, const float* x_v, int t, const float* w_in,
                                  const float* b_in, const int* cu, const int* kv_seg, int nseg,
                                  int max_len_host, int nhead, int head_dim, float scale,
                                  float* out, int o_stride, const float* xqk_range,
                                  int xqk_range_n, const float* xv_range, int xv_range_n,
-                                 float* out_range, void* ws, size_t ws_bytes, void* stream);
+                                 float* out_range, const float* w_prep, void* ws, size_t ws_bytes, void* stream);
 
 /* Arithmetic of spr_linear (and of the correlation GEMMs inside the matching
  * head):

@@ -46,7 +46,8 @@ SIGNATURES = {
     "spr_layernorm_range_count": (_i, [_i]),
     "spr_layernorm_r": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spr_attn_inproj_varlen_fwd_r": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp,
-                                          _i, _vp, _vp, _sz, _vp]),
+                                          _i, _vp, _vp, _vp, _sz, _vp]),
+    "spr_attn_inproj_prepare": (_i, [_vp, _i, _vp, _vp]),
     "spr_set_gemm_mode": (_i, [_i]),
     "spr_layernorm": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "spr_posemb_sine": (_i, [_vp, _i, _i, _f, _f, _vp, _vp]),

@@ -859,15 +859,26 @@ extern "C" int spr_attn_inproj_varlen_fwd(const float* x_qk, const float* x_v, i
                                           int max_len_host, int nhead, int head_dim, float scale, float* out,
                                           int o_stride, void* ws, size_t ws_bytes, void* stream_) {
   return spr_attn_inproj_varlen_fwd_r(x_qk, x_v, t, w_in, b_in, cu, kv_seg, nseg, max_len_host, nhead, head_dim, scale,
-                                      out, o_stride, nullptr, 0, nullptr, 0, nullptr, ws, ws_bytes, stream_);
+                                      out, o_stride, nullptr, 0, nullptr, 0, nullptr, nullptr, ws, ws_bytes, stream_);
+}
+
+// Weight-side inputs of the fused in-projection, measured once per weight version:
+// out[0 .. spr_range_parts()) = max |w| partials, then 3 d row L1 norms of w_in [3d, d].
+extern "C" int spr_attn_inproj_prepare(const float* w_in, int d, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(w_in != nullptr && out != nullptr && d >= 1 && 3 * d <= 1024, "inproj_prepare: bad arguments");
+  if (int rc = launch_absmax(w_in, 3 * d, d, d, out, stream)) return rc;
+  hipLaunchKernelGGL(k_row_l1, dim3(cdiv((long)3 * d * 64, 256)), dim3(256), 0, stream, w_in, 3 * d, d, out + kAmaxParts);
+  SPR_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int spr_attn_inproj_varlen_fwd_r(const float* x_qk, const float* x_v, int t, const float* w_in,
                                             const float* b_in, const int* cu, const int* kv_seg, int nseg,
                                             int max_len_host, int nhead, int head_dim, float scale, float* out,
                                             int o_stride, const float* xqk_range, int xqk_range_n,
-                                            const float* xv_range, int xv_range_n, float* out_range, void* ws,
-                                            size_t ws_bytes, void* stream_) {
+                                            const float* xv_range, int xv_range_n, float* out_range,
+                                            const float* w_prep, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(head_dim == HD, "attention: head_dim must be %d (got %d)", HD, head_dim);
   SPR_REQUIRE(nhead * head_dim == 256, "attention in-projection: d_model must be 256 (got %d)", nhead * head_dim);
@@ -926,15 +937,22 @@ extern "C" int spr_attn_inproj_varlen_fwd_r(const float* x_qk, const float* x_v,
   // operand ranges: max|x| (inputs), max|w| (the projection's own operand scale) and the plane
   // multipliers from the bounds max|x| * max row-L1(W block) + max|bias block|
   // input ranges: published by the producer (LayerNorm) or measured here
+  // weight side (max |w| partials + row L1 norms): measured here, or once per weight version by
+  // the caller (spr_attn_inproj_prepare -> w_prep)
+  const float* wparts = w_prep != nullptr ? w_prep : sm.p1;
+  const float* rowl1 = w_prep != nullptr ? w_prep + kAmaxParts : sm.rowl1;
   const float* xqp = sm.p0;
   int n_xq = kAmaxParts;
   if (xqk_range != nullptr) {
     SPR_REQUIRE(xqk_range_n >= 1, "attention in-projection: xqk_range needs a count");
     xqp = xqk_range;
     n_xq = xqk_range_n;
-    if (int rc = launch_absmax(w_in, 3 * d, d, d, sm.p1, stream)) return rc;
-  } else {
+    if (w_prep == nullptr)
+      if (int rc = launch_absmax(w_in, 3 * d, d, d, sm.p1, stream)) return rc;
+  } else if (w_prep == nullptr) {
     if (int rc = launch_absmax2(x_qk, t, d, d, sm.p0, w_in, 3 * d, d, d, sm.p1, stream)) return rc;
+  } else {
+    if (int rc = launch_absmax(x_qk, t, d, d, sm.p0, stream)) return rc;
   }
   const float* xvp = xqp;
   int n_xv = n_xq;
@@ -949,15 +967,16 @@ extern "C" int spr_attn_inproj_varlen_fwd_r(const float* x_qk, const float* x_v,
       n_xv = kAmaxParts;
     }
   }
-  hipLaunchKernelGGL(k_row_l1, dim3(cdiv((long)3 * d * 64, 256)), dim3(256), 0, stream, w_in, 3 * d, d, sm.rowl1);
-  hipLaunchKernelGGL(k_plane_scales, dim3(1), dim3(256), 0, stream, xqp, xqp, xvp, sm.rowl1, b_in, d,
+  if (w_prep == nullptr)
+    hipLaunchKernelGGL(k_row_l1, dim3(cdiv((long)3 * d * 64, 256)), dim3(256), 0, stream, w_in, 3 * d, d, sm.rowl1);
+  hipLaunchKernelGGL(k_plane_scales, dim3(1), dim3(256), 0, stream, xqp, xqp, xvp, rowl1, b_in, d,
                      scale * 1.4426950408889634f, sm.scales, n_xq, n_xq, n_xv, out_range);
   hipLaunchKernelGGL(k_attn_zero_gaps, dim3(d), dim3(256), 0, stream, cu, nseg, (int)tp, pl.vth, pl.vtl);
   if (x_v == x_qk) {
-    if (int rc = launch_inproj_planes(x_qk, t, d, w_in, 3 * d, b_in, 0, pl, xqp, n_xq, sm.p1, stream)) return rc;
+    if (int rc = launch_inproj_planes(x_qk, t, d, w_in, 3 * d, b_in, 0, pl, xqp, n_xq, wparts, stream)) return rc;
   } else {
-    if (int rc = launch_inproj_planes(x_qk, t, d, w_in, 2 * d, b_in, 0, pl, xqp, n_xq, sm.p1, stream)) return rc;
-    if (int rc = launch_inproj_planes(x_v, t, d, w_in + (size_t)2 * d * d, d, b_in + 2 * d, 2 * d, pl, xvp, n_xv, sm.p1,
+    if (int rc = launch_inproj_planes(x_qk, t, d, w_in, 2 * d, b_in, 0, pl, xqp, n_xq, wparts, stream)) return rc;
+    if (int rc = launch_inproj_planes(x_v, t, d, w_in + (size_t)2 * d * d, d, b_in + 2 * d, 2 * d, pl, xvp, n_xv, wparts,
                                       stream))
       return rc;
   }

@@ -441,8 +441,26 @@ def attention_raw(q, k, v, cu, kv_seg, max_len: int, nhead: int, out=None) -> to
     return out
 
 
-def attention_inproj(x_qk, x_v, w_in, b_in, cu, kv_seg, max_len: int, nhead: int) -> torch.Tensor:
-    """In-projection (packed [3d, d] weight, q/k from x_qk, v from x_v) + attention core."""
+def inproj_prepare(w_in: torch.Tensor):
+    """Weight-side inputs of the fused in-projection (max |w| partials + row L1 norms), measured
+    once per weight version and cached on the tensor like _static_range."""
+    if not _HANDOVER:
+        return None
+    r = getattr(w_in, '_spr_inproj', None)
+    if r is not None and r[1] == w_in._version and r[2] == w_in.data_ptr() and r[3] == _range_epoch[0]:
+        return r[0]
+    L = _lib.lib()
+    d = w_in.shape[1]
+    buf = torch.empty((L.spr_range_parts() + 3 * d,), dtype=torch.float32, device=w_in.device)
+    _lib.check(L.spr_attn_inproj_prepare(_ptr(w_in), d, _ptr(buf), _stream(w_in)), "spr_attn_inproj_prepare")
+    w_in._spr_inproj = (buf, w_in._version, w_in.data_ptr(), _range_epoch[0])
+    return buf
+
+
+def attention_inproj(x_qk, x_v, w_in, b_in, cu, kv_seg, max_len: int, nhead: int, w_prep=None) -> torch.Tensor:
+    """In-projection (packed [3d, d] weight, q/k from x_qk, v from x_v) + attention core.
+    w_prep: inproj_prepare(weight) of the SAME weight (callers that hold the parameter object
+    pass it so that the measurement is cached across calls)."""
     x_qk = _dev(x_qk, "x_qk", torch.float32)
     x_v = x_qk if x_v is x_qk else _dev(x_v, "x_v", torch.float32)
     w_in = _dev(w_in, "w_in", torch.float32)
@@ -463,7 +481,8 @@ def attention_inproj(x_qk, x_v, w_in, b_in, cu, kv_seg, max_len: int, nhead: int
     _lib.check(L.spr_attn_inproj_varlen_fwd_r(_ptr(x_qk), _ptr(x_v), T, _ptr(w_in), _ptr(b_in), _ptr(cu),
                                               _ptr(kv_seg), nseg, int(max_len), nhead, hd, 1.0 / math.sqrt(hd),
                                               _ptr(out), out.stride(0), _ptr(qr), int(qn), _ptr(vr), int(vn),
-                                              _ptr(orng), _ptr(ws), ws.numel(), _stream(x_qk)),
+                                              _ptr(orng), _ptr(w_prep if fused else None), _ptr(ws), ws.numel(),
+                                              _stream(x_qk)),
                "spr_attn_inproj_varlen_fwd_r")
     if orng is not None:
         _set_range(out, orng, 1)

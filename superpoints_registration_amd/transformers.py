@@ -111,7 +111,8 @@ class TransformerCrossEncoderLayer(nn.Module):
         training = torch.is_grad_enabled() and (qk_in.requires_grad or W.requires_grad)
         if d == 256 and not training:
             # in-projection GEMM writes the attention operand planes directly (inference path)
-            o = ops.attention_inproj(qk_in, v_in, W.detach(), b.detach(), cu, kv_seg, max_len, self.nhead)
+            o = ops.attention_inproj(qk_in, v_in, W.detach(), b.detach(), cu, kv_seg, max_len, self.nhead,
+                                     w_prep=ops.inproj_prepare(W))   # cached on the parameter object
         else:
             if v_in is qk_in:
                 qkv = ops.linear(qk_in, W, b)                      # [T, 3d]
