@@ -435,6 +435,236 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Persistent form of k_gemm_nt_h3 for K = 256 whose output stores overlap the next tile's main loop.
+// A 256 x 256 tile of k_gemm_nt_h3 ends with 256 KB of stores that drain at the CU's share of the
+// HBM write rate (~11 us) with nothing else to do, and the next tile's operand loads queue behind
+// them in the CU's one vector-memory pipeline: main loop and epilogue ADD (70 + 54 us for the
+// [61 745 x 256] x [768 x 256] in-projection).  Here one workgroup per CU walks 128 x 256 tiles;
+// a finished tile stays in registers (64 accumulators per thread) while the next tile's K loop
+// runs into a second set, and its stores leave in sixteen "quarters" (4 accumulator registers of
+// one 32 x 32 block = 4 consecutive rows of the lane's column), two per K slab.  The counted
+// s_waitcnt of the slab prefetch leaves exactly those youngest stores outstanding (vector-memory
+// operations retire in issue order), so a wave never waits for its own stores; the first slab of
+// the NEXT tile is prefetched in the last iteration of the current one for the same reason.
+// K slabs are unrolled (8), which makes every quarter's registers static.
+template <int ACT>
+__global__ __launch_bounds__(512) void k_gemm_nt_h3p(
+    const float* __restrict__ X, int M, const float* __restrict__ Wt, int N,
+    const float* __restrict__ bias, float* __restrict__ out,
+    const float* __restrict__ a_parts, int n_aparts, const float* __restrict__ w_parts, int n_wparts,
+    float* __restrict__ out_parts, int ntiles) {
+  constexpr int K = 256, NSLAB = K / BK;
+  constexpr int BM = 128, BN = 256, WN = 4, NT = 512, TM = 2, TN = 2;
+  constexpr int A_PT = BM * BK / 4 / NT, B_PT = BN * BK / 4 / NT;   // 2, 4 float4 per thread and slab
+  constexpr int QPS = 16 / NSLAB;                                   // quarters leaving per slab: 2
+  extern __shared__ __align__(16) unsigned char gemm_smem[];
+  _Float16* Ah = reinterpret_cast<_Float16*>(gemm_smem);
+  _Float16* Al = Ah + BM * HS;
+  _Float16* Bh = Al + BM * HS;
+  _Float16* Bl = Bh + BN * HS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int gx = (N + BN - 1) / BN;
+
+  float sa, sb, unscale;
+  {
+    float* shf = reinterpret_cast<float*>(gemm_smem);
+    const int ka = pow2_exp_for(block_absmax(a_parts, shf, n_aparts));
+    const int kb = pow2_exp_for(block_absmax(w_parts, shf, n_wparts));
+    __syncthreads();
+    sa = pow2f(ka);
+    sb = pow2f(kb);
+    unscale = pow2f(-ka - kb);
+  }
+
+  f32x16 acc[TM][TN], prev[TM][TN];
+  f32x4 ra[A_PT], rb[B_PT];
+  auto load_slab = [&](int m0, int n0, int k0) {
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) {
+      const int f = tid + i * NT;
+      const int r = f / (BK / 4), c4 = f % (BK / 4);
+      const float* p = X + (size_t)min(m0 + r, M - 1) * K + k0 + c4 * 4;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[i]) : "v"(p));
+    }
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) {
+      const int f = tid + i * NT;
+      const int r = f / (BK / 4), c4 = f % (BK / 4);
+      const float* p = Wt + (size_t)min(n0 + r, N - 1) * K + k0 + c4 * 4;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[i]) : "v"(p));
+    }
+  };
+  auto split_store = [&](const f32x4& v, float sc, _Float16* hi, _Float16* lo) {
+    unsigned int h0, h1, l0, l1;
+    split_pk_s(v[0], v[1], sc, h0, l0);
+    split_pk_s(v[2], v[3], sc, h1, l1);
+    *reinterpret_cast<u32x2*>(hi) = (u32x2){h0, h1};
+    *reinterpret_cast<u32x2*>(lo) = (u32x2){l0, l1};
+  };
+  auto store_slab = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) {
+      const int f = tid + i * NT;
+      const int r = f / (BK / 4), c4 = f % (BK / 4);
+      split_store(ra[i], sa, Ah + r * HS + c4 * 4, Al + r * HS + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) {
+      const int f = tid + i * NT;
+      const int r = f / (BK / 4), c4 = f % (BK / 4);
+      split_store(rb[i], sb, Bh + r * HS + c4 * 4, Bl + r * HS + c4 * 4);
+    }
+  };
+
+  // deferred tile
+  bool have_prev = false;
+  int pm0 = 0, pn0 = 0, ptile = 0;
+  float pbias[TN] = {0.f, 0.f};
+  float pmax = 0.f;
+  // quarter Q of prev: block Q >> 2 = (row block Q >> 3, column block (Q >> 2) & 1), registers 4 (Q & 3) .. +3
+  auto emit = [&](auto qtag) {
+    constexpr int Q = decltype(qtag)::value;
+    constexpr int b = Q >> 2, g = Q & 3, bi = b >> 1, bj = b & 1;
+    const int row0 = pm0 + (wm * TM + bi) * 32 + 8 * g + 4 * lh;
+    const int col = pn0 + (wn * TN + bj) * 32 + l31;
+    if (col < N) {
+      float* p = out + (size_t)row0 * N + col;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float y = prev[bi][bj][4 * g + e] * unscale + pbias[bj];
+        if (ACT == SPR_ACT_RELU) y = fmaxf(y, 0.f);
+        if (ACT == SPR_ACT_SIGMOID) y = 1.f / (1.f + expf(-y));
+        if (row0 + e < M) {
+          asm volatile("global_store_dword %0, %1, off" ::"v"(p + (size_t)e * N), "v"(y) : "memory");
+          pmax = fmaxf(pmax, fabsf(y));
+        }
+      }
+    }
+  };
+  auto publish_prev_max = [&]() {   // all 512 threads, LDS not in use at the call sites
+    if (out_parts == nullptr) return;
+    float* shf = reinterpret_cast<float*>(gemm_smem);
+    const float t_ = wave_max(pmax);
+    __syncthreads();
+    if (lane == 0) shf[wave] = t_;
+    __syncthreads();
+    if (tid == 0) {
+      float m_ = shf[0];
+      for (int w_ = 1; w_ < 8; ++w_) m_ = fmaxf(m_, shf[w_]);
+      out_parts[ptile] = m_;
+    }
+    __syncthreads();
+    pmax = 0.f;
+  };
+
+  int t = blockIdx.x;
+  if (t < ntiles) {
+    const int lid = xcd_swizzle(t, ntiles);
+    load_slab((lid / gx) * BM, (lid % gx) * BN, 0);
+  }
+  bool young = false;   // the previous iteration issued its two quarters (8 stores) after the operand prefetch
+  for (; t < ntiles; t += gridDim.x) {
+    const int lid = xcd_swizzle(t, ntiles);
+    const int m0 = (lid / gx) * BM, n0 = (lid % gx) * BN;
+    const int tn = t + gridDim.x;
+    int nm0 = 0, nn0 = 0;
+    if (tn < ntiles) {
+      const int nl = xcd_swizzle(tn, ntiles);
+      nm0 = (nl / gx) * BM;
+      nn0 = (nl % gx) * BN;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto slab = [&](auto stag) {
+      constexpr int S = decltype(stag)::value;
+      // operand slab S was prefetched one iteration ago; the 8 stores issued after it may stay in flight
+      if (young) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      store_slab();
+      __syncthreads();
+      if (S + 1 < NSLAB) load_slab(m0, n0, (S + 1) * BK);
+      else if (tn < ntiles) load_slab(nm0, nn0, 0);      // first slab of the next tile
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        const int ko = 16 * ks + 8 * lh;
+        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = (wm * TM + i) * 32 + l31;
+          ah[i] = *reinterpret_cast<const f16x8*>(Ah + row * HS + ko);
+          al[i] = *reinterpret_cast<const f16x8*>(Al + row * HS + ko);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = (wn * TN + j) * 32 + l31;
+          bh[j] = *reinterpret_cast<const f16x8*>(Bh + row * HS + ko);
+          bl[j] = *reinterpret_cast<const f16x8*>(Bl + row * HS + ko);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      young = false;
+      if (have_prev) {
+        emit(std::integral_constant<int, QPS * S>{});
+        emit(std::integral_constant<int, QPS * S + 1>{});
+        young = true;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+    };
+    slab(std::integral_constant<int, 0>{});
+    slab(std::integral_constant<int, 1>{});
+    slab(std::integral_constant<int, 2>{});
+    slab(std::integral_constant<int, 3>{});
+    slab(std::integral_constant<int, 4>{});
+    slab(std::integral_constant<int, 5>{});
+    slab(std::integral_constant<int, 6>{});
+    slab(std::integral_constant<int, 7>{});
+    if (have_prev) publish_prev_max();
+    // this tile becomes the deferred one
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) prev[i][j] = acc[i][j];
+    pm0 = m0;
+    pn0 = n0;
+    ptile = t;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + l31;
+      pbias[j] = (bias && col < N) ? bias[col] : 0.f;
+    }
+    have_prev = true;
+  }
+  if (have_prev) {   // the last tile of this workgroup: nothing left to hide its stores behind
+    emit(std::integral_constant<int, 0>{});  emit(std::integral_constant<int, 1>{});
+    emit(std::integral_constant<int, 2>{});  emit(std::integral_constant<int, 3>{});
+    emit(std::integral_constant<int, 4>{});  emit(std::integral_constant<int, 5>{});
+    emit(std::integral_constant<int, 6>{});  emit(std::integral_constant<int, 7>{});
+    emit(std::integral_constant<int, 8>{});  emit(std::integral_constant<int, 9>{});
+    emit(std::integral_constant<int, 10>{}); emit(std::integral_constant<int, 11>{});
+    emit(std::integral_constant<int, 12>{}); emit(std::integral_constant<int, 13>{});
+    emit(std::integral_constant<int, 14>{}); emit(std::integral_constant<int, 15>{});
+    publish_prev_max();
+  }
+}
+
 static std::atomic<int> g_gemm_mode{1};   // 1 = split-fp16 (default), 0 = exact f32 MFMA
 
 // N small (overlap_predictor, N = 1): one wave per (row, n).
@@ -625,7 +855,22 @@ int launch_gemm(const float* x, int m, int k, const float* w, int n, const float
     SPR_REQUIRE(a_parts != nullptr && w_parts != nullptr, "linear: split-fp16 mode needs the absmax partials");
     // LDS bytes of a BM x BN tile's slab (hi + lo planes of both operands)
     auto lds = [](int bm, int bn) { return (size_t)(bm + bn) * spr::HS * 2 * sizeof(_Float16); };
-    if (n >= 256 && m >= 256) {
+    static const bool use_p = [] { const char* e = getenv("SPR_GEMM_PERSIST"); return e == nullptr || e[0] != '0'; }();
+    if (use_p && !RES && ACT <= SPR_ACT_SIGMOID && n >= 256 && k == 256 && m >= 1024 && m < 32768) {
+      // persistent 128x256 tiles (k_gemm_nt_h3p): for a few thousand rows the finer tiles fill the
+      // chip better (27 vs 43 us at 5 000 x 256 x 300); at 60 k rows both forms sit on the CU's
+      // vector-memory throughput and the 256x256 tiles move fewer operand bytes
+      auto kern = spr::k_gemm_nt_h3p<ACT>;
+      if (int rc = ensure_dyn_lds((const void*)kern, (int)lds(128, 256))) return rc;
+      const int ntiles = cdiv(n, 256) * cdiv(m, 128);
+      int grid = device_cu_count();
+      grid = grid < ntiles ? grid : ntiles;
+      if (grid >= 8) grid &= ~7;                       // whole XCD rounds: t and t + grid share an L2
+      float* op = (out_parts && ntiles <= out_cap) ? out_parts : nullptr;
+      if (op && out_n) *out_n = ntiles;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds(128, 256), stream, x, m, w, n, bias, out,
+                         a_parts, n_aparts, w_parts, n_wparts, op, ntiles);
+    } else if (n >= 256 && m >= 256) {
       // 256x256 tiles, 8 waves of 64x128: ~64 flop per operand byte fetched from
       // L2 (the 128-wide tiles below need 2-4x the L2 traffic and are bound by it)
       auto kern = spr::k_gemm_nt_h3<256, 256, 4, 2, ACT, RES>;
