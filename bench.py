@@ -53,6 +53,10 @@ def parse():
                          "stretch each other, so the per-kernel roofline leg is only meaningful at 1")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--config", default="3dmatch")
+    ap.add_argument("--generator", default="box", choices=["box", "lidar"],
+                    help="box: three faces of a 2 m box (--points per cloud, the headline workload); lidar: the "
+                         "KITTI-shaped 120 k-return scan of synthetic.make_lidar_pair, pre-voxelised at 0.3 m "
+                         "(BASELINE configs[3]; use with --config kitti)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-mode", type=int, default=1, help="1 = range-scaled split-fp16 MFMA (default), 0 = exact f32")
     ap.add_argument("--attn-mode", type=int, default=1,
@@ -149,7 +153,10 @@ def main():
     model.inputs_resident = not args.no_cross_step_overlap
 
     B = args.pairs_per_step
-    pairs = [synthetic.make_pair(args.points, seed=sd) for sd in sharding.pair_seeds(rank, B)]
+    if args.generator == "lidar":
+        pairs = [synthetic.make_lidar_pair(seed=sd)[:2] + (None,) for sd in sharding.pair_seeds(rank, B)]
+    else:
+        pairs = [synthetic.make_pair(args.points, seed=sd) for sd in sharding.pair_seeds(rank, B)]
     batch = {"src_xyz": [torch.from_numpy(p[0]).to(dev) for p in pairs],
              "tgt_xyz": [torch.from_numpy(p[1]).to(dev) for p in pairs]}
 
