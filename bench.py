@@ -365,6 +365,8 @@ def main():
                    "point_order": "canonical" if args.canonical_order else "reference",
                    "upsample_indices": not args.skip_upsamples,
                    "cross_step_overlap": not args.no_cross_step_overlap,
+                   "streams_inside_a_forward": ("1 (SPR_NO_SIDE_STREAM)" if os.environ.get("SPR_NO_SIDE_STREAM", "0") == "1"
+                                                else "3: main path, pyramid searches, ResNet shortcut branches"),
                    "parallelism": f"pairs sharded over {world} rank(s), no data-path collective; per rank "
                                   f"{max(1, args.streams)} concurrent forwards of {B // max(1, args.streams)} pairs"},
         "roofline": roofline,
