@@ -142,3 +142,38 @@ def test_match_index_arrays_follow_the_per_pair_rule():
         sc.append(sc[-1] + len(r))
     assert off.tolist() == exp_off and own.tolist() == exp_own
     assert flag.long().tolist() == exp_flag and set_cu.tolist() == sc
+
+
+def test_streamed_encoder_launches_every_block_as_soon_as_its_level_exists():
+    """KPFEncoder.forward_streamed: a non-strided block of level l runs right after ('conv', l), the
+    strided block that ends the level after ('down', l) -- never earlier, and in architecture order."""
+    from superpoints_registration_amd.kpconv import KPFEncoder, plan_pyramid
+    cfg = get_config("3dmatch")
+    enc = KPFEncoder(cfg, cfg.d_embed)
+    plans, levels, _ = plan_pyramid(cfg)
+    log = []
+
+    class Rec(torch.nn.Module):
+        def __init__(self, i):
+            super().__init__()
+            self.i = i
+
+        def forward(self, x, meta):
+            log.append(('block', self.i, meta['seen'][-1]))
+            return x
+    enc.encoder_blocks = torch.nn.ModuleList(Rec(i) for i in range(len(plans)))
+
+    def events():
+        meta = {'seen': []}
+        for l, lv in enumerate(levels):
+            meta['seen'].append(('conv', l))
+            yield meta, 'conv', l
+            meta['seen'].append(('down', l))
+            yield meta, 'down', l
+    x, skips, meta = enc.forward_streamed(torch.zeros(1), events())
+    assert [b[1] for b in log] == list(range(len(plans)))           # architecture order
+    for _, i, seen in log:
+        bp = plans[i]
+        want = ('down', bp.level) if bp.down else ('conv', bp.level)
+        assert seen == want, (i, seen, want)                         # launched at the first possible event
+    assert len(skips) == len(enc.encoder_skips)
