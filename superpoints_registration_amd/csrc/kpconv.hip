@@ -103,6 +103,16 @@ __global__ __launch_bounds__(256) void k_rowflag(const float* __restrict__ x, co
   }
 }
 
+// Shadow record (index ns) for the ring kernel: a support point far away from everything (influence
+// 0 on every kernel point) with flag 0; pad_word = ns, the index every padded slot of a staged
+// neighbour row reads.
+__global__ void k_kp_shadow(float4* __restrict__ sxf, int ns, int* __restrict__ pad_word) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    sxf[ns] = make_float4(-1.0e17f, -1.0e17f, -1.0e17f, __int_as_float(0));
+    pad_word[0] = ns;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Simple reference kernel (impl = 1, and the fallback for shapes the MFMA
 // path does not cover): one thread per (query, output channel).
@@ -629,18 +639,582 @@ int launch_mfma(const float* q_xyz, int nq, const float* s_xyz, int ns, const in
   return 0;
 }
 
+
+// ===========================================================================
+// Ring kernel (round 3): the same contraction with the neighbour gather taken
+// OFF the critical path.
+//
+// What the round-2 kernel lost: its
+// gathers were register loads, so a wave had at most two 16-neighbour items in
+// flight, each item walked the chain LDS index -> gather -> influence -> MFMA
+// serially, the [15 Cin, Cout] weights were re-streamed from L2 for every 32
+// queries (as many bytes as the gather itself) and nothing moved while the
+// tile's index rows were staged.  scripts/abl/kp_gather.hip measured what the
+// memory side can do on the bench's own index matrices: 43-45 GB/s per CU
+// (11 TB/s chip-wide) for 256-byte rows fetched by LDS-DMA, already with 16-32
+// KiB in flight per CU -- three to four times what that kernel drew.
+//
+// Structure (one persistent 8-wave workgroup per CU, tiles of TQ = 16 queries):
+//   * a tile descriptor table (k_kp_tiles, cached per neighbour matrix) gives
+//     wave w of tile t its two queries -- the 16 queries sorted by live item
+//     count and dealt serpentine (rank w and rank 15-w) so that the eight waves
+//     reach the tile barrier together -- and their item counts;
+//   * an ITEM is (query, block of 8 neighbours).  Its 8 feature rows and 8
+//     {x,y,z,flag} records arrive by global_load_lds_dwordx4 (per-lane source
+//     address = a row gather) in a per-wave LDS ring of NS items, issued NS-1
+//     items ahead and retired with COUNTED s_waitcnt vmcnt: no VGPR staging, the
+//     loads of the next tile's first items fly during phase 2 and the barriers.
+//     The wave's two index rows for tile t+1 come the same way, two tiles ahead;
+//   * phase 1 per item: 2 k-steps of v_mfma_f32_16x16x4_f32 exactly as before
+//     (lane (kernel point, neighbour) computes one influence = the A layout; the B
+//     operand is a ds_read of the gathered row), shadow neighbours carry a
+//     far-away record (influence 0) instead of a select;
+//   * phase 2: the [16 x 15 Cin] weighted-feature tile (split fp16 in LDS) times W,
+//     with W held in REGISTERS for the whole launch (15 Cin Cout fp16 hi/lo =
+//     61-245 KB over 8 waves x <=120 VGPRs: wave = (16-channel group, k-slice)):
+//     nothing is streamed, so a 16-query tile costs no more weight traffic than a
+//     64-query one; the k-slices are summed through LDS in a fixed order.
+//   Two raw s_barriers per tile (wf complete / wf free); outputs are bitwise
+//   independent of the tile walk and of the ring depth.
+// Covers Cin in {32, 64} with Cin * Cout <= 4096 (the 32->32 and 64->64 layers:
+// every KPConv of levels 0 and 1); other shapes keep k_kpconv_mfma.
+constexpr int kRingTQ = 16;
+
+// Tile descriptors: one wave per tile of 16 queries (in `order` if given).  Entry [tile][w] =
+// {query A, query B, items A, items B} for wave w (-1 / 0 beyond nq).  An item = 8 neighbour
+// slots; rows_sorted: live items = ceil(valid / 8) (>= 1), else every slot block.
+__global__ __launch_bounds__(256) void k_kp_tiles(const int* __restrict__ nbr, int nq, int ns, int nbr_stride,
+                                                  int kmax, int rows_sorted, const int* __restrict__ order,
+                                                  int ntiles, int4* __restrict__ desc) {
+  const int tile = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (tile >= ntiles) return;
+  int my_q = -1, my_c = 0;
+  for (int r = 0; r < kRingTQ; ++r) {
+    const int pos = tile * kRingTQ + r;
+    int q = -1, c = 0;
+    if (pos < nq) {
+      q = order ? order[pos] : pos;
+      if (rows_sorted) {
+        int v = 0;
+        for (int k0 = 0; k0 < kmax; k0 += 64) {
+          const int k = k0 + lane;
+          const int id = k < kmax ? nbr[(size_t)q * nbr_stride + k] : ns;
+          v += __popcll(__ballot(id >= 0 && id < ns));
+        }
+        c = max(1, (v + 7) >> 3);
+      } else {
+        c = (kmax + 7) >> 3;
+      }
+    }
+    if (lane == r) { my_q = q; my_c = c; }
+  }
+  // rank by (items descending, position ascending) among the 16 entries
+  int rank = 0;
+  for (int j = 0; j < kRingTQ; ++j) {
+    const int cj = __shfl(my_c, j, 64);
+    rank += (cj > my_c || (cj == my_c && j < lane)) ? 1 : 0;
+  }
+  if (lane < kRingTQ) {
+    int* d = reinterpret_cast<int*>(desc + (size_t)tile * 8);
+    const int w = rank < 8 ? rank : 15 - rank, second = rank < 8 ? 0 : 1;
+    d[w * 4 + second] = my_q;
+    d[w * 4 + 2 + second] = my_c;
+  }
+}
+
+// LDS-DMA: 16 bytes per active lane from base + off (per-lane byte offset) to LDS at dst_s + 16 * lane.
+// The wait in front orders the write behind every ds_read this wave has issued (the slot being refilled).
+__device__ __forceinline__ void ring_dma16(const void* base, unsigned off, unsigned dst_s) {
+  unsigned keep;
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep) : "v"(off), "s"(base), "s"(dst_s) : "memory");
+}
+__device__ __forceinline__ void ring_dma16_nw(const void* base, unsigned off, unsigned dst_s) {   // no LDS wait
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep) : "v"(off), "s"(base), "s"(dst_s) : "memory");
+}
+// m0 is not preserved (declared as a clobber: the compiler keeps nothing in it across the statement)
+__device__ __forceinline__ void ring_dma16_m0(const void* base, unsigned off, unsigned dst_s) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               : : "v"(off), "s"(base), "s"(dst_s) : "memory", "m0");
+}
+// lanes 0..7 only (8 records of 16 bytes -> dst_s .. dst_s + 128); exec is restored inside the statement
+__device__ __forceinline__ void ring_dma16_rec8(const void* base, unsigned off, unsigned dst_s) {
+  unsigned long long keep;
+  asm volatile(
+      "s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xff\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
+      : "=&s"(keep) : "v"(off), "s"(base), "s"(dst_s) : "memory", "m0");
+}
+__device__ __forceinline__ void ring_dma4(const void* base, unsigned off, unsigned dst_s) {
+  unsigned keep;
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+      "global_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep) : "v"(off), "s"(base), "s"(dst_s) : "memory");
+}
+__device__ __forceinline__ void wait_vm_any(int n) {   // n is wave uniform
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+template <int CC, int COUT, int NS>
+struct RingShape {
+  static constexpr int NTC = CC / 16;                 // phase-1 n-tiles
+  static constexpr int KW = kKP * CC;                 // phase-2 K
+  static constexpr int SH = KW + 16;                  // wf row stride (halves): conflict-free ds_read_b128
+  static constexpr int KS = KW / 32;                  // 32-deep k-steps
+  static constexpr int NG = COUT / 16;                // 16-channel output groups
+  static constexpr int SPLIT = 8 / NG;                // k-slices (waves per group)
+  static constexpr int KSW = (KS + SPLIT - 1) / SPLIT;  // k-steps per wave (the last slice may hold fewer)
+  static constexpr int RB = CC * 4;                   // feature row bytes
+  static constexpr int LPR = RB / 16;                 // lanes per row in a 1-KiB piece
+  static constexpr int RPP = 64 / LPR;                // rows per piece
+  static constexpr int PPI = 8 / RPP;                 // row pieces per item
+  static constexpr int DPI = PPI + 1;                 // DMA instructions per item (+ the record piece)
+  static constexpr int SLOT = 8 * RB + 128;           // ring slot bytes: 8 rows + 8 records
+  static constexpr int WF_BYTES = 2 * kRingTQ * SH * 2;
+  static constexpr int RED_BYTES = NG * (SPLIT - 1) * 4 * 64 * 4;
+  static constexpr int RING_BYTES = 8 * NS * SLOT;
+  static constexpr int SMALL_BYTES = 2 * kRingTQ * 4 * 2;   // lcnt[2][16], lqid[2][16]
+  static_assert(NG * SPLIT == 8 && NS >= 3, "shape");
+  static size_t lds_bytes(int idxw) {                 // idxw: ints per staged index row (64 or 128)
+    return (size_t)WF_BYTES + RED_BYTES + RING_BYTES + SMALL_BYTES + (size_t)8 * 2 * 2 * idxw * 4;
+  }
+};
+
+#ifdef SPR_KP_RING_PROF
+// Experiment builds only (make EXTRA=-DSPR_KP_RING_PROF): per-phase shader-clock totals summed over
+// all waves.  0 phase-1 total, 1 of which waiting for the ring, 2 issue, 3 stage + prime, 4 barrier 1,
+// 5 phase 2, 6 barrier 2, 7 epilogue, 8 items, 9 tiles
+__device__ unsigned long long g_kp_prof[16];
+#define KP_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define KP_ACC(slot, a, b) prof_acc[slot] += (b) - (a)
+#else
+#define KP_STAMP(v)
+#define KP_ACC(slot, a, b)
+#endif
+
+template <int CC, int COUT, int NS>
+__global__ __launch_bounds__(512) void k_kpconv_ring(
+    const float* __restrict__ q_xyz, int ns, const int* __restrict__ nbr, int nbr_stride, int kmax,
+    const float* __restrict__ x, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl,
+    const float* __restrict__ kpts, float inv_extent, const float4* __restrict__ sxf,
+    const int4* __restrict__ desc, int ntiles, const int* __restrict__ pad_word, int idxw,
+    const float* __restrict__ x_parts, const float* __restrict__ w_parts, int n_xparts, int n_wparts,
+    float* __restrict__ out) {
+  typedef RingShape<CC, COUT, NS> S;
+  constexpr int NTC = S::NTC, SH = S::SH, KS = S::KS, NG = S::NG, SPLIT = S::SPLIT, KSW = S::KSW;
+  constexpr int RB = S::RB, LPR = S::LPR, RPP = S::RPP, PPI = S::PPI, DPI = S::DPI, SLOT = S::SLOT;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  _Float16* wfh = (_Float16*)lds_raw;                                   // [16][SH] hi
+  _Float16* wfl = wfh + kRingTQ * SH;                                   // [16][SH] lo
+  float* red = (float*)(lds_raw + S::WF_BYTES);                         // [NG][SPLIT-1][4][64]
+  unsigned char* ring_all = lds_raw + S::WF_BYTES + S::RED_BYTES;       // [8][NS][SLOT]
+  int* lcnt = (int*)(ring_all + S::RING_BYTES);                         // [2][16]
+  int* lqid = lcnt + 2 * kRingTQ;                                       // [2][16]
+  int* idx_all = lqid + 2 * kRingTQ;                                    // [8][2 parity][2 queries][idxw]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p16 = lane & 15, j4 = lane >> 4;
+  unsigned char* ring = ring_all + wave * (NS * SLOT);
+  int* idxbuf = idx_all + wave * (4 * idxw);
+  const unsigned ring_s = (unsigned)(uintptr_t)ring;
+  const unsigned idx_s = (unsigned)(uintptr_t)idxbuf;
+
+  // kernel point of this lane; lane 15 of each 16 is padding: parked far away -> influence 0
+  float kx = 1.0e18f, ky = 1.0e18f, kz = 1.0e18f;
+  if (p16 < kKP) {
+    kx = kpts[3 * p16];
+    ky = kpts[3 * p16 + 1];
+    kz = kpts[3 * p16 + 2];
+  }
+  float sa, unscale;
+  {
+    float* shf = reinterpret_cast<float*>(lds_raw);
+    const int ka = pow2_exp_for(block_absmax(x_parts, shf, n_xparts) * (float)kmax);
+    const int kb = pow2_exp_for(block_absmax(w_parts, shf, n_wparts));
+    __syncthreads();
+    sa = pow2f(ka);
+    unscale = pow2f(-ka - kb);
+  }
+
+  // phase-2 role and the wave's slice of W, resident in registers for the whole launch
+  const int ng = wave % NG, sp = wave / NG;
+  const int ks0 = sp * KSW;
+  kh8 bh[KSW], bl[KSW];
+#pragma unroll
+  for (int k = 0; k < KSW; ++k) {
+    const int ks = ks0 + k;
+    if (ks < KS) {
+      const size_t o = ((size_t)ng * KS + ks) * 512 + lane * 8;
+      bh[k] = *reinterpret_cast<const kh8*>(Wh + o);
+      bl[k] = *reinterpret_cast<const kh8*>(Wl + o);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { bh[k][e] = (_Float16)0.f; bl[k][e] = (_Float16)0.f; }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // everything the compiler issued so far has landed
+
+  // ---- per-wave item stream ------------------------------------------------------------------
+  // Index rows of a tile, staged by LDS-DMA into idxbuf[par]: query A's row at int 0, query B's row
+  // right behind A's LIVE blocks (int 8 * items(A)), so that item j of the wave's stream finds its 8
+  // neighbour ids at int 8 j whichever query it belongs to.  Lanes beyond kmax read a word holding
+  // ns (= shadow).  A's DMA is issued first and lands first (loads return in order).
+  const int idxb = 2 * idxw;                                   // ints per (wave, parity)
+  auto stage_idx = [&](const int4 d, int par) {
+#pragma unroll
+    for (int sel = 0; sel < 2; ++sel) {
+      const int q = sel ? d.y : d.x;
+      for (int h = 0; h < idxw; h += 64) {
+        const int k = h + lane;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(idx_s + (par * idxb + (sel ? 8 * d.z : 0) + h) * 4);
+        // two masked instructions, each with a uniform base; both write dst + 4 * lane
+        if (q >= 0 && k < kmax) ring_dma4(nbr, (unsigned)(((size_t)q * nbr_stride + k) * 4), dst);
+        else ring_dma4(pad_word, 0u, dst);
+      }
+    }
+  };
+  // The gathers of an item in two steps, so that the LDS reads of the neighbour ids are never on the
+  // issue path: load_ids(item) one stage ahead, issue_ids(slot, ids) when the slot is free.
+  struct Ids { unsigned row[PPI]; unsigned rec; };
+  const unsigned a_idr = (lane / LPR) * 4, a_idc = (lane & 7) * 4;      // per-lane byte offsets inside an item's ids
+  auto load_ids = [&](int par, int j) -> Ids {
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(idxbuf) + (par * idxb + 8 * j) * 4;
+    Ids r;
+#pragma unroll
+    for (int pc = 0; pc < PPI; ++pc) r.row[pc] = *reinterpret_cast<const unsigned*>(base + a_idr + pc * RPP * 4);
+    r.rec = *reinterpret_cast<const unsigned*>(base + a_idc);
+    return r;
+  };
+  // No LDS wait in front of these DMAs: a slot is refilled only after the item that lived in it has
+  // been moved to registers and its first influence computed, and the LDS retires a wave's reads in
+  // order, hundreds of cycles before a DMA can return.
+  const unsigned a_dma = (lane % LPR) * 16;
+  auto issue_ids = [&](unsigned slot_off, const Ids& ids) {
+#ifdef SPR_KP_ABL_NODMA
+    return;
+#endif
+    const unsigned slot = __builtin_amdgcn_readfirstlane(ring_s + slot_off);
+#pragma unroll
+    for (int pc = 0; pc < PPI; ++pc) {
+      const unsigned rid = min(ids.row[pc], (unsigned)(ns - 1));   // shadow slots fetch a real (finite) row
+      ring_dma16_m0(x, rid * RB + a_dma, slot + pc * 1024);
+    }
+    ring_dma16_rec8(sxf, min(ids.rec, (unsigned)ns) * 16, slot + 8 * RB);   // record ns = the shadow record
+  };
+  // first min(NS, n) items of a tile: all ids first, then all gathers
+  auto prime = [&](const int4 d, int par) {
+    const int n = d.z + d.w;
+    Ids ids[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) ids[i] = load_ids(par, i);
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+      if (i < n) issue_ids(i * SLOT, ids[i]);
+  };
+
+  int4 d_cur = make_int4(-1, -1, 0, 0), d_nxt = make_int4(-1, -1, 0, 0);
+  int tile = blockIdx.x;
+  if (tile < ntiles) d_cur = desc[(size_t)tile * 8 + wave];
+  if (tile + (int)gridDim.x < ntiles) d_nxt = desc[(size_t)(tile + gridDim.x) * 8 + wave];
+  if (tile < ntiles) {
+    stage_idx(d_cur, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tile + (int)gridDim.x < ntiles) stage_idx(d_nxt, 1);
+    prime(d_cur, 0);
+  }
+
+#ifdef SPR_KP_RING_PROF
+  unsigned long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  typedef typename VecF<NTC>::type vec_t;
+  struct KStep { float4 rec; vec_t xv; };
+  // operands of k-step s2 (neighbours 4 s2 + j4) of the item in the slot at byte offset slot_off
+  const unsigned a_rec = 8 * RB + j4 * 16, a_xv = j4 * RB + p16 * (NTC * 4);
+  auto ld_kstep = [&](unsigned slot_off, int s2) -> KStep {
+    KStep k;
+    k.rec = *reinterpret_cast<const float4*>(ring + slot_off + a_rec + s2 * 64);
+    k.xv = *reinterpret_cast<const vec_t*>(ring + slot_off + a_xv + s2 * 4 * RB);
+    return k;
+  };
+  int par = 0;
+  for (; tile < ntiles; tile += gridDim.x, par ^= 1) {
+    const int4 d = d_cur;
+    KP_STAMP(t_p1);
+    const int n_items = d.z + d.w;
+    // descriptor two tiles ahead (scalar load; its index rows are staged at the end of this phase 1)
+    int4 d_nn = make_int4(-1, -1, 0, 0);
+    const bool has_nxt = tile + (int)gridDim.x < ntiles, has_nn = tile + 2 * (int)gridDim.x < ntiles;
+    if (has_nn) d_nn = desc[(size_t)(tile + 2 * gridDim.x) * 8 + wave];
+
+    // ------------------------------ phase 1 --------------------------------
+    // coordinates of the wave's two queries (scalar loads, issued here so that none sits in the item loop)
+    float qax = 0.f, qay = 0.f, qaz = 0.f, qbx = 0.f, qby = 0.f, qbz = 0.f;
+    if (d.x >= 0) { qax = q_xyz[3 * (size_t)d.x]; qay = q_xyz[3 * (size_t)d.x + 1]; qaz = q_xyz[3 * (size_t)d.x + 2]; }
+    if (d.y >= 0) { qbx = q_xyz[3 * (size_t)d.y]; qby = q_xyz[3 * (size_t)d.y + 1]; qbz = q_xyz[3 * (size_t)d.y + 2]; }
+    // Pipeline at k-step granularity with FIXED register roles: R0 / R1 hold the operands of k-step
+    // 0 / 1 of the current item; each is reloaded from the next item's slot right after its MFMAs
+    // have been issued, so an LDS read has a whole k-step of work in front of its first use, no
+    // register set is ever copied, and the gathers of items i + 2 .. i + NS - 1 stay in flight.
+    auto wait_item = [&](int i) {   // item i has landed: at most the younger items may be outstanding
+      const int younger = n_items - 1 - i;
+      if (younger >= NS - 2) wait_vm_any(DPI * (NS - 2));
+      else wait_vm_any(DPI * max(younger, 0));
+    };
+    KStep R0, R1;
+    if (n_items == 0) {
+      wait_vm_any(0);
+    } else {
+      wait_item(0);
+      R0 = ld_kstep(0, 0);
+      R1 = ld_kstep(0, 1);
+    }
+    Ids ids_next = load_ids(par, NS);
+    int i = 0;
+    unsigned slot_off = 0;
+#pragma unroll 1
+    for (int sel = 0; sel < 2; ++sel) {
+      const int n_q = sel ? d.w : d.z;
+      if (n_q == 0) continue;
+      const float qx = sel ? qbx : qax, qy = sel ? qby : qay, qz = sel ? qbz : qaz;
+      f32x4 acc1[NTC];
+#pragma unroll
+      for (int t = 0; t < NTC; ++t) acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      int cnt = 0;
+#pragma unroll 1
+      for (int b = 0; b < n_q; ++b) {
+        const unsigned nslot = slot_off + SLOT == NS * SLOT ? 0u : slot_off + SLOT;
+        {   // k-step 0
+          const float dx = (R0.rec.x - qx) - kx, dy = (R0.rec.y - qy) - ky, dz = (R0.rec.z - qz) - kz;
+          const float w = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
+          cnt += __float_as_int(R0.rec.w);
+#ifndef SPR_KP_ABL_NOMFMA1
+#pragma unroll
+          for (int t = 0; t < NTC; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, R0.xv[t], acc1[t], 0, 0, 0);
+#else
+#pragma unroll
+          for (int t = 0; t < NTC; ++t) acc1[t][0] += w * R0.xv[t];
+#endif
+        }
+        wait_item(i + 1);                   // (the last item of the tile: everything has landed)
+        R0 = ld_kstep(nslot, 0);
+        if (i + NS < n_items) issue_ids(slot_off, ids_next);   // refill the slot item i lived in
+        {   // k-step 1
+          const float dx = (R1.rec.x - qx) - kx, dy = (R1.rec.y - qy) - ky, dz = (R1.rec.z - qz) - kz;
+          const float w = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
+          cnt += __float_as_int(R1.rec.w);
+#ifndef SPR_KP_ABL_NOMFMA1
+#pragma unroll
+          for (int t = 0; t < NTC; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, R1.xv[t], acc1[t], 0, 0, 0);
+#else
+#pragma unroll
+          for (int t = 0; t < NTC; ++t) acc1[t][0] += w * R1.xv[t];
+#endif
+        }
+        R1 = ld_kstep(nslot, 1);
+        ids_next = load_ids(par, i + NS + 1);   // (past the tile's last item: unused ints of the buffer)
+        slot_off = nslot;
+        ++i;
+      }
+      // the query's weighted features -> wf row ql (split fp16), its neighbour count and id
+      {
+        const int ql = sel ? 15 - wave : wave;
+        // C/D layout: row (kernel point) = 4*j4 + r, col = p16 <-> channels NTC*p16 + t
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = 4 * j4 + r;
+          typedef typename VecH<NTC>::type hv_t;
+          hv_t hh, ll;
+          if constexpr (NTC == 2) {
+            unsigned int hu, lu;
+            split_pk_s(acc1[0][r], acc1[1][r], sa, hu, lu);
+            hh = __builtin_bit_cast(hv_t, hu);
+            ll = __builtin_bit_cast(hv_t, lu);
+          } else {
+            typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+            unsigned int h0, l0, h1, l1;
+            split_pk_s(acc1[0][r], acc1[1][r], sa, h0, l0);
+            split_pk_s(acc1[2][r], acc1[3][r], sa, h1, l1);
+            hh = __builtin_bit_cast(hv_t, (u2_t){h0, h1});
+            ll = __builtin_bit_cast(hv_t, (u2_t){l0, l1});
+          }
+          if (p < kKP) {
+            *reinterpret_cast<hv_t*>(wfh + ql * SH + p * CC + NTC * p16) = hh;
+            *reinterpret_cast<hv_t*>(wfl + ql * SH + p * CC + NTC * p16) = ll;
+          }
+        }
+        int c = cnt;   // every lane of a 16-group saw the same records: one count per j4
+        c += __shfl_xor(c, 16, 64);
+        c += __shfl_xor(c, 32, 64);
+        if (lane == 0) {
+          lcnt[par * kRingTQ + ql] = c;
+          lqid[par * kRingTQ + ql] = sel ? d.y : d.x;
+        }
+      }
+    }
+    KP_STAMP(t_p1e);
+    KP_ACC(0, t_p1, t_p1e);
+    // rows of this tile that hold no query (tail tile): mark them so that the epilogue skips them
+    if (lane == 0) {
+      if (d.x < 0) lqid[par * kRingTQ + wave] = -1;
+      if (d.y < 0) lqid[par * kRingTQ + 15 - wave] = -1;
+    }
+    // everything issued so far has landed (the last item waited for vmcnt(0)): the index rows of the
+    // next tile are in LDS.  Stage those of the tile after it, then prime the ring with the next tile's
+    // first items: they fly during phase 2, the barriers and the epilogue.
+    if (has_nn) stage_idx(d_nn, par);
+    if (has_nxt) prime(d_nxt, par ^ 1);
+    KP_STAMP(t_pr);
+    KP_ACC(3, t_p1e, t_pr);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // B1: the wf tile is complete
+    KP_STAMP(t_b1);
+    KP_ACC(4, t_pr, t_b1);
+
+    // ------------------------------ phase 2 --------------------------------
+    f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+    {
+      const _Float16* ah_row = wfh + p16 * SH + 8 * j4;
+      const _Float16* al_row = wfl + p16 * SH + 8 * j4;
+#ifdef SPR_KP_ABL_NOP2
+      if (ntiles < 0)
+#endif
+#pragma unroll
+      for (int k = 0; k < KSW; ++k) {
+        const int ks = min(ks0 + k, KS - 1);            // a slice short of KSW steps meets zero weights
+        const kh8 ah = *reinterpret_cast<const kh8*>(ah_row + 32 * ks);
+        const kh8 al = *reinterpret_cast<const kh8*>(al_row + 32 * ks);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[k], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[k], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[k], acc2, 0, 0, 0);
+      }
+    }
+    if (sp > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((ng * (SPLIT - 1) + sp - 1) * 4 + r) * 64 + lane] = acc2[r];
+    }
+    KP_STAMP(t_p2);
+    KP_ACC(5, t_b1, t_p2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // B2: wf free again, partial sums visible
+    KP_STAMP(t_b2);
+    KP_ACC(6, t_p2, t_b2);
+    if (sp == 0) {
+#pragma unroll
+      for (int s2 = 1; s2 < SPLIT; ++s2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc2[r] += red[((ng * (SPLIT - 1) + s2 - 1) * 4 + r) * 64 + lane];
+      // C layout: row (query of the tile) = 4*j4 + r, col = p16
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = 4 * j4 + r;
+        const int n = lqid[par * kRingTQ + ql];
+        if (n >= 0) {
+          const float inv = unscale / (float)max(lcnt[par * kRingTQ + ql], 1);   // unscale: exact power of two
+          out[(size_t)n * COUT + ng * 16 + p16] = acc2[r] * inv;
+        }
+      }
+    }
+    KP_STAMP(t_ep);
+    KP_ACC(7, t_b2, t_ep);
+#ifdef SPR_KP_RING_PROF
+    prof_acc[8] += n_items;
+    prof_acc[9] += 1;
+#endif
+    d_cur = d_nxt;
+    d_nxt = d_nn;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef SPR_KP_RING_PROF
+  if (lane == 0)
+    for (int k = 0; k < 10; ++k) atomicAdd(&g_kp_prof[k], prof_acc[k]);
+#endif
+}
+
+template <int CC, int COUT, int NS>
+int launch_ring(const float* q_xyz, int nq, int ns, const int* nbr, int nbr_stride, int kmax, const float* x,
+                const _Float16* Wh, const _Float16* Wl, const float* kpts, float inv_extent, const float4* sxf,
+                const int4* desc, const int* pad_word, const float* x_parts, const float* w_parts, int n_xparts,
+                int n_wparts, float* out, hipStream_t stream) {
+  typedef RingShape<CC, COUT, NS> S;
+  const int idxw = kmax <= 64 ? 64 : 128;
+  const size_t lds = S::lds_bytes(idxw);
+  auto kern = k_kpconv_ring<CC, COUT, NS>;
+  ProfScope prof(stream, CC * 100000 + COUT, nq);
+  if (lds > 64 * 1024)
+    if (int rc = ensure_dyn_lds((const void*)kern, 160 * 1024)) return rc;
+  const int ntiles = cdiv(nq, kRingTQ);
+  const int n_cu = device_cu_count();
+  const int grid = ntiles < n_cu ? ntiles : n_cu;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, q_xyz, ns, nbr, nbr_stride, kmax, x, Wh, Wl, kpts,
+                     inv_extent, sxf, desc, ntiles, pad_word, idxw, x_parts, w_parts, n_xparts, n_wparts, out);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace
 }  // namespace spr
 
 using namespace spr;
 
+#ifdef SPR_KP_RING_PROF
+extern "C" int spr_debug_kp_prof(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_kp_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_kp_prof), z, sizeof(z)) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
+
 extern "C" size_t spr_kpconv_workspace_bytes(int nq, int ns, int cin, int cout) {
-  (void)nq;
   // flag bytes + {x,y,z,flag} support records + pre-split fragment-order weights (hi, lo fp16; up to
   // 32 kernel points)
   const size_t n = (size_t)(ns > 0 ? ns : 1);
-  return align_up(n, 256) + align_up(16 * n, 256) + 2 * align_up((size_t)32 * cin * cout * 2, 256) +
-         2 * align_up(kAmaxParts * sizeof(float), 256) + 256;
+  const size_t tiles = (size_t)cdiv(nq > 0 ? nq : 1, kRingTQ);
+  return align_up(n, 256) + align_up(16 * (n + 1), 256) + 2 * align_up((size_t)32 * cin * cout * 2, 256) +
+         2 * align_up(kAmaxParts * sizeof(float), 256) + align_up(tiles * 8 * sizeof(int4), 256) + 256 + 256;
 }
 
 extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, int ns,
@@ -670,10 +1244,12 @@ extern "C" int spr_kpconv_fwd_r(const float* q_xyz, int nq, const float* s_xyz, 
   SPR_REQUIRE(ws_bytes >= spr_kpconv_workspace_bytes(nq, ns, cin, cout), "kpconv: workspace too small");
   unsigned char* flag = (unsigned char*)ws;
   float4* sxf = (float4*)((char*)ws + align_up((size_t)ns, 256));
-  _Float16* wh = (_Float16*)((char*)sxf + align_up((size_t)ns * 16, 256));
+  _Float16* wh = (_Float16*)((char*)sxf + align_up(((size_t)ns + 1) * 16, 256));
   _Float16* wl = (_Float16*)((char*)wh + align_up((size_t)32 * cin * cout * 2, 256));
   float* x_parts = (float*)((char*)wl + align_up((size_t)32 * cin * cout * 2, 256));
   float* w_parts = x_parts + align_up(kAmaxParts * sizeof(float), 256) / sizeof(float);
+  int4* desc = (int4*)((char*)w_parts + align_up(kAmaxParts * sizeof(float), 256));
+  int* pad_word = (int*)((char*)desc + align_up((size_t)cdiv(nq, kRingTQ) * 8 * sizeof(int4), 256));
   const float inv_extent = 1.0f / kp_extent;
 
   if (cin == 1 && impl == 0 && n_kp <= 16) {
@@ -692,7 +1268,7 @@ extern "C" int spr_kpconv_fwd_r(const float* q_xyz, int nq, const float* s_xyz, 
   }
   SPR_LAUNCH_CHECK();
 
-  if (impl == 0 && n_kp == kKP && cin % 32 == 0 && cout % 32 == 0 && cout <= 256) {
+  if ((impl == 0 || impl == 2) && n_kp == kKP && cin % 32 == 0 && cout % 32 == 0 && cout <= 256) {
     const int ktot = n_kp * cin;
     const float* xp = x_range != nullptr ? x_range : x_parts;
     const float* wp = w_range != nullptr ? w_range : w_parts;
@@ -706,6 +1282,28 @@ extern "C" int spr_kpconv_fwd_r(const float* q_xyz, int nq, const float* s_xyz, 
     }
     hipLaunchKernelGGL(k_w_prep, dim3(cdiv((long)ktot * cout, 256)), dim3(256), 0, stream, weights, cin, cout,
                        cin % 64 == 0 ? 64 : 32, wp, n_wp, wh, wl);
+    // ring kernel: 32- / 64-channel inputs whose whole weight matrix fits the register file
+    const bool ring_ok = impl == 0 && (cin == 32 || cin == 64) && cin * cout <= 4096 && cout % 16 == 0 &&
+                         8 % (cout / 16) == 0 && kmax <= 128 && (size_t)ns * cin * 4 < (1ull << 32) &&
+                         (size_t)nq * nbr_stride * 4 < (1ull << 32);
+    if (ring_ok) {
+      const int ntiles = cdiv(nq, kRingTQ);
+      hipLaunchKernelGGL(k_kp_shadow, dim3(1), dim3(64), 0, stream, sxf, ns, pad_word);
+      hipLaunchKernelGGL(k_kp_tiles, dim3(cdiv((long)ntiles * 64, 256)), dim3(256), 0, stream, nbr, nq, ns,
+                         nbr_stride, kmax, rows_sorted, (const int*)nullptr, ntiles, desc);
+      SPR_LAUNCH_CHECK();
+#define SPR_RING_ARGS                                                                                       \
+  q_xyz, nq, ns, nbr, nbr_stride, kmax, x, wh, wl, kernel_points, inv_extent, sxf, desc, pad_word, xp, wp, \
+      n_xp, n_wp, out, stream
+      if (cin == 64 && cout == 64) return launch_ring<64, 64, 4>(SPR_RING_ARGS);
+      if (cin == 64 && cout == 32) return launch_ring<64, 32, 4>(SPR_RING_ARGS);
+      if (cin == 64 && cout == 16) return launch_ring<64, 16, 4>(SPR_RING_ARGS);
+      if (cin == 32 && cout == 32) return launch_ring<32, 32, 8>(SPR_RING_ARGS);
+      if (cin == 32 && cout == 64) return launch_ring<32, 64, 8>(SPR_RING_ARGS);
+      if (cin == 32 && cout == 128) return launch_ring<32, 128, 8>(SPR_RING_ARGS);
+      if (cin == 32 && cout == 16) return launch_ring<32, 16, 8>(SPR_RING_ARGS);
+#undef SPR_RING_ARGS
+    }
 #define SPR_KP_ARGS                                                                         \
   q_xyz, nq, s_xyz, ns, nbr, nbr_stride, kmax, rows_sorted, x, cin, wh, wl, cout,           \
       kernel_points, inv_extent, sxf, xp, wp, n_xp, n_wp, out, stream

@@ -54,9 +54,9 @@ def invalidate_ranges() -> None:
     _range_epoch[0] += 1
 
 
-def _set_range(t: torch.Tensor, parts: torch.Tensor, n: int) -> None:
-    if n > 0:
-        t._spr_range = (parts, int(n), t._version, t.data_ptr(), _range_epoch[0])
+def _set_range(t: torch.Tensor, parts: torch.Tensor, n: int, guard=None) -> None:
+    if n > 0:     # ONE attribute store: a reader on another thread sees the range and its guard together
+        t._spr_range = (parts, int(n), t._version, t.data_ptr(), _range_epoch[0], guard)
 
 
 _HANDOVER = os.environ.get("SPR_NO_RANGE_HANDOVER", "0") != "1"   # experiment switch (A/B timing)
@@ -68,6 +68,8 @@ def _get_range(t):
     r = getattr(t, '_spr_range', None)
     if r is None or r[2] != t._version or r[3] != t.data_ptr() or r[4] != _range_epoch[0]:
         return None, 0
+    if r[5] is not None:
+        r[5].acquire()
     return r[0], r[1]
 
 _RANGE_CAP = 4096   # partials a GEMM may publish (one per workgroup)
@@ -88,6 +90,28 @@ def _zero_slots(n: int, device) -> torch.Tensor:
     return out
 
 
+class _StreamGuard:
+    """Ordering of a cached, weight-side measurement against consumers on OTHER streams.  The
+    measuring kernel runs on the stream of the thread that first needed it; the cache lives on the
+    shared Parameter, and StreamedForward threads / the side streams of one forward read it from
+    their own streams.  The producing stream records an event behind the measurement; the first
+    consumer on any other stream waits for it (and registers the buffer with its stream)."""
+
+    def __init__(self, buf: torch.Tensor):
+        self.stream = torch.cuda.current_stream(buf.device)
+        self.event = torch.cuda.Event()
+        self.event.record(self.stream)
+        self.buf = buf
+        self.seen = {self.stream.cuda_stream}
+
+    def acquire(self):
+        cur = torch.cuda.current_stream(self.buf.device)
+        if cur.cuda_stream not in self.seen:
+            cur.wait_event(self.event)
+            self.buf.record_stream(cur)
+            self.seen.add(cur.cuda_stream)
+
+
 def _static_range(w: torch.Tensor):
     """Range partials of a tensor that rarely changes (weights): measured once per (storage,
     version) with spr_absmax and kept on the tensor like a published range -- an optimizer step
@@ -103,7 +127,7 @@ def _static_range(w: torch.Tensor):
     parts = torch.empty((n,), dtype=torch.float32, device=w.device)
     _lib.check(L.spr_absmax(_ptr(flat), flat.shape[0], flat.shape[1], flat.shape[1], _ptr(parts), _stream(w)),
                "spr_absmax")
-    _set_range(w, parts, n)
+    _set_range(w, parts, n, _StreamGuard(parts))
     return parts, n
 
 
@@ -448,12 +472,13 @@ def inproj_prepare(w_in: torch.Tensor):
         return None
     r = getattr(w_in, '_spr_inproj', None)
     if r is not None and r[1] == w_in._version and r[2] == w_in.data_ptr() and r[3] == _range_epoch[0]:
+        r[4].acquire()
         return r[0]
     L = _lib.lib()
     d = w_in.shape[1]
     buf = torch.empty((L.spr_range_parts() + 3 * d,), dtype=torch.float32, device=w_in.device)
     _lib.check(L.spr_attn_inproj_prepare(_ptr(w_in), d, _ptr(buf), _stream(w_in)), "spr_attn_inproj_prepare")
-    w_in._spr_inproj = (buf, w_in._version, w_in.data_ptr(), _range_epoch[0])
+    w_in._spr_inproj = (buf, w_in._version, w_in.data_ptr(), _range_epoch[0], _StreamGuard(buf))
     return buf
 
 

@@ -56,11 +56,17 @@ class GradientSync:
     (loss-only or frozen tensors never fire), whose buckets are simply launched from finish().
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, bucket_bytes: int = 16 << 20):
+    def __init__(self, params, process_group=None, bucket_bytes: int = 16 << 20):
+        """params: an nn.Module or an iterable of parameters.  The collective runs whenever a
+        process group is initialised -- also for a one-rank group, so that a single-GPU box
+        exercises the same RCCL path the N-GPU job takes."""
         import torch.distributed as dist
         self.dist = dist
         self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if self.active else 1
+        if isinstance(params, torch.nn.Module):
+            params = params.parameters()
         self.params = [p for p in params if p.requires_grad]
         self.buckets: List[torch.Tensor] = []
         self._slot = {}                      # param -> (bucket index, offset)
@@ -78,6 +84,8 @@ class GradientSync:
         self._expected: Optional[List[set]] = None      # learned on the first step
         self._fired: List[set] = [set() for _ in self.buckets]
         self._handles: Dict[int, object] = {}
+        self._late: List[torch.nn.Parameter] = []       # fired after their bucket had left
+        self.n_reduced = 0                              # collectives issued by the last finish()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def _close(self, entries, members, elems):
@@ -90,42 +98,85 @@ class GradientSync:
             self._slot[p] = (bi, off)
             p.grad = flat[off:off + p.numel()].view_as(p)
 
+    def _view(self, p):
+        bi, off = self._slot[p]
+        return self.buckets[bi][off:off + p.numel()].view_as(p)
+
     # -- step protocol ------------------------------------------------------------------------
     def zero_grad(self):
-        """Replaces optimizer.zero_grad(): keeps the gradients as bucket views."""
+        """Replaces optimizer.zero_grad(): zeroes the buckets and (re-)points the gradients of the
+        parameters that take part at their bucket views.  Parameters known never to receive a
+        gradient keep grad = None, as they do without GradientSync (AdamW then skips them)."""
         for b in self.buckets:
             b.zero_()
         for p in self.params:
-            bi, off = self._slot[p]
-            want = self.buckets[bi][off:off + p.numel()].view_as(p)
+            bi, _ = self._slot[p]
+            if self._expected is not None and p not in self._expected[bi]:
+                p.grad = None
+                continue
+            want = self._view(p)
             if p.grad is None or p.grad.data_ptr() != want.data_ptr():
                 p.grad = want
         self._fired = [set() for _ in self.buckets]
         self._handles = {}
+        self._late = []
 
     def _launch(self, bi):
-        if bi in self._handles or self.world == 1:
+        if bi in self._handles or not self.active:
             return
         self._handles[bi] = self.dist.all_reduce(self.buckets[bi], op=self.dist.ReduceOp.SUM, group=self.group,
                                                  async_op=True)
 
     def _on_grad(self, p):
         bi, _ = self._slot[p]
+        want = self._view(p)
+        if p.grad is not None and p.grad.data_ptr() != want.data_ptr():
+            # the caller used optimizer.zero_grad(set_to_none=True) (or the parameter was thought
+            # unused): autograd then assigned a fresh tensor outside the buckets
+            if bi in self._handles:
+                self._late.append(p)        # the bucket is already on the wire: reduced on its own in finish()
+                return
+            want.copy_(p.grad)
+            p.grad = want
+        elif bi in self._handles:
+            raise RuntimeError("GradientSync: a gradient was accumulated into a bucket whose all-reduce had "
+                               "already been launched (call sync.zero_grad() before every backward)")
         self._fired[bi].add(p)
         if self._expected is not None and self._fired[bi] >= self._expected[bi]:
             self._launch(bi)
 
     def finish(self):
-        """Call after backward(): launches what the hooks could not, waits, turns sums into means."""
+        """Call after backward() on EVERY rank (also when the loss carried no gradient: the
+        collectives must match across ranks): launches what the hooks could not, waits, turns sums
+        into means, and drops the zero gradients of parameters that did not take part."""
         if self._expected is None:
             self._expected = [set(f) for f in self._fired]
         for bi in range(len(self.buckets)):
             self._launch(bi)
         for bi, h in self._handles.items():
             h.wait()
+        for p in self._late:                 # same set on every rank (decided by the config, not the data)
+            if self.active:
+                self.dist.all_reduce(p.grad, op=self.dist.ReduceOp.SUM, group=self.group)
+            want = self._view(p)
+            want.copy_(p.grad)
+            p.grad = want
+            bi, _ = self._slot[p]
+            self._expected[bi].add(p)
+            self._fired[bi].add(p)
         if self.world > 1:
             for b in self.buckets:
                 b.div_(self.world)
+        for p in self.params:
+            bi, _ = self._slot[p]
+            if p not in self._fired[bi] and p.grad is not None and p.grad.data_ptr() == self._view(p).data_ptr():
+                p.grad = None
+        # ready for the next backward even if the caller resets gradients with optimizer.zero_grad()
+        # instead of sync.zero_grad()
+        self.n_reduced = len(self._handles) + len(self._late)
+        self._fired = [set() for _ in self.buckets]
+        self._handles = {}
+        self._late = []
 
     def close(self):
         for h in self._hooks:
@@ -291,10 +342,12 @@ class Trainer:
                 self.sync.zero_grad()
             else:
                 self.optimizer.zero_grad()
-            if 'total' in losses and losses['total'].requires_grad:
+            has_grad = 'total' in losses and losses['total'].requires_grad
+            if has_grad:
                 losses['total'].backward()
-                if self.sync is not None:
-                    self.sync.finish()                           # explicit RCCL gradient all-reduce (mean)
+            if self.sync is not None:
+                self.sync.finish()        # explicit RCCL gradient all-reduce (mean); on every rank, always
+            if has_grad:
                 if self.grad_clip > 0:
                     torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=self.grad_clip)
                 self.optimizer.step()

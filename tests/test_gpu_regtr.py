@@ -159,6 +159,35 @@ def test_streamed_forward_equals_group_forwards(device):
     assert isinstance(batch["kpconv_meta"], list) and len(batch["kpconv_meta"]) == 2
 
 
+def test_streamed_forward_is_the_first_forward_after_a_weight_version_bump(device):
+    """The weight-side range caches (ops._static_range, ops.inproj_prepare) are measured on the
+    stream of whichever thread needs them first and then shared through the Parameter: a second
+    stream must wait for that measurement (ops._StreamGuard).  StreamedForward is run as the VERY
+    FIRST forward after every weight version moved -- nothing is cached, both stream threads race
+    to measure and to consume -- and must reproduce the sequential group forwards bit for bit."""
+    from superpoints_registration_amd.streams import StreamedForward, split_batch
+    cfg = get_config("3dmatch")
+    model = RegTR(cfg)
+    synthetic.fill_parameters(model, seed=3)
+    model = model.to(device).eval()
+    pairs = [synthetic.make_pair(2500 + 173 * i, seed=70 + i) for i in range(4)]
+    batch = {"src_xyz": [torch.from_numpy(p[0]).to(device) for p in pairs],
+             "tgt_xyz": [torch.from_numpy(p[1]).to(device) for p in pairs]}
+    sf = StreamedForward(model, n_streams=2, device=device)
+    for trial in range(3):
+        with torch.no_grad():
+            for p in model.parameters():          # bumps every version counter: all cached ranges are stale
+                p.mul_(1.0 + 1e-3 * (trial + 1))
+            torch.cuda.synchronize()
+            out = sf(dict(batch))
+            torch.cuda.synchronize()
+            ref = [model(sub) for sub in split_batch(dict(batch), 2)]
+        torch.cuda.synchronize()
+        assert torch.equal(out["pose"], torch.cat([r["pose"] for r in ref])), trial
+        flat = [f for r in ref for f in r["src_feat"]]
+        assert all(torch.equal(a, b) for a, b in zip(out["src_feat"], flat)), trial
+
+
 @pytest.mark.parametrize("tag", ["3dmatch", "kitti", "modelnet"])
 def test_compute_loss_matches_reference(device, tag):
     """RegTR.compute_loss (HIP) vs the reference's own compute_loss on the golden pairs

@@ -46,13 +46,31 @@ def test_train_step_over_rccl_single_rank(device):
             model = model.to(device)
             tr = Trainer(cfg, rank=0, world=1).setup(model)
             if sync:   # a one-rank group still goes through the bucketed RCCL all-reduce
-                tr.sync = GradientSync(model.parameters(), None, bucket_bytes=4 << 20)
-                assert len(tr.sync.buckets) > 1 and all(b.is_cuda for b in tr.sync.buckets)
+                tr.sync = GradientSync(model, None, bucket_bytes=4 << 20)
+                assert tr.sync.active and len(tr.sync.buckets) > 1 and all(b.is_cuda for b in tr.sync.buckets)
+            losses = tr.train_step(model, dict(batch))
+            torch.cuda.synchronize()
+            if sync:   # every bucket really went through dist.all_reduce on the RCCL group
+                assert tr.sync.n_reduced == len(tr.sync.buckets), (tr.sync.n_reduced, len(tr.sync.buckets))
+                losses = tr.train_step(model, dict(batch))     # second step: launched from the hooks
+                torch.cuda.synchronize()
+                assert tr.sync.n_reduced == len(tr.sync.buckets)
+                return float(losses["total"]), None
+            return float(losses["total"]), {n: p.detach().clone() for n, p in model.named_parameters()}
+        run(True)
+        # parameters after ONE step, with and without the synchroniser
+        def one(sync):
+            model = RegTR(cfg)
+            synthetic.fill_parameters(model, seed=0)
+            model = model.to(device)
+            tr = Trainer(cfg, rank=0, world=1).setup(model)
+            if sync:
+                tr.sync = GradientSync(model, None, bucket_bytes=4 << 20)
             losses = tr.train_step(model, dict(batch))
             torch.cuda.synchronize()
             return float(losses["total"]), {n: p.detach().clone() for n, p in model.named_parameters()}
-        l_sync, p_sync = run(True)
-        l_ref, p_ref = run(False)
+        l_sync, p_sync = one(True)
+        l_ref, p_ref = one(False)
         assert abs(l_sync - l_ref) <= 1e-6 * max(1.0, abs(l_ref))
         # the mean over one rank is the gradient itself: the optimizer step must land on the same
         # parameters (the backward's float atomics make the last bits run-dependent)

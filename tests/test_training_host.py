@@ -168,3 +168,85 @@ def test_checkpoint_format_and_resume(tmp_path):
         tr.saver.save(model, s, score=0.1)
     kept = sorted(f for f in os.listdir(tmp_path / "ckpt") if f.endswith('.pth'))
     assert 'model-3.pth' in kept and len(kept) == 7
+
+
+def _sync_worker(rank, world, port, q):
+    """The reference trainer's calling convention: optimizer.zero_grad() (set_to_none=True) instead
+    of sync.zero_grad(), a Module handed to the constructor, and a parameter that starts to receive
+    gradients only from the third step on."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = Toy()
+    sync = GradientSync(model, None, bucket_bytes=256)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    out = []
+    for step in range(4):
+        opt.zero_grad()                                  # gradients become None: fresh tensors outside the buckets
+        b = _batch(100 * step + rank)
+        loss = model.compute_loss(model(b), b)['total']
+        if step >= 2:
+            loss = loss + (model.unused * float(rank + 1)).sum()     # late joiner (its bucket learnt without it)
+        loss.backward()
+        sync.finish()
+        out.append({n: (None if p.grad is None else p.grad.detach().numpy().copy())
+                    for n, p in model.named_parameters()})
+        assert sync.n_reduced >= len(sync.buckets)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_sync_with_the_reference_trainers_zero_grad_and_late_parameters():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model = Toy()
+    for step in range(4):
+        per_rank = []
+        for rank in range(2):
+            model.zero_grad(set_to_none=True)
+            b = _batch(100 * step + rank)
+            loss = model.compute_loss(model(b), b)['total']
+            if step >= 2:
+                loss = loss + (model.unused * float(rank + 1)).sum()
+            loss.backward()
+            per_rank.append({n: (None if p.grad is None else p.grad.clone()) for n, p in model.named_parameters()})
+        for n in per_rank[0]:
+            for rank in range(2):
+                got = res[rank][step][n]
+                if per_rank[0][n] is None:
+                    assert got is None, (step, n)        # stays None, as without the synchroniser
+                else:
+                    want = 0.5 * (per_rank[0][n] + per_rank[1][n])
+                    assert got is not None and torch.allclose(torch.from_numpy(got), want, rtol=1e-6, atol=1e-8), (step, n)
+
+
+def test_gradient_sync_refuses_a_second_backward_into_a_launched_bucket():
+    port = _free_port()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        model = Toy()
+        sync = GradientSync(model, None, bucket_bytes=256)
+        b = _batch(1)
+        model.compute_loss(model(b), b)['total'].backward()
+        sync.finish()
+        assert sync.n_reduced == len(sync.buckets)       # a one-rank group still runs the collectives
+        sync.zero_grad()
+        model.compute_loss(model(b), b)['total'].backward()          # buckets leave from the hooks now
+        try:
+            model.compute_loss(model(b), b)['total'].backward()      # no zero_grad / finish in between
+            raised = False
+        except RuntimeError as e:
+            raised = 'already been launched' in str(e)
+        assert raised
+    finally:
+        dist.destroy_process_group()
