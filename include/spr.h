@@ -97,7 +97,8 @@ int spr_radius_neighbors(const float* q_xyz, const int* q_cu, int nq,
  *   out [nq, cout]
  * rows_sorted != 0 promises that shadow entries only trail valid ones (true
  * for spr_radius_neighbors output) and enables early exit.
- * impl: 0 = default (MFMA tile kernel), 1 = simple reference kernel.
+ * impl: 0 = default (ring kernel for 32/64-channel inputs, streamed MFMA tile kernel otherwise),
+ *       1 = simple reference kernel, 2 = the streamed MFMA tile kernel for every MFMA shape (A/B).
  */
 size_t spr_kpconv_workspace_bytes(int nq, int ns, int cin, int cout);
 int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, int ns,
@@ -173,6 +174,29 @@ int spr_kpconv_fwd_r(const float* q_xyz, int nq, const float* s_xyz, int ns, con
                      const float* weights, int cout, const float* kernel_points, int n_kp,
                      float kp_extent, float* out, int impl, const float* x_range, int x_range_n,
                      const float* w_range, int w_range_n, void* ws, size_t ws_bytes, void* stream);
+/* Static inputs of the ring KPConv (csrc/kpconv.hip, k_kpconv_ring), hoisted out of the per-call
+ * path.  Both are pure functions of their arguments; callers cache them per neighbour matrix / per
+ * weight version (ops.py does).  The reference recomputes everything per call
+ * (kpconv_blocks.py:269-414); these have no counterpart there.
+ *   spr_kpconv_plan: tile descriptors of a neighbour matrix -- tiles of 16 queries (in `order` if
+ *     given: a permutation of [0, nq), e.g. a spatial order; NULL = natural order), the 16 queries of
+ *     a tile dealt to the eight waves by live neighbour-block count.  The plan depends on
+ *     (nbr contents, nq, ns, nbr_stride, kmax, rows_sorted, order) only.
+ *   spr_kpconv_prep_weights: the [15, cin, cout] weights as range-scaled split-fp16 planes in
+ *     MFMA-fragment order; w_range = spr_absmax partials of the same weights (required).
+ *   spr_kpconv_fwd_p: spr_kpconv_fwd_r with plan / wplanes handed in (NULL = built per call). */
+size_t spr_kpconv_plan_bytes(int nq);
+int spr_kpconv_plan(const int* nbr, int nq, int ns, int nbr_stride, int kmax, int rows_sorted,
+                    const int* order, void* plan, size_t plan_bytes, void* stream);
+size_t spr_kpconv_wplanes_bytes(int cin, int cout);
+int spr_kpconv_prep_weights(const float* weights, int n_kp, int cin, int cout, const float* w_range,
+                            int w_range_n, void* wplanes, size_t wplanes_bytes, void* stream);
+int spr_kpconv_fwd_p(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
+                     int nbr_stride, int kmax, int rows_sorted, const float* x, int cin,
+                     const float* weights, int cout, const float* kernel_points, int n_kp,
+                     float kp_extent, float* out, int impl, const float* x_range, int x_range_n,
+                     const float* w_range, int w_range_n, const void* plan, const void* wplanes,
+                     void* ws, size_t ws_bytes, void* stream);
 int spr_instnorm_r(const float* x, const int* cu, int n, int nb, int max_len_host, int c,
                    float eps, int norm, const float* add, float slope, float* out,
                    float* out_range, int out_range_n, void* ws, size_t ws_bytes, void* stream);

@@ -41,6 +41,12 @@ SIGNATURES = {
     "spr_absmax": (_i, [_vp, _l, _i, _l, _vp, _vp]),
     "spr_kpconv_fwd_r": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp,
                               _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "spr_kpconv_plan_bytes": (_sz, [_i]),
+    "spr_kpconv_plan": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "spr_kpconv_wplanes_bytes": (_sz, [_i, _i]),
+    "spr_kpconv_prep_weights": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "spr_kpconv_fwd_p": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp,
+                              _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "spr_instnorm_r": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _f, _vp, _vp, _i, _vp, _sz, _vp]),
     "spr_maxpool_gather_r": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "spr_layernorm_range_count": (_i, [_i]),

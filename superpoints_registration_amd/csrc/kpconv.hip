@@ -43,6 +43,9 @@ __global__ __launch_bounds__(256) void k_rowflag(const float* __restrict__ x, co
   const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const int c4 = cin >> 2;
+  // record ns = the shadow support point of the ring kernel: far away from everything (influence 0
+  // on every kernel point), flag 0
+  if (blockIdx.x == 0 && threadIdx.x == 0) sxf[ns] = make_float4(-1.0e17f, -1.0e17f, -1.0e17f, __int_as_float(0));
   if ((cin & 3) == 0 && c4 <= 64 && (c4 & (c4 - 1)) == 0) {
     // float4 per lane; a wave load covers 64 / c4 whole rows (1 KiB), kRfSteps loads in flight
     constexpr int kRfSteps = 4;
@@ -100,16 +103,6 @@ __global__ __launch_bounds__(256) void k_rowflag(const float* __restrict__ x, co
     flag[row] = (unsigned char)f;
     sxf[row] = make_float4(s_xyz[3 * (size_t)row], s_xyz[3 * (size_t)row + 1],
                            s_xyz[3 * (size_t)row + 2], __int_as_float(f));
-  }
-}
-
-// Shadow record (index ns) for the ring kernel: a support point far away from everything (influence
-// 0 on every kernel point) with flag 0; pad_word = ns, the index every padded slot of a staged
-// neighbour row reads.
-__global__ void k_kp_shadow(float4* __restrict__ sxf, int ns, int* __restrict__ pad_word) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    sxf[ns] = make_float4(-1.0e17f, -1.0e17f, -1.0e17f, __int_as_float(0));
-    pad_word[0] = ns;
   }
 }
 
@@ -679,15 +672,19 @@ int launch_mfma(const float* q_xyz, int nq, const float* s_xyz, int ns, const in
 // Covers Cin in {32, 64} with Cin * Cout <= 4096 (the 32->32 and 64->64 layers:
 // every KPConv of levels 0 and 1); other shapes keep k_kpconv_mfma.
 constexpr int kRingTQ = 16;
+#ifndef SPR_KP_NS64
+#define SPR_KP_NS64 4   // ring depth of the 64 -> 64 instantiation (experiment builds override it)
+#endif
 
 // Tile descriptors: one wave per tile of 16 queries (in `order` if given).  Entry [tile][w] =
 // {query A, query B, items A, items B} for wave w (-1 / 0 beyond nq).  An item = 8 neighbour
 // slots; rows_sorted: live items = ceil(valid / 8) (>= 1), else every slot block.
 __global__ __launch_bounds__(256) void k_kp_tiles(const int* __restrict__ nbr, int nq, int ns, int nbr_stride,
                                                   int kmax, int rows_sorted, const int* __restrict__ order,
-                                                  int ntiles, int4* __restrict__ desc) {
+                                                  int ntiles, int4* __restrict__ desc, int* __restrict__ pad_word) {
   const int tile = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0) pad_word[0] = ns;   // what padded slots of a staged index row read
   if (tile >= ntiles) return;
   int my_q = -1, my_c = 0;
   for (int r = 0; r < kRingTQ; ++r) {
@@ -813,26 +810,35 @@ struct RingShape {
   static constexpr int RED_BYTES = NG * (SPLIT - 1) * 4 * 64 * 4;
   static constexpr int RING_BYTES = 8 * NS * SLOT;
   static constexpr int SMALL_BYTES = 2 * kRingTQ * 4 * 2;   // lcnt[2][16], lqid[2][16]
+  // 32 -> 32 fits 128 VGPRs and (with NS = 3) 80 KB of LDS: two workgroups = 16 waves per CU
+  static constexpr int MINW = (CC == 32 && COUT == 32) ? 4 : 2;   // waves per SIMD the register budget is cut for
   static_assert(NG * SPLIT == 8 && NS >= 3, "shape");
-  static size_t lds_bytes(int idxw) {                 // idxw: ints per staged index row (64 or 128)
+  static __host__ __device__ size_t lds_bytes(int idxw) {                 // idxw: ints per staged index row (64 or 128)
     return (size_t)WF_BYTES + RED_BYTES + RING_BYTES + SMALL_BYTES + (size_t)8 * 2 * 2 * idxw * 4;
   }
 };
 
 #ifdef SPR_KP_RING_PROF
-// Experiment builds only (make EXTRA=-DSPR_KP_RING_PROF): per-phase shader-clock totals summed over
-// all waves.  0 phase-1 total, 1 of which waiting for the ring, 2 issue, 3 stage + prime, 4 barrier 1,
-// 5 phase 2, 6 barrier 2, 7 epilogue, 8 items, 9 tiles
-__device__ unsigned long long g_kp_prof[16];
-#define KP_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
-#define KP_ACC(slot, a, b) prof_acc[slot] += (b) - (a)
+// Experiment builds only (make EXTRA=-DSPR_KP_RING_PROF): workgroup 0 records a shader-clock time line
+// of its first tiles -- per wave up to kTraceN stamps {id, s_memtime} in LDS, dumped to g_kp_trace at
+// the end.  ids: 1 phase-1 start, 2 item start, 3 item loop done, 4 primed, 5 past barrier 1,
+// 6 phase 2 done, 7 past barrier 2, 8 epilogue done.
+constexpr int kTraceN = 160;
+__device__ unsigned long long g_kp_trace[8 * kTraceN];
+#define KP_STAMP(id)                                                                            \
+  do {                                                                                          \
+    if (blockIdx.x == 0 && trace_n < kTraceN) {                                                 \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                               \
+      if (lane == 0) trace_lds[wave * kTraceN + trace_n] = (t_ << 4) | (unsigned long long)(id); \
+      ++trace_n;                                                                                \
+    }                                                                                           \
+  } while (0)
 #else
-#define KP_STAMP(v)
-#define KP_ACC(slot, a, b)
+#define KP_STAMP(id)
 #endif
 
 template <int CC, int COUT, int NS>
-__global__ __launch_bounds__(512) void k_kpconv_ring(
+__global__ __launch_bounds__(512, (RingShape<CC, COUT, NS>::MINW)) void k_kpconv_ring(
     const float* __restrict__ q_xyz, int ns, const int* __restrict__ nbr, int nbr_stride, int kmax,
     const float* __restrict__ x, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl,
     const float* __restrict__ kpts, float inv_extent, const float4* __restrict__ sxf,
@@ -953,6 +959,9 @@ __global__ __launch_bounds__(512) void k_kpconv_ring(
       if (i < n) issue_ids(i * SLOT, ids[i]);
   };
 
+#ifdef SPR_KP_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every issue arbitration otherwise
+#endif
   int4 d_cur = make_int4(-1, -1, 0, 0), d_nxt = make_int4(-1, -1, 0, 0);
   int tile = blockIdx.x;
   if (tile < ntiles) d_cur = desc[(size_t)tile * 8 + wave];
@@ -965,7 +974,8 @@ __global__ __launch_bounds__(512) void k_kpconv_ring(
   }
 
 #ifdef SPR_KP_RING_PROF
-  unsigned long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long* trace_lds = reinterpret_cast<unsigned long long*>(lds_raw + S::lds_bytes(idxw));
+  int trace_n = 0;
 #endif
   typedef typename VecF<NTC>::type vec_t;
   struct KStep { float4 rec; vec_t xv; };
@@ -977,10 +987,21 @@ __global__ __launch_bounds__(512) void k_kpconv_ring(
     k.xv = *reinterpret_cast<const vec_t*>(ring + slot_off + a_xv + s2 * 4 * RB);
     return k;
   };
+  // Output rows of the previous tile, held back by the writer waves: vmcnt counts stores in issue
+  // order with the gathers, so a store issued right after phase 2 would sit in FRONT of the next
+  // tile's counted waits and expose its write latency there.  They leave at the end of the next
+  // phase 1 instead, when the wave has just drained its queue anyway.
+  float pend_v[4] = {0.f, 0.f, 0.f, 0.f};
+  int pend_n[4] = {-1, -1, -1, -1};
+  auto flush_pending = [&]() {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (pend_n[r] >= 0) out[(size_t)pend_n[r] * COUT + ng * 16 + p16] = pend_v[r];
+  };
   int par = 0;
   for (; tile < ntiles; tile += gridDim.x, par ^= 1) {
     const int4 d = d_cur;
-    KP_STAMP(t_p1);
+    KP_STAMP(1);
     const int n_items = d.z + d.w;
     // descriptor two tiles ahead (scalar load; its index rows are staged at the end of this phase 1)
     int4 d_nn = make_int4(-1, -1, 0, 0);
@@ -1023,6 +1044,7 @@ __global__ __launch_bounds__(512) void k_kpconv_ring(
       int cnt = 0;
 #pragma unroll 1
       for (int b = 0; b < n_q; ++b) {
+        KP_STAMP(2);
         const unsigned nslot = slot_off + SLOT == NS * SLOT ? 0u : slot_off + SLOT;
         {   // k-step 0
           const float dx = (R0.rec.x - qx) - kx, dy = (R0.rec.y - qy) - ky, dz = (R0.rec.z - qz) - kz;
@@ -1092,8 +1114,7 @@ __global__ __launch_bounds__(512) void k_kpconv_ring(
         }
       }
     }
-    KP_STAMP(t_p1e);
-    KP_ACC(0, t_p1, t_p1e);
+    KP_STAMP(3);
     // rows of this tile that hold no query (tail tile): mark them so that the epilogue skips them
     if (lane == 0) {
       if (d.x < 0) lqid[par * kRingTQ + wave] = -1;
@@ -1102,14 +1123,13 @@ __global__ __launch_bounds__(512) void k_kpconv_ring(
     // everything issued so far has landed (the last item waited for vmcnt(0)): the index rows of the
     // next tile are in LDS.  Stage those of the tile after it, then prime the ring with the next tile's
     // first items: they fly during phase 2, the barriers and the epilogue.
+    if (sp == 0) flush_pending();
     if (has_nn) stage_idx(d_nn, par);
     if (has_nxt) prime(d_nxt, par ^ 1);
-    KP_STAMP(t_pr);
-    KP_ACC(3, t_p1e, t_pr);
+    KP_STAMP(4);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // B1: the wf tile is complete
-    KP_STAMP(t_b1);
-    KP_ACC(4, t_pr, t_b1);
+    KP_STAMP(5);
 
     // ------------------------------ phase 2 --------------------------------
     f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -1133,12 +1153,10 @@ __global__ __launch_bounds__(512) void k_kpconv_ring(
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[((ng * (SPLIT - 1) + sp - 1) * 4 + r) * 64 + lane] = acc2[r];
     }
-    KP_STAMP(t_p2);
-    KP_ACC(5, t_b1, t_p2);
+    KP_STAMP(6);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                       // B2: wf free again, partial sums visible
-    KP_STAMP(t_b2);
-    KP_ACC(6, t_p2, t_b2);
+    KP_STAMP(7);
     if (sp == 0) {
 #pragma unroll
       for (int s2 = 1; s2 < SPLIT; ++s2)
@@ -1148,26 +1166,22 @@ __global__ __launch_bounds__(512) void k_kpconv_ring(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ql = 4 * j4 + r;
-        const int n = lqid[par * kRingTQ + ql];
-        if (n >= 0) {
-          const float inv = unscale / (float)max(lcnt[par * kRingTQ + ql], 1);   // unscale: exact power of two
-          out[(size_t)n * COUT + ng * 16 + p16] = acc2[r] * inv;
-        }
+        pend_n[r] = lqid[par * kRingTQ + ql];
+        const float inv = unscale / (float)max(lcnt[par * kRingTQ + ql], 1);   // unscale: exact power of two
+        pend_v[r] = acc2[r] * inv;
       }
     }
-    KP_STAMP(t_ep);
-    KP_ACC(7, t_b2, t_ep);
-#ifdef SPR_KP_RING_PROF
-    prof_acc[8] += n_items;
-    prof_acc[9] += 1;
-#endif
+    KP_STAMP(8);
     d_cur = d_nxt;
     d_nxt = d_nn;
   }
+  if (sp == 0) flush_pending();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef SPR_KP_RING_PROF
-  if (lane == 0)
-    for (int k = 0; k < 10; ++k) atomicAdd(&g_kp_prof[k], prof_acc[k]);
+  if (blockIdx.x == 0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int k = lane; k < kTraceN; k += 64) g_kp_trace[wave * kTraceN + k] = k < trace_n ? trace_lds[wave * kTraceN + k] : 0ull;
+  }
 #endif
 }
 
@@ -1178,14 +1192,20 @@ int launch_ring(const float* q_xyz, int nq, int ns, const int* nbr, int nbr_stri
                 int n_wparts, float* out, hipStream_t stream) {
   typedef RingShape<CC, COUT, NS> S;
   const int idxw = kmax <= 64 ? 64 : 128;
+#ifdef SPR_KP_RING_PROF
+  const size_t lds = S::lds_bytes(idxw) + 8 * kTraceN * 8;
+#else
   const size_t lds = S::lds_bytes(idxw);
+#endif
   auto kern = k_kpconv_ring<CC, COUT, NS>;
   ProfScope prof(stream, CC * 100000 + COUT, nq);
   if (lds > 64 * 1024)
     if (int rc = ensure_dyn_lds((const void*)kern, 160 * 1024)) return rc;
   const int ntiles = cdiv(nq, kRingTQ);
   const int n_cu = device_cu_count();
-  const int grid = ntiles < n_cu ? ntiles : n_cu;
+  int per_cu = (int)((160 * 1024) / lds);                       // LDS-limited residency
+  per_cu = per_cu < 1 ? 1 : (per_cu > S::MINW / 2 ? S::MINW / 2 : per_cu);
+  const int grid = ntiles < n_cu * per_cu ? ntiles : n_cu * per_cu;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, q_xyz, ns, nbr, nbr_stride, kmax, x, Wh, Wl, kpts,
                      inv_extent, sxf, desc, ntiles, pad_word, idxw, x_parts, w_parts, n_xparts, n_wparts, out);
   SPR_LAUNCH_CHECK();
@@ -1198,23 +1218,58 @@ int launch_ring(const float* q_xyz, int nq, int ns, const int* nbr, int nbr_stri
 using namespace spr;
 
 #ifdef SPR_KP_RING_PROF
-extern "C" int spr_debug_kp_prof(unsigned long long* out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_kp_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
-  if (reset) {
-    unsigned long long z[16] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_kp_prof), z, sizeof(z)) != hipSuccess) return 1;
-  }
+extern "C" int spr_debug_kp_trace(unsigned long long* out, int n) {   // n <= 8 * kTraceN
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kp_trace), sizeof(unsigned long long) * n) != hipSuccess) return 1;
   return 0;
 }
 #endif
+
+static inline size_t plan_desc_bytes(int nq) { return align_up((size_t)cdiv(nq > 0 ? nq : 1, kRingTQ) * 8 * sizeof(int4), 256); }
+static inline int w_chunk(int cin) { return cin % 64 == 0 ? 64 : 32; }
+static inline bool ring_shape(int cin, int cout) {
+  return (cin == 32 || cin == 64) && cin * cout <= 4096 && cout % 32 == 0 && 8 % (cout / 16) == 0;
+}
+
+extern "C" size_t spr_kpconv_plan_bytes(int nq) { return plan_desc_bytes(nq) + 256; }
+
+extern "C" int spr_kpconv_plan(const int* nbr, int nq, int ns, int nbr_stride, int kmax, int rows_sorted,
+                               const int* order, void* plan, size_t plan_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(nq > 0 && ns > 0 && kmax >= 1 && kmax <= nbr_stride, "kpconv plan: bad sizes");
+  SPR_REQUIRE(plan != nullptr && plan_bytes >= spr_kpconv_plan_bytes(nq), "kpconv plan: buffer too small");
+  const int ntiles = cdiv(nq, kRingTQ);
+  int4* desc = (int4*)plan;
+  int* pad_word = (int*)((char*)plan + plan_desc_bytes(nq));
+  hipLaunchKernelGGL(k_kp_tiles, dim3(cdiv((long)ntiles * 64, 256)), dim3(256), 0, stream, nbr, nq, ns, nbr_stride,
+                     kmax, rows_sorted, order, ntiles, desc, pad_word);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t spr_kpconv_wplanes_bytes(int cin, int cout) { return 2 * align_up((size_t)32 * cin * cout * 2, 256); }
+
+extern "C" int spr_kpconv_prep_weights(const float* weights, int n_kp, int cin, int cout, const float* w_range,
+                                       int w_range_n, void* wplanes, size_t bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(n_kp == kKP && cin % 32 == 0 && cout % 32 == 0 && cout <= 256,
+              "kpconv weight planes exist for the MFMA shapes only (15 kernel points, channels in multiples of 32)");
+  SPR_REQUIRE(w_range != nullptr && w_range_n >= 1, "kpconv weight planes: the weight range is required");
+  SPR_REQUIRE(wplanes != nullptr && bytes >= spr_kpconv_wplanes_bytes(cin, cout), "kpconv weight planes: buffer too small");
+  _Float16* wh = (_Float16*)wplanes;
+  _Float16* wl = (_Float16*)((char*)wplanes + align_up((size_t)32 * cin * cout * 2, 256));
+  hipLaunchKernelGGL(k_w_prep, dim3(cdiv((long)n_kp * cin * cout, 256)), dim3(256), 0, stream, weights, cin, cout,
+                     w_chunk(cin), w_range, w_range_n, wh, wl);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" size_t spr_kpconv_workspace_bytes(int nq, int ns, int cin, int cout) {
   // flag bytes + {x,y,z,flag} support records + pre-split fragment-order weights (hi, lo fp16; up to
   // 32 kernel points)
   const size_t n = (size_t)(ns > 0 ? ns : 1);
-  const size_t tiles = (size_t)cdiv(nq > 0 ? nq : 1, kRingTQ);
-  return align_up(n, 256) + align_up(16 * (n + 1), 256) + 2 * align_up((size_t)32 * cin * cout * 2, 256) +
-         2 * align_up(kAmaxParts * sizeof(float), 256) + align_up(tiles * 8 * sizeof(int4), 256) + 256 + 256;
+  return align_up(n, 256) + align_up(16 * (n + 1), 256) + spr_kpconv_wplanes_bytes(cin, cout) +
+         2 * align_up(kAmaxParts * sizeof(float), 256) + spr_kpconv_plan_bytes(nq) + 256;
 }
 
 extern "C" int spr_kpconv_fwd(const float* q_xyz, int nq, const float* s_xyz, int ns,
@@ -1234,6 +1289,20 @@ extern "C" int spr_kpconv_fwd_r(const float* q_xyz, int nq, const float* s_xyz, 
                                 const float* kernel_points, int n_kp, float kp_extent,
                                 float* out, int impl, const float* x_range, int x_range_n, const float* w_range,
                                 int w_range_n, void* ws, size_t ws_bytes, void* stream_) {
+  return spr_kpconv_fwd_p(q_xyz, nq, s_xyz, ns, nbr, nbr_stride, kmax, rows_sorted, x, cin, weights, cout, kernel_points,
+                          n_kp, kp_extent, out, impl, x_range, x_range_n, w_range, w_range_n, nullptr, nullptr, ws,
+                          ws_bytes, stream_);
+}
+
+// plan / wplanes: spr_kpconv_plan of THIS neighbour matrix (same nq, ns, stride, kmax, rows_sorted) and
+// spr_kpconv_prep_weights of THESE weights with THIS w_range; NULL = built here, per call.
+extern "C" int spr_kpconv_fwd_p(const float* q_xyz, int nq, const float* s_xyz, int ns,
+                                const int* nbr, int nbr_stride, int kmax, int rows_sorted,
+                                const float* x, int cin, const float* weights, int cout,
+                                const float* kernel_points, int n_kp, float kp_extent,
+                                float* out, int impl, const float* x_range, int x_range_n, const float* w_range,
+                                int w_range_n, const void* plan, const void* wplanes, void* ws, size_t ws_bytes,
+                                void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE((x_range == nullptr || x_range_n >= 1) && (w_range == nullptr || w_range_n >= 1),
               "kpconv: a range needs a count");
@@ -1248,8 +1317,12 @@ extern "C" int spr_kpconv_fwd_r(const float* q_xyz, int nq, const float* s_xyz, 
   _Float16* wl = (_Float16*)((char*)wh + align_up((size_t)32 * cin * cout * 2, 256));
   float* x_parts = (float*)((char*)wl + align_up((size_t)32 * cin * cout * 2, 256));
   float* w_parts = x_parts + align_up(kAmaxParts * sizeof(float), 256) / sizeof(float);
-  int4* desc = (int4*)((char*)w_parts + align_up(kAmaxParts * sizeof(float), 256));
-  int* pad_word = (int*)((char*)desc + align_up((size_t)cdiv(nq, kRingTQ) * 8 * sizeof(int4), 256));
+  void* ws_plan = (char*)w_parts + align_up(kAmaxParts * sizeof(float), 256);
+  SPR_REQUIRE(wplanes == nullptr || w_range != nullptr, "kpconv: prepared weight planes come with the range they were scaled by");
+  if (wplanes != nullptr) {
+    wh = (_Float16*)wplanes;
+    wl = (_Float16*)((char*)wplanes + align_up((size_t)32 * cin * cout * 2, 256));
+  }
   const float inv_extent = 1.0f / kp_extent;
 
   if (cin == 1 && impl == 0 && n_kp <= 16) {
@@ -1280,28 +1353,28 @@ extern "C" int spr_kpconv_fwd_r(const float* q_xyz, int nq, const float* s_xyz, 
     } else if (w_range == nullptr) {
       if (int rc = launch_absmax(weights, ktot, cout, cout, w_parts, stream)) return rc;
     }
-    hipLaunchKernelGGL(k_w_prep, dim3(cdiv((long)ktot * cout, 256)), dim3(256), 0, stream, weights, cin, cout,
-                       cin % 64 == 0 ? 64 : 32, wp, n_wp, wh, wl);
+    if (wplanes == nullptr)
+      hipLaunchKernelGGL(k_w_prep, dim3(cdiv((long)ktot * cout, 256)), dim3(256), 0, stream, weights, cin, cout,
+                         w_chunk(cin), wp, n_wp, wh, wl);
     // ring kernel: 32- / 64-channel inputs whose whole weight matrix fits the register file
-    const bool ring_ok = impl == 0 && (cin == 32 || cin == 64) && cin * cout <= 4096 && cout % 16 == 0 &&
-                         8 % (cout / 16) == 0 && kmax <= 128 && (size_t)ns * cin * 4 < (1ull << 32) &&
+    const bool ring_ok = impl == 0 && ring_shape(cin, cout) && kmax <= 128 && (size_t)ns * cin * 4 < (1ull << 32) &&
                          (size_t)nq * nbr_stride * 4 < (1ull << 32);
     if (ring_ok) {
-      const int ntiles = cdiv(nq, kRingTQ);
-      hipLaunchKernelGGL(k_kp_shadow, dim3(1), dim3(64), 0, stream, sxf, ns, pad_word);
-      hipLaunchKernelGGL(k_kp_tiles, dim3(cdiv((long)ntiles * 64, 256)), dim3(256), 0, stream, nbr, nq, ns,
-                         nbr_stride, kmax, rows_sorted, (const int*)nullptr, ntiles, desc);
-      SPR_LAUNCH_CHECK();
+      if (plan == nullptr) {
+        if (int rc = spr_kpconv_plan(nbr, nq, ns, nbr_stride, kmax, rows_sorted, nullptr, ws_plan,
+                                     spr_kpconv_plan_bytes(nq), stream_)) return rc;
+        plan = ws_plan;
+      }
+      const int4* desc = (const int4*)plan;
+      const int* pad_word = (const int*)((const char*)plan + plan_desc_bytes(nq));
 #define SPR_RING_ARGS                                                                                       \
   q_xyz, nq, ns, nbr, nbr_stride, kmax, x, wh, wl, kernel_points, inv_extent, sxf, desc, pad_word, xp, wp, \
       n_xp, n_wp, out, stream
-      if (cin == 64 && cout == 64) return launch_ring<64, 64, 4>(SPR_RING_ARGS);
+      if (cin == 64 && cout == 64) return launch_ring<64, 64, SPR_KP_NS64>(SPR_RING_ARGS);
       if (cin == 64 && cout == 32) return launch_ring<64, 32, 4>(SPR_RING_ARGS);
-      if (cin == 64 && cout == 16) return launch_ring<64, 16, 4>(SPR_RING_ARGS);
-      if (cin == 32 && cout == 32) return launch_ring<32, 32, 8>(SPR_RING_ARGS);
+      if (cin == 32 && cout == 32) return launch_ring<32, 32, 3>(SPR_RING_ARGS);
       if (cin == 32 && cout == 64) return launch_ring<32, 64, 8>(SPR_RING_ARGS);
       if (cin == 32 && cout == 128) return launch_ring<32, 128, 8>(SPR_RING_ARGS);
-      if (cin == 32 && cout == 16) return launch_ring<32, 16, 8>(SPR_RING_ARGS);
 #undef SPR_RING_ARGS
     }
 #define SPR_KP_ARGS                                                                         \

@@ -247,7 +247,10 @@ def kpconv(q_pts, s_pts, nbr, x, weights, kernel_points, kp_extent: float, rows_
 
 
 def kpconv_raw(q_pts, s_pts, nbr, x, weights, kernel_points, kp_extent: float, rows_sorted: bool = False,
-               impl: int = 0) -> torch.Tensor:
+               impl: int = 0, order: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """order: optional int32 permutation of the queries (the tile walk of the ring kernel, e.g. a
+    spatial order so that the workgroups of an XCD share neighbour rows in its L2); the output is
+    bitwise independent of it."""
     q_pts = _dev(q_pts, "q_pts", torch.float32)
     s_pts = _dev(s_pts, "s_pts", torch.float32)
     x = _dev(x, "x", torch.float32)
@@ -269,12 +272,60 @@ def kpconv_raw(q_pts, s_pts, nbr, x, weights, kernel_points, kp_extent: float, r
     out = torch.empty((nq, cout), dtype=torch.float32, device=x.device)
     xr, xr_n = _get_range(x)
     wr, wr_n = _static_range(weights)
-    _lib.check(L.spr_kpconv_fwd_r(_ptr(q_pts), nq, _ptr(s_pts), ns, _ptr(nbr), int(stride), kmax,
+    plan = wplanes = None
+    if impl == 0 and n_kp == 15 and cin % 32 == 0 and cout % 32 == 0 and cout <= 256:
+        if cin in (32, 64) and cin * cout <= 4096 and kmax <= 128:
+            plan = _kpconv_plan(nbr, nq, ns, int(stride), kmax, bool(rows_sorted), order)
+        if wr is not None:
+            wplanes = _kpconv_wplanes(weights, wr, wr_n)
+    _lib.check(L.spr_kpconv_fwd_p(_ptr(q_pts), nq, _ptr(s_pts), ns, _ptr(nbr), int(stride), kmax,
                                   int(bool(rows_sorted)), _ptr(x), cin, _ptr(weights), cout,
                                   _ptr(kernel_points), n_kp, float(kp_extent), _ptr(out), int(impl),
-                                  _ptr(xr), int(xr_n), _ptr(wr), int(wr_n),
-                                  _ptr(ws), ws.numel(), _stream(x)), "spr_kpconv_fwd_r")
+                                  _ptr(xr), int(xr_n), _ptr(wr), int(wr_n), _ptr(plan), _ptr(wplanes),
+                                  _ptr(ws), ws.numel(), _stream(x)), "spr_kpconv_fwd_p")
     return out
+
+
+def _kpconv_plan(nbr: torch.Tensor, nq: int, ns: int, stride: int, kmax: int, rows_sorted: bool,
+                 order: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Tile descriptors of a neighbour matrix for the ring KPConv (spr_kpconv_plan), cached on the
+    index tensor: the pyramid hands the same int32 tensor to every block of a level, and training
+    re-uses it for the recomputation in the backward.  Keyed like a published range (storage pointer
+    + version counter), with the arguments the plan depends on; guarded for readers on other streams."""
+    if order is not None:
+        order = _dev(order, "order", torch.int32)
+        assert order.shape == (nq,)
+    key = (nbr.data_ptr(), nbr._version, nq, ns, stride, kmax, rows_sorted, _range_epoch[0],
+           None if order is None else (order.data_ptr(), order._version))
+    c = getattr(nbr, '_spr_kp_plan', None)
+    if c is not None and c[0] == key:
+        c[2].acquire()
+        return c[1]
+    L = _lib.lib()
+    nbytes = L.spr_kpconv_plan_bytes(nq)
+    plan = torch.empty((nbytes,), dtype=torch.uint8, device=nbr.device)
+    _lib.check(L.spr_kpconv_plan(_ptr(nbr), nq, ns, stride, kmax, int(rows_sorted), _ptr(order), _ptr(plan), nbytes,
+                                 _stream(nbr)), "spr_kpconv_plan")
+    nbr._spr_kp_plan = (key, plan, _StreamGuard(plan))
+    return plan
+
+
+def _kpconv_wplanes(weights: torch.Tensor, wr: torch.Tensor, wr_n: int) -> torch.Tensor:
+    """Split-fp16 fragment-order planes of a KPConv weight tensor (spr_kpconv_prep_weights), cached per
+    weight version next to its range."""
+    key = (weights.data_ptr(), weights._version, wr.data_ptr(), _range_epoch[0])
+    c = getattr(weights, '_spr_kp_wplanes', None)
+    if c is not None and c[0] == key:
+        c[2].acquire()
+        return c[1]
+    L = _lib.lib()
+    n_kp, cin, cout = weights.shape
+    nbytes = L.spr_kpconv_wplanes_bytes(cin, cout)
+    planes = torch.empty((nbytes,), dtype=torch.uint8, device=weights.device)
+    _lib.check(L.spr_kpconv_prep_weights(_ptr(weights), n_kp, cin, cout, _ptr(wr), int(wr_n), _ptr(planes), nbytes,
+                                         _stream(weights)), "spr_kpconv_prep_weights")
+    weights._spr_kp_wplanes = (key, planes, _StreamGuard(planes))
+    return planes
 
 
 def instnorm(x, cu, eps: float = 1e-5, norm: bool = True, add=None, slope: float = 1.0,

@@ -65,6 +65,78 @@ def test_kpconv_unsorted_rows_and_int64_indices(gold, inp, device):
     _close(y.cpu().numpy(), ref.numpy(), 1e-5, "kpconv unsorted")
 
 
+def _ring_case(seed, nq, ns, kmax, cin, cout, sorted_rows=True, fill=0.7):
+    """Random clouds + a neighbour matrix with `fill` valid entries per row on average (shadow = ns)."""
+    rng = np.random.default_rng(seed)
+    s_pts = rng.uniform(-0.5, 0.5, (ns, 3)).astype(np.float32)
+    q_pts = (s_pts[rng.integers(0, ns, nq)] + rng.normal(0, 0.01, (nq, 3))).astype(np.float32)
+    nb = rng.integers(0, ns, (nq, kmax)).astype(np.int64)
+    # neighbours close to the query so that influences are non-trivial
+    d = np.linalg.norm(s_pts[None, :, :] - q_pts[:, None, :], axis=2) if nq * ns <= 4_000_000 else None
+    if d is not None:
+        nb = np.argsort(d, axis=1)[:, :kmax]
+    valid = rng.random((nq, kmax)) < fill
+    valid[:, 0] |= rng.random(nq) < 0.9                       # a few rows with no valid neighbour at all
+    if sorted_rows:
+        cnt = valid.sum(1)
+        valid = np.arange(kmax)[None, :] < cnt[:, None]
+    nb = np.where(valid, nb, ns)
+    x = (rng.random((ns, cin)).astype(np.float32) - 0.4)
+    w = ((rng.random((15, cin, cout)).astype(np.float32) - 0.5) * 0.5)
+    return q_pts, s_pts, nb, x, w
+
+
+@pytest.mark.parametrize("nq,ns,kmax,cin,cout,srt", [
+    (1000, 1000, 40, 64, 64, True),      # the level-1 layer shape, tail tile (1000 = 62 * 16 + 8)
+    (333, 1200, 38, 32, 32, True),       # strided: queries are another cloud
+    (5, 700, 12, 64, 64, True),          # fewer queries than one tile
+    (16, 300, 8, 32, 32, True),          # exactly one tile, one block per query
+    (777, 900, 70, 64, 64, True),        # rows wider than 64 slots (two index pieces per row)
+    (640, 640, 33, 32, 64, True),        # the other register-resident weight shapes
+    (640, 640, 33, 64, 32, True),
+    (500, 500, 24, 32, 128, True),
+    (900, 900, 40, 64, 64, False),       # shadow entries anywhere in a row
+    (450, 800, 17, 32, 32, False),
+])
+def test_kpconv_ring_kernel_vs_oracle(gold, device, nq, ns, kmax, cin, cout, srt):
+    """The ring kernel (LDS-DMA gather, register-resident weights; csrc/kpconv.hip k_kpconv_ring) against the
+    float64 restatement of kpconv_blocks.py:309-412, on shapes chosen to hit its tile / ring / index-row edges;
+    features <= 1e-5 of scale, bitwise equal between two runs and under a permuted tile walk."""
+    q, s, nb, x, w = _ring_case(nq * 7 + kmax, nq, ns, kmax, cin, cout, srt)
+    kp = T(gold["kp.c32.kpts"]).to(device)
+    ext = 0.1
+    args = (T(q).to(device), T(s).to(device), T(nb.astype(np.int32)).to(device), T(x).to(device), T(w).to(device), kp, ext)
+    y = ops.kpconv_raw(*args, rows_sorted=srt)
+    ref = O.kpconv(T(q).double(), T(s).double(), T(nb), T(x).double(), T(w).double(), kp.cpu().double(), ext)
+    _close(y.cpu().numpy(), ref.numpy(), 1e-5, f"ring kpconv {nq}x{kmax} {cin}->{cout}")
+    assert torch.equal(y, ops.kpconv_raw(*args, rows_sorted=srt))
+    order = torch.from_numpy(np.random.default_rng(1).permutation(nq).astype(np.int32)).to(device)
+    assert torch.equal(y, ops.kpconv_raw(*args, rows_sorted=srt, order=order))
+    y2 = ops.kpconv_raw(*args, rows_sorted=srt, impl=2)           # the streamed tile kernel of round 2
+    _close(y.cpu().numpy(), y2.cpu().numpy(), 2e-6, "ring vs streamed kernel")
+
+
+def test_kpconv_plan_and_weight_planes_are_cached_and_invalidated(gold, device):
+    """ops caches the tile plan on the index tensor and the split weight planes on the weight tensor; an
+    in-place edit of either (version counter) must rebuild them."""
+    q, s, nb, x, w = _ring_case(11, 400, 400, 20, 32, 32)
+    kp = T(gold["kp.c32.kpts"]).to(device)
+    nbt, wt = T(nb.astype(np.int32)).to(device), T(w).to(device)
+    args = lambda: (T(q).to(device), T(s).to(device), nbt, T(x).to(device), wt, kp, 0.1)
+    y0 = ops.kpconv_raw(*args(), rows_sorted=True)
+    plan0, planes0 = nbt._spr_kp_plan[1], wt._spr_kp_wplanes[1]
+    assert ops.kpconv_raw(*args(), rows_sorted=True) is not None and nbt._spr_kp_plan[1] is plan0
+    wt.mul_(2.0)                                    # new weight version: planes AND range are re-made
+    y1 = ops.kpconv_raw(*args(), rows_sorted=True)
+    assert wt._spr_kp_wplanes[1] is not planes0
+    _close(y1.cpu().numpy(), 2.0 * y0.cpu().numpy(), 1e-6, "weights doubled")
+    nbt[:, 1:] = 400                                # new index version: one neighbour per row
+    y2 = ops.kpconv_raw(*args(), rows_sorted=True)
+    assert nbt._spr_kp_plan[1] is not plan0
+    ref = O.kpconv(T(q).double(), T(s).double(), nbt.cpu().long(), T(x).double(), wt.cpu().double(), kp.cpu().double(), 0.1)
+    _close(y2.cpu().numpy(), ref.numpy(), 1e-5, "after index edit")
+
+
 def test_instnorm_lrelu_maxpool_residual(gold, inp, device):
     cu = ops.lengths_to_cu(inp["kp.lens"].tolist(), device)
     x = inp["in.x"].to(device)
