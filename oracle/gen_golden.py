@@ -430,6 +430,8 @@ def sized_inputs(case):
         return '3dmatch', [synthetic.make_pair(20000, seed=10)]
     if case == 'c3':     # KITTI-shaped outdoor pair: 120 k raw LiDAR-like points, pre-voxelised at 0.3 m
         return 'kitti', [synthetic.make_lidar_pair(120000, seed=3)]
+    if case == 'c3w':    # KITTI-sized pair with a well-conditioned pose solve (translated copy, synthetic.py)
+        return 'kitti', [synthetic.make_lidar_translated_pair(120000, seed=5)[:2]]
     return 'modelnet', [synthetic.make_sphere_pair(1024, seed=100 + i) for i in range(8)]   # c4
 
 
@@ -465,6 +467,90 @@ def gen_sized(case):
           f'{time.time() - t0:.0f} s', out['pose'][0, :, 3].numpy())
 
 
+FORMAT_SCENES = ('7-scenes-redkitchen', 'sun3d-hotel_umd-maryland_hotel3')
+
+
+def formats_est_poses(gt_pairs, gt_traj, seed):
+    """est.log content derived from a scene's gt.log with a seeded generator (shared by the generator
+    and tests/test_formats.py): most pairs exact, some perturbed a little (still inside the 0.2 m RMSE
+    bound), some perturbed a lot (outside), some missing.  (Every estimated pair must be listed in gt.log:
+    the reference's extract_corresponding_trajectors, :156-176, fails otherwise.  Consecutive pairs are
+    listed too and get flag 2.)"""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(seed)
+    pairs, poses = [], []
+    for k in range(len(gt_pairs)):
+        u = rng.random()
+        if u < 0.06:
+            continue                                            # the method produced nothing for this pair
+        T = np.array(gt_traj[k], dtype=np.float64)
+        if u >= 0.70:
+            big = u >= 0.88
+            dT = np.eye(4)
+            dT[:3, :3] = Rotation.from_rotvec(rng.normal(0, 0.25 if big else 0.01, 3)).as_matrix()
+            dT[:3, 3] = rng.normal(0, 0.5 if big else 0.02, 3)
+            T = T @ dT
+        pairs.append((int(gt_pairs[k][0]), int(gt_pairs[k][1])))
+        poses.append(T)
+    return pairs, np.stack(poses)
+
+
+def write_formats_est(est_root, gt_root, scenes=FORMAT_SCENES):
+    """<est_root>/<scene>/est.log through the PRODUCT writer (formats.write_est_log), from the gt.log of
+    each scene under gt_root."""
+    from superpoints_registration_amd import formats
+    for si, scene in enumerate(scenes):
+        gt_pairs, gt_traj = formats.read_trajectory(os.path.join(gt_root, scene, 'gt.log'))
+        pairs, poses = formats_est_poses(gt_pairs, gt_traj, seed=40 + si)
+        batch = {'src_xyz': [None] * len(pairs),
+                 'src_path': [os.path.join('test', scene, f'cloud_bin_{b}.pth') for a, b in pairs],
+                 'tgt_path': [os.path.join('test', scene, f'cloud_bin_{a}.pth') for a, b in pairs]}
+        formats.write_est_log(est_root, '', batch, {'pose': torch.from_numpy(poses[:, :3])})
+
+
+def gen_formats():
+    """SURVEY 8f row 4 pinned to the reference: its evaluator (benchmark_predator.benchmark, :285-375,
+    with evaluate_registration :222-282 and the two readers :82-153) is run HERE on est.log files
+    written by the product writer for two scenes whose gt.log / gt.info the reference holds
+    (src/datasets/3dmatch/benchmarks/3DMatch/<scene>/; copied as data to tests/golden/3dmatch_gt/).
+    Stored: the report text, mean recall, per-scene flags and errors, and what the reference's
+    readers return for the real files."""
+    import gzip, shutil, tempfile
+    bp = ref_harness.load_benchmark()
+    src_root = os.path.join(ref_harness.REF_SRC, 'datasets', '3dmatch', 'benchmarks', '3DMatch')
+    fix_root = os.path.join(OUT, '3dmatch_gt')
+    for scene in FORMAT_SCENES:                                  # fixtures = the reference's data files
+        os.makedirs(os.path.join(fix_root, scene), exist_ok=True)
+        for name in ('gt.log', 'gt.info'):
+            with open(os.path.join(src_root, scene, name), 'rb') as f, \
+                    gzip.GzipFile(os.path.join(fix_root, scene, name + '.gz'), 'wb', mtime=0) as g:
+                shutil.copyfileobj(f, g)
+    fx = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        gt_root, est_root = os.path.join(tmp, 'gt'), os.path.join(tmp, 'est')
+        for scene in FORMAT_SCENES:
+            os.makedirs(os.path.join(gt_root, scene))
+            for name in ('gt.log', 'gt.info'):
+                shutil.copy(os.path.join(src_root, scene, name), os.path.join(gt_root, scene, name))
+        write_formats_est(est_root, gt_root)
+        report, recall = bp.benchmark(est_root, gt_root)
+        fx['report'] = np.array(report)
+        fx['recall'] = np.float64(recall)
+        for si, scene in enumerate(sorted(FORMAT_SCENES)):
+            fx[f'flags{si}'] = np.load(os.path.join(est_root, scene, 'flag.npy'))
+            fx[f'errors{si}'] = np.load(os.path.join(est_root, scene, 'errors.npy'))
+            keys, traj = bp.read_trajectory(os.path.join(gt_root, scene, 'gt.log'))
+            n_frag, info = bp.read_trajectory_info(os.path.join(gt_root, scene, 'gt.info'))
+            fx[f'gt_keys{si}'], fx[f'gt_traj{si}'] = np.asarray(keys), traj
+            fx[f'n_frag{si}'], fx[f'gt_info{si}'] = np.int64(n_frag), info
+            ekeys, etraj = bp.read_trajectory(os.path.join(est_root, scene, 'est.log'))
+            fx[f'est_keys{si}'], fx[f'est_traj{si}'] = np.asarray(ekeys), etraj
+    path = os.path.join(OUT, 'formats_3dmatch.npz')
+    np.savez_compressed(path, **fx)
+    print(os.path.basename(path), os.path.getsize(path) // 1024, 'KB; recall', recall)
+    print(report)
+
+
 def main():
     assert ref_harness.available(), "needs /root/reference (dev container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -490,7 +576,9 @@ def main():
             gen_train('3dmatch', 2, 2)
         if 'refine' in what:
             gen_refine('kitti', 2)
-        for case in ('c2', 'c3', 'c4'):
+        if 'formats' in what:
+            gen_formats()
+        for case in ('c2', 'c3', 'c3w', 'c4'):
             if f'sized_{case}' in what or 'sized' in what:
                 gen_sized(case)
     finally:

@@ -134,6 +134,36 @@ def load():
     return _loaded
 
 
+def _mat2quat(M):
+    """nibabel.quaternions.mat2quat restated (nibabel is not installed here and the reference does not
+    pin a version; algorithm of nibabel 2.x-5.x, Bar-Itzhack 2000): the unit quaternion (w, x, y, z),
+    w >= 0, is the eigenvector of the largest eigenvalue of the symmetric 4x4 matrix K built from M."""
+    Qxx, Qyx, Qzx, Qxy, Qyy, Qzy, Qxz, Qyz, Qzz = np.asarray(M, dtype=np.float64).flat
+    K = np.array([[Qxx - Qyy - Qzz, 0, 0, 0],
+                  [Qyx + Qxy, Qyy - Qxx - Qzz, 0, 0],
+                  [Qzx + Qxz, Qzy + Qyz, Qzz - Qxx - Qyy, 0],
+                  [Qyz - Qzy, Qzx - Qxz, Qxy - Qyx, Qxx + Qyy + Qzz]]) / 3.0
+    vals, vecs = np.linalg.eigh(K)
+    q = vecs[[3, 0, 1, 2], np.argmax(vals)]
+    if q[0] < 0:
+        q = q * -1
+    return q
+
+
+def load_benchmark():
+    """The reference's 3DMatch evaluator, src/benchmark/benchmark_predator.py, imported as it stands.
+    It was written against numpy < 1.24 (np.int / np.float) and imports nibabel: the two aliases are
+    restored for the import and nibabel.quaternions.mat2quat is provided by the restatement above."""
+    load()
+    if not hasattr(np, 'int'):
+        np.int = int          # noqa: NPY001 -- aliases the reference file expects (numpy < 1.24)
+    if not hasattr(np, 'float'):
+        np.float = float
+    sys.modules['nibabel.quaternions'].mat2quat = _mat2quat
+    sys.modules['nibabel'].quaternions = sys.modules['nibabel.quaternions']
+    return importlib.import_module("benchmark.benchmark_predator")
+
+
 def load_regtr():
     ns = load()
     if "regtr" not in ns:

@@ -1325,7 +1325,7 @@ extern "C" int spr_kpconv_fwd_p(const float* q_xyz, int nq, const float* s_xyz, 
   }
   const float inv_extent = 1.0f / kp_extent;
 
-  if (cin == 1 && impl == 0 && n_kp <= 16) {
+  if (cin == 1 && (impl == 0 || impl == 2) && n_kp <= 16) {
     ProfScope prof(stream, cin * 100000 + cout, nq);
     hipLaunchKernelGGL(k_kpconv_cin1, dim3(cdiv(nq, 64)), dim3(256), 0, stream, q_xyz, nq, s_xyz, ns, nbr,
                        nbr_stride, kmax, rows_sorted, x, weights, cout, kernel_points, n_kp, inv_extent, out);

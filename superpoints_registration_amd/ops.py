@@ -246,11 +246,16 @@ def kpconv(q_pts, s_pts, nbr, x, weights, kernel_points, kp_extent: float, rows_
     return kpconv_raw(q_pts, s_pts, nbr, x, weights, kernel_points, kp_extent, rows_sorted, impl)
 
 
+_KP_IMPL_AB = os.environ.get("SPR_KPCONV_IMPL")   # experiment switch (A/B timing): "2" = round-2 streamed kernel
+
+
 def kpconv_raw(q_pts, s_pts, nbr, x, weights, kernel_points, kp_extent: float, rows_sorted: bool = False,
                impl: int = 0, order: Optional[torch.Tensor] = None) -> torch.Tensor:
     """order: optional int32 permutation of the queries (the tile walk of the ring kernel, e.g. a
     spatial order so that the workgroups of an XCD share neighbour rows in its L2); the output is
     bitwise independent of it."""
+    if _KP_IMPL_AB is not None and impl == 0:
+        impl = int(_KP_IMPL_AB)
     q_pts = _dev(q_pts, "q_pts", torch.float32)
     s_pts = _dev(s_pts, "s_pts", torch.float32)
     x = _dev(x, "x", torch.float32)

@@ -109,6 +109,21 @@ def make_lidar_pair(n: int = 120000, seed: int = 0, r_max: float = 26.0, voxel: 
             pose.astype(np.float32))
 
 
+def make_lidar_translated_pair(n: int = 120000, seed: int = 0, shift=(4.8, -2.4, 0.0)):
+    """KITTI-shaped pair whose pose solve is WELL conditioned whatever the network weights: the target
+    is the (pre-voxelised) source scan translated by a multiple of every pyramid voxel size (0.3 m *
+    2^level), in a random point order.  Both clouds then get the same voxel grids, neighbourhoods and
+    therefore (up to the positional embedding) the same encoder features point for point, so even a
+    randomly initialised matcher finds the true correspondences with high confidence, and the weighted
+    Kabsch solve sees a consistent rigid motion instead of random matches.  Returns (src, tgt, pose_gt)."""
+    src, _, _ = make_lidar_pair(n, seed)
+    rng = np.random.default_rng(seed + 1000)
+    t = np.asarray(shift, np.float32)
+    tgt = (src[rng.permutation(len(src))] + t[None]).astype(np.float32)
+    pose = np.concatenate([np.eye(3, dtype=np.float32), t[:, None]], 1)
+    return src, tgt, pose
+
+
 @torch.no_grad()
 def fill_parameters(model: torch.nn.Module, seed: int = 0) -> None:
     """Overwrite every entry of model.state_dict() with values drawn from a

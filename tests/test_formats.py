@@ -1,7 +1,10 @@
-"""CPU: on-disk formats around the path (formats.py).  The reference's evaluator
-cannot be executed in this image (benchmark_predator.py uses np.int / np.float, removed from
-numpy 2, and imports nibabel), so these are known-answer tests of the Redwood protocol it
-implements, plus an exact check of the est.log text layout of generic_reg_model.py:382-403."""
+"""CPU: on-disk formats around the path (formats.py).  Pinned to the reference:
+its evaluator (benchmark_predator.py) was run in the dev container by oracle/gen_golden.py
+gen_formats (np.int / np.float aliases restored for the import, nibabel.quaternions.mat2quat
+restated) on est.log files of two scenes whose gt.log / gt.info the reference itself holds; the
+last two tests compare formats.py with what it returned.  The first tests are known-answer
+checks of the Redwood protocol and an exact check of the est.log text layout of
+generic_reg_model.py:382-403."""
 import os
 
 import numpy as np
@@ -90,3 +93,62 @@ def test_registration_recall_protocol(tmp_path):
     errs = np.load(est_dir / 'scene_a' / 'errors.npy')
     assert errs[0] < 1e-12 and 0 < errs[1] <= 0.04 < errs[2] and np.isnan(errs[3])
     assert 'Mean precision: 0.667' in report and 'scene_a' not in report.split('\n')[0]
+
+
+# ---- pinned to the reference's own evaluator (oracle/gen_golden.py gen_formats) --------------------
+def _unpack_gt(tmp_path):
+    """tests/golden/3dmatch_gt/<scene>/gt.{log,info}.gz are the reference's data files
+    (src/datasets/3dmatch/benchmarks/3DMatch/<scene>/), stored as fixtures."""
+    import gzip
+    from conftest import GOLDEN as GOLDEN_DIR
+    from oracle.gen_golden import FORMAT_SCENES
+    gt_root = tmp_path / 'gt'
+    for scene in FORMAT_SCENES:
+        (gt_root / scene).mkdir(parents=True)
+        for name in ('gt.log', 'gt.info'):
+            with gzip.open(os.path.join(GOLDEN_DIR, '3dmatch_gt', scene, name + '.gz'), 'rb') as g:
+                (gt_root / scene / name).write_bytes(g.read())
+    return str(gt_root)
+
+
+def test_readers_parse_the_references_real_files_like_the_reference(tmp_path):
+    """read_trajectory / read_trajectory_info on real 3DMatch gt.log / gt.info files == what
+    benchmark_predator.py:82-153 returned for them in the dev container."""
+    from conftest import load_golden
+    from oracle.gen_golden import FORMAT_SCENES
+    g = load_golden('formats_3dmatch.npz')
+    gt_root = _unpack_gt(tmp_path)
+    for si, scene in enumerate(sorted(FORMAT_SCENES)):
+        keys, traj = formats.read_trajectory(os.path.join(gt_root, scene, 'gt.log'))
+        assert keys.tolist() == g[f'gt_keys{si}'].tolist()
+        assert np.array_equal(traj, g[f'gt_traj{si}'])
+        n_frag, info = formats.read_trajectory_info(os.path.join(gt_root, scene, 'gt.info'))
+        assert n_frag == int(g[f'n_frag{si}']) and np.array_equal(info, g[f'gt_info{si}'])
+
+
+def test_benchmark_matches_the_references_evaluator(tmp_path):
+    """formats.benchmark (and evaluate_registration, compute_transformation_error, write_est_log under
+    it) against benchmark_predator.benchmark (:285-375) run by the reference itself on the same
+    est.log files: exact, slightly and grossly perturbed, missing and consecutive pairs of two scenes.
+    Flags identical, per-pair errors to 1e-9 relative, recall and the printed report identical."""
+    from conftest import load_golden
+    from oracle.gen_golden import FORMAT_SCENES, write_formats_est
+    g = load_golden('formats_3dmatch.npz')
+    gt_root = _unpack_gt(tmp_path)
+    est_root = str(tmp_path / 'est')
+    write_formats_est(est_root, gt_root)
+    for si, scene in enumerate(sorted(FORMAT_SCENES)):            # our est.log, read back == the reference's reading
+        keys, traj = formats.read_trajectory(os.path.join(est_root, scene, 'est.log'))
+        assert keys.tolist() == g[f'est_keys{si}'].tolist() and np.array_equal(traj, g[f'est_traj{si}'])
+    report, recall = formats.benchmark(est_root, gt_root)
+    assert abs(recall - float(g['recall'])) < 1e-12
+    for si, scene in enumerate(sorted(FORMAT_SCENES)):
+        flags = np.load(os.path.join(est_root, scene, 'flag.npy'))
+        errors = np.load(os.path.join(est_root, scene, 'errors.npy'))
+        assert np.array_equal(flags, g[f'flags{si}'])
+        ref = g[f'errors{si}']
+        assert np.array_equal(np.isnan(errors), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        assert np.allclose(errors[ok], ref[ok], rtol=1e-9, atol=1e-15)
+        assert set(np.unique(flags)) == {0, 1, 2}                  # all three outcomes occur in the fixture
+    assert report == str(g['report'])

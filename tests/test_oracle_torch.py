@@ -174,3 +174,21 @@ def test_compute_loss_matches_reference(tag):
     assert np.allclose(losses["overlap_gt"].numpy(), g["overlap_gt"], atol=1e-6)
     for k in ("feature", "T", "overlap", "total"):
         assert abs(float(losses[k]) - float(g[f"loss_{k}"])) <= 2e-5 * max(1.0, abs(float(g[f"loss_{k}"]))), k
+
+
+def test_voxel_down_sample_oracle_known_answers():
+    """oracle.torch_oracle.voxel_down_sample (kitti_pred.py:12-14 / kiss-icp VoxelDownsample restated):
+    first point per voxel, voxel = trunc(p / size) toward zero, survivors in input order."""
+    from oracle.torch_oracle import voxel_down_sample
+    pts = np.array([[0.05, 0.05, 0.05],      # voxel (0, 0, 0)
+                    [0.29, 0.01, 0.0],       # (0, 0, 0) again -> dropped
+                    [-0.29, 0.0, 0.0],       # trunc toward zero: still (0, 0, 0) -> dropped
+                    [-0.31, 0.0, 0.0],       # (-1, 0, 0)
+                    [0.31, 0.0, 0.0],        # (1, 0, 0)
+                    [0.59, 0.29, -0.29],     # (1, 0, 0) -> dropped
+                    [0.6, 0.0, 0.0]],        # 0.6 / 0.3 = 2.0000000000000004 -> (2, 0, 0)
+                   dtype=np.float64)
+    out = voxel_down_sample(pts, 0.3)
+    assert out.tolist() == pts[[0, 3, 4, 6]].tolist()
+    f32 = pts.astype(np.float32)
+    assert voxel_down_sample(f32, 0.3).dtype == np.float32      # points are returned untouched
