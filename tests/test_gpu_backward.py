@@ -257,7 +257,9 @@ def test_parameter_gradients_match_the_reference(device, tag, which):
     factor 10 and hence one row of a weight gradient (a sum of a few hundred signed terms) by a
     few per cent -- tests/test_backward_conditioning.py shows the same jump inside the float64
     oracle itself.  Every operator's backward is checked separately
-    at 2e-5 above, where both sides see identical inputs."""
+    at 2e-5 above, where both sides see identical inputs, and the whole encoder entry by entry at
+    2e-5 with the decisions frozen in test_encoder_gradients_entrywise_with_frozen_decisions below --
+    the norm / RMS window here only covers what is left: the effect of the flips themselves."""
     g, model, losses = _train_step(tag, device, which)
     for k in ("feature", "T", "overlap", "total"):
         assert abs(float(losses[k].detach()) - float(g[f"loss_{k}"])) <= 5e-5 * max(1.0, abs(float(g[f"loss_{k}"])))
@@ -302,6 +304,82 @@ def test_parameter_gradients_match_the_reference(device, tag, which):
     # so the entry-wise count is not asserted there (norm and RMS bounds above still are)
     if tag != "3dmatch":
         assert enc_loose <= 0.5 * n_enc, f"{enc_loose} of {n_enc} encoder tensors deviate entrywise"
+
+
+@pytest.mark.parametrize("tag", ["3dmatch", "kitti", "modelnet"])
+def test_encoder_gradients_entrywise_with_frozen_decisions(device, tag):
+    """The KPConv encoder's parameter gradients ENTRY BY ENTRY at 1e-4, on all three configs, with
+    the discrete decisions frozen.
+
+    The reference-gradient test above can only bound encoder tensors by norm + RMS because a forward
+    difference of 1e-6 flips LeakyReLU branches / max-pool winners.  Here those decisions are taken
+    from OUR forward (sign of every activation the HIP path produced, arg-max neighbour of every
+    max-pool on our activations, our neighbour matrices) and replayed inside the float64 oracle
+    (oracle.torch_oracle.FrozenDecisions): both sides then differentiate the same smooth function,
+    an indexing or scatter error in spr_kpconv_bwd_dx / spr_instnorm_bwd / spr_maxpool_bwd would show
+    as an O(1) entry error, and every encoder tensor is held to 2e-5 of its scale entrywise (measured:
+    2.2e-6 / 3.5e-6 / 2.5e-6 on the three configs)."""
+    cfg = get_config(tag)
+    pairs, sizes = pairs_for(tag, 2)
+    model = RegTR(cfg)
+    synthetic.fill_parameters(model, seed=0)
+    model = model.to(device).train()
+    pts = [T(p[0][:n]).to(device) for p, (n, m) in zip(pairs, sizes)] + \
+          [T(p[1][:m]).to(device) for p, (n, m) in zip(pairs, sizes)]
+    meta = model.preprocessor(pts)
+    enc = model.kpf_encoder
+    # every LeakyReLU site of the encoder, in the oracle's call order: SimpleBlock output; per
+    # ResNet block unary1 (when present), batch_norm_conv, block output
+    acts, hooks = [], []
+    for blk in enc.encoder_blocks:
+        if hasattr(blk, 'unary1') and not isinstance(blk.unary1, torch.nn.Identity):
+            hooks.append(blk.unary1.register_forward_hook(lambda m, a, o: acts.append(o.detach())))
+        if hasattr(blk, 'batch_norm_conv'):
+            hooks.append(blk.batch_norm_conv.register_forward_hook(lambda m, a, o: acts.append(o.detach())))
+        hooks.append(blk.register_forward_hook(lambda m, a, o: acts.append(o.detach())))
+    block_in = []
+    for blk in enc.encoder_blocks:
+        hooks.append(blk.register_forward_pre_hook(lambda m, a: block_in.append(a[0].detach())))
+    x0 = torch.ones((meta['points'][0].shape[0], 1), device=device)
+    f, _ = enc(x0, meta)
+    for h in hooks:
+        h.remove()
+    G = synthetic.rand(tuple(f.shape), 77, -1.0, 1.0).to(device)
+    enc.zero_grad(set_to_none=True)
+    (f * G).sum().backward()
+    # ---- the same objective through the float64 oracle with our decisions ------------------------
+    meta64 = {'points': [p.double().cpu() for p in meta['points']],
+              'stack_lengths': [l.cpu() for l in meta['stack_lengths']],
+              'neighbors': [n.long().cpu() for n in meta['neighbors']],
+              'pools': [n.long().cpu() for n in meta['pools']]}
+    pool_args = []
+    for i, name in enumerate(cfg.architecture):
+        if 'strided' in name and 'resnetb' in name:
+            lvl = sum(1 for n in cfg.architecture[:i] if 'strided' in n or 'pool' in n)
+            xin = block_in[i].cpu()
+            x_ext = torch.cat((xin, torch.zeros_like(xin[:1])), 0)
+            pool_args.append(x_ext[meta64['pools'][lvl]].max(1)[1])       # first maximum, like spr_maxpool_bwd
+    sd = {k: v.detach().double().cpu().requires_grad_(v.requires_grad and 'kernel_points' not in k)
+          for k, v in model.state_dict(keep_vars=True).items() if k.startswith('kpf_encoder.')}
+    frozen = O.FrozenDecisions([a.cpu() > 0 for a in acts], pool_args)
+    f64, _ = O.encoder(cfg, sd, meta64, frozen=frozen)
+    assert frozen.i_mask == len(acts) and frozen.i_pool == len(pool_args)
+    assert float((f.detach().double().cpu() - f64.detach()).abs().max()) <= 2e-5 * float(f64.detach().abs().max())
+    (f64 * G.double().cpu()).sum().backward()
+    worst, n_checked = [], 0
+    for name, p in model.named_parameters():
+        if not name.startswith('kpf_encoder.') or not p.requires_grad:
+            continue
+        ref = sd[name].grad
+        assert p.grad is not None and ref is not None, name
+        err = float((p.grad.double().cpu() - ref).abs().max())
+        scale = max(float(ref.abs().max()), float(ref.norm()) / math.sqrt(ref.numel()), 1e-30)
+        worst.append((err / scale, name))
+        n_checked += 1
+    worst.sort(reverse=True)
+    print(f"{tag}: {n_checked} encoder tensors, worst entrywise deviations: " + ", ".join(f"{n} {e:.1e}" for e, n in worst[:3]))
+    assert n_checked >= 15
+    assert worst[0][0] <= 2e-5, f"{tag}: {worst[0][1]} deviates entrywise by {worst[0][0]:.2e}"
 
 
 def test_two_training_steps_match_the_reference_loop(device):

@@ -143,13 +143,17 @@ def test_config4_modelnet_shaped_batch256(device):
 
 
 # ---- float parity at (close to) full size: reference forwards run in the dev container ------------
-@pytest.mark.parametrize("case", ["c2", "c3", "c4"])
+@pytest.mark.parametrize("case", ["c2", "c3", "c3w", "c4"])
 def test_full_size_pose_and_features_match_the_reference(device, case):
     """BASELINE configs[2..4] against the reference itself at size (oracle/gen_golden.py gen_sized:
     one 20 000-pt 3DMatch-shaped pair; one LiDAR-like 120 000-pt pair pre-voxelised at 0.3 m --
     radial density ~ 1/r, ~2 k superpoints per cloud; eight ModelNet-shaped crops).
     Only summaries are stored: pose, level sizes / widths, statistics and the first rows of the
-    conditioned features, overlap scores, match weights, first matches."""
+    conditioned features, overlap scores, match weights, first matches.
+    c3w is the KITTI-sized pair with a WELL-conditioned pose solve (synthetic.make_lidar_translated_pair:
+    the target is a translated copy of the source, so even randomly initialised features match the true
+    correspondences): it is held at north_star's unrelaxed 1e-4.  The conditioning clause below applies
+    to the named case c3 only (random matches: the reference's own float32 SVD is the unstable step)."""
     from conftest import load_golden
     from oracle.gen_golden import sized_inputs
     g = load_golden(f"sized_{case}.npz")
@@ -177,8 +181,11 @@ def test_full_size_pose_and_features_match_the_reference(device, case):
             # weights the arg-max matches of the KITTI-scale pair (coordinates to 26 m, weights
             # ~1e-4) give a poorly conditioned covariance
             ref_dev = np.linalg.norm(g["pose"][b] - T64)
-            assert err < 1e-4 or (ref_dev > 1e-4 and err <= 1.5 * ref_dev), \
-                f"{case} pair {b}: pose error {err:.2e} (reference vs float64 solve: {ref_dev:.2e})"
+            if case == "c3":
+                assert err < 1e-4 or (ref_dev > 1e-4 and err <= 1.5 * ref_dev), \
+                    f"{case} pair {b}: pose error {err:.2e} (reference vs float64 solve: {ref_dev:.2e})"
+            else:
+                assert err < 1e-4, f"{case} pair {b}: pose error {err:.2e} (reference vs float64 solve: {ref_dev:.2e})"
         else:
             assert err < 1e-4, f"{case} pair {b}: pose error {err:.2e}"                 # north_star bound
         for side in ("src", "tgt"):
@@ -195,3 +202,49 @@ def test_full_size_pose_and_features_match_the_reference(device, case):
         assert v.shape[0] == int(vs[2]) and abs(v.mean() - vs[0]) <= 5e-3 * vs[0] and abs(v.max() - vs[1]) <= 5e-3 * vs[1]
         ind = out["ind_list"][b][:256].cpu().numpy()
         assert (ind == g[f"ind_head{b}"]).mean() >= 0.99
+
+
+def test_fp16_attention_mode_end_to_end_on_modelnet_batch256(device):
+    """BASELINE configs[4] names "fp16 MFMA attention": spr_set_attn_mode(2) (single-pass fp16 operands,
+    fp32 softmax and accumulation) END TO END on the config it exists for, with the accuracy it costs
+    stated as bounds:
+      * the 8 ModelNet-shaped pairs of golden sized_c4.npz (the reference's own forward at B = 8):
+        pose within 2e-3 Frobenius of the REFERENCE, conditioned features within 2e-3 of their scale
+        -- i.e. mode 2 does NOT meet north_star's 1e-4 pose bound and is an opt-in throughput mode;
+        the default (split) mode on the same pairs stays below 1e-4 (asserted here side by side);
+      * the full B = 256 batch against the default mode's poses: median deviation below 5e-4, 90 % of
+        the pairs below 5e-3, every pair below 5e-2 (the tail are crops whose weighted Kabsch solve is
+        poorly conditioned: a 1e-3 change of the match weights moves them by 1e-2), all rotations proper."""
+    from conftest import load_golden
+    from oracle.gen_golden import sized_inputs
+    cfg, model = _model('modelnet', device)
+    g = load_golden("sized_c4.npz")
+    _, pairs8 = sized_inputs('c4')
+    b8 = {"src_xyz": [torch.from_numpy(p[0]).to(device) for p in pairs8],
+          "tgt_xyz": [torch.from_numpy(p[1]).to(device) for p in pairs8]}
+    pairs = [synthetic.make_sphere_pair(1024, seed=100 + i) for i in range(256)]
+    b256 = {"src_xyz": [torch.from_numpy(p[0]).to(device) for p in pairs],
+            "tgt_xyz": [torch.from_numpy(p[1]).to(device) for p in pairs]}
+    try:
+        with torch.no_grad():
+            ops.set_attn_mode(1)
+            o8_split, o256_split = model(dict(b8)), model(dict(b256))
+            ops.set_attn_mode(2)
+            o8, o256 = model(dict(b8)), model(dict(b256))
+    finally:
+        ops.set_attn_mode(1)
+    worst_pose = worst_feat = worst_split = 0.0
+    for b in range(8):
+        worst_pose = max(worst_pose, float(np.linalg.norm(o8["pose"][b].cpu().numpy() - g["pose"][b])))
+        worst_split = max(worst_split, float(np.linalg.norm(o8_split["pose"][b].cpu().numpy() - g["pose"][b])))
+        for side in ("src", "tgt"):
+            f = o8[f"{side}_feat"][b][0][:16].cpu().numpy()
+            worst_feat = max(worst_feat, float(np.abs(f - g[f"{side}_feat_head{b}"]).max() / g[f"{side}_feat_stats{b}"][2]))
+    d256 = (o256["pose"] - o256_split["pose"]).flatten(1).norm(dim=1).cpu().numpy()
+    print(f"mode 2 vs reference (8 pairs): pose {worst_pose:.2e}, features {worst_feat:.2e} of scale "
+          f"(split mode: pose {worst_split:.2e}); B=256 vs split mode: max {d256.max():.2e}, p99 {np.percentile(d256, 99):.2e}, "
+          f"p90 {np.percentile(d256, 90):.2e}, median {np.median(d256):.2e}")
+    assert worst_split < 1e-4
+    assert worst_pose <= 2e-3 and worst_feat <= 2e-3
+    assert np.median(d256) <= 5e-4 and np.percentile(d256, 90) <= 5e-3 and d256.max() <= 5e-2
+    _check_poses(o256, 256)
