@@ -39,13 +39,16 @@ constexpr int kKP = 15;  // kernel points handled by the MFMA path (padded to 16
 // that the fused kernel fetches a neighbour's position and flag with ONE load.
 __global__ __launch_bounds__(256) void k_rowflag(const float* __restrict__ x, const float* __restrict__ s_xyz,
                                                  int ns, int cin, unsigned char* __restrict__ flag,
-                                                 float4* __restrict__ sxf) {
+                                                 float4* __restrict__ sxf, int* __restrict__ tile_ctr) {
   const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const int c4 = cin >> 2;
   // record ns = the shadow support point of the ring kernel: far away from everything (influence 0
   // on every kernel point), flag 0
-  if (blockIdx.x == 0 && threadIdx.x == 0) sxf[ns] = make_float4(-1.0e17f, -1.0e17f, -1.0e17f, __int_as_float(0));
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    sxf[ns] = make_float4(-1.0e17f, -1.0e17f, -1.0e17f, __int_as_float(0));
+    tile_ctr[0] = 0;   // the ring kernel's tile hand-out counter (same stream, next launch)
+  }
   if ((cin & 3) == 0 && c4 <= 64 && (c4 & (c4 - 1)) == 0) {
     // float4 per lane; a wave load covers 64 / c4 whole rows (1 KiB), kRfSteps loads in flight
     constexpr int kRfSteps = 4;
@@ -809,7 +812,7 @@ struct RingShape {
   static constexpr int WF_BYTES = 2 * kRingTQ * SH * 2;
   static constexpr int RED_BYTES = NG * (SPLIT - 1) * 4 * 64 * 4;
   static constexpr int RING_BYTES = 8 * NS * SLOT;
-  static constexpr int SMALL_BYTES = 2 * kRingTQ * 4 * 2;   // lcnt[2][16], lqid[2][16]
+  static constexpr int SMALL_BYTES = 2 * kRingTQ * 4 * 2 + 16;   // lcnt[2][16], lqid[2][16], ltile[4]
   // 32 -> 32 fits 128 VGPRs and (with NS = 3) 80 KB of LDS: two workgroups = 16 waves per CU
   static constexpr int MINW = (CC == 32 && COUT == 32) ? 4 : 2;   // waves per SIMD the register budget is cut for
   static_assert(NG * SPLIT == 8 && NS >= 3, "shape");
@@ -844,7 +847,7 @@ __global__ __launch_bounds__(512, (RingShape<CC, COUT, NS>::MINW)) void k_kpconv
     const float* __restrict__ kpts, float inv_extent, const float4* __restrict__ sxf,
     const int4* __restrict__ desc, int ntiles, const int* __restrict__ pad_word, int idxw,
     const float* __restrict__ x_parts, const float* __restrict__ w_parts, int n_xparts, int n_wparts,
-    float* __restrict__ out) {
+    int* __restrict__ tile_ctr, float* __restrict__ out) {
   typedef RingShape<CC, COUT, NS> S;
   constexpr int NTC = S::NTC, SH = S::SH, KS = S::KS, NG = S::NG, SPLIT = S::SPLIT, KSW = S::KSW;
   constexpr int RB = S::RB, LPR = S::LPR, RPP = S::RPP, PPI = S::PPI, DPI = S::DPI, SLOT = S::SLOT;
@@ -855,7 +858,8 @@ __global__ __launch_bounds__(512, (RingShape<CC, COUT, NS>::MINW)) void k_kpconv
   unsigned char* ring_all = lds_raw + S::WF_BYTES + S::RED_BYTES;       // [8][NS][SLOT]
   int* lcnt = (int*)(ring_all + S::RING_BYTES);                         // [2][16]
   int* lqid = lcnt + 2 * kRingTQ;                                       // [2][16]
-  int* idx_all = lqid + 2 * kRingTQ;                                    // [8][2 parity][2 queries][idxw]
+  int* ltile = lqid + 2 * kRingTQ;                                      // [4] tile hand-out (below)
+  int* idx_all = ltile + 4;                                             // [8][2 parity][2 queries][idxw]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -962,14 +966,28 @@ __global__ __launch_bounds__(512, (RingShape<CC, COUT, NS>::MINW)) void k_kpconv
 #ifdef SPR_KP_PRIO
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every issue arbitration otherwise
 #endif
+  // Tile walk: tiles are handed out by one device-wide counter (zeroed by k_rowflag ahead of this
+  // launch) instead of blockIdx + k * gridDim.  The kernel shares the chip with the pyramid builder and
+  // the shortcut branches of the same forward (other HIP streams): a workgroup that becomes resident
+  // late -- its CU was busy -- then simply takes fewer tiles, where a static partition made the whole
+  // launch wait for it.  A workgroup holds three tile indices at any time (current, next: gathers
+  // primed, after-next: index rows staged); wave 0 draws the following one during phase 1 and
+  // publishes it through LDS across barrier 2.  Outputs do not depend on the walk.
+  if (tid == 0) {
+    const int t0 = __hip_atomic_fetch_add(tile_ctr, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ltile[0] = t0;
+  }
+  __syncthreads();
+  int tile = __builtin_amdgcn_readfirstlane(ltile[0]);
+  int tile_nxt = tile + 1, tile_nn = tile + 2;
+  __syncthreads();
   int4 d_cur = make_int4(-1, -1, 0, 0), d_nxt = make_int4(-1, -1, 0, 0);
-  int tile = blockIdx.x;
   if (tile < ntiles) d_cur = desc[(size_t)tile * 8 + wave];
-  if (tile + (int)gridDim.x < ntiles) d_nxt = desc[(size_t)(tile + gridDim.x) * 8 + wave];
+  if (tile_nxt < ntiles) d_nxt = desc[(size_t)tile_nxt * 8 + wave];
   if (tile < ntiles) {
     stage_idx(d_cur, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tile + (int)gridDim.x < ntiles) stage_idx(d_nxt, 1);
+    if (tile_nxt < ntiles) stage_idx(d_nxt, 1);
     prime(d_cur, 0);
   }
 
@@ -999,14 +1017,17 @@ __global__ __launch_bounds__(512, (RingShape<CC, COUT, NS>::MINW)) void k_kpconv
       if (pend_n[r] >= 0) out[(size_t)pend_n[r] * COUT + ng * 16 + p16] = pend_v[r];
   };
   int par = 0;
-  for (; tile < ntiles; tile += gridDim.x, par ^= 1) {
+  for (; tile < ntiles; par ^= 1) {
     const int4 d = d_cur;
     KP_STAMP(1);
     const int n_items = d.z + d.w;
     // descriptor two tiles ahead (scalar load; its index rows are staged at the end of this phase 1)
     int4 d_nn = make_int4(-1, -1, 0, 0);
-    const bool has_nxt = tile + (int)gridDim.x < ntiles, has_nn = tile + 2 * (int)gridDim.x < ntiles;
-    if (has_nn) d_nn = desc[(size_t)(tile + 2 * gridDim.x) * 8 + wave];
+    const bool has_nxt = tile_nxt < ntiles, has_nn = tile_nn < ntiles;
+    if (has_nn) d_nn = desc[(size_t)tile_nn * 8 + wave];
+    // the tile after those: drawn now, used after barrier 2 (the value returns during the item loop)
+    int drawn = ntiles;
+    if (tid == 0 && has_nn) drawn = __hip_atomic_fetch_add(tile_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // ------------------------------ phase 1 --------------------------------
     // coordinates of the wave's two queries (scalar loads, issued here so that none sits in the item loop)
@@ -1033,86 +1054,94 @@ __global__ __launch_bounds__(512, (RingShape<CC, COUT, NS>::MINW)) void k_kpconv
     Ids ids_next = load_ids(par, NS);
     int i = 0;
     unsigned slot_off = 0;
-#pragma unroll 1
-    for (int sel = 0; sel < 2; ++sel) {
-      const int n_q = sel ? d.w : d.z;
-      if (n_q == 0) continue;
-      const float qx = sel ? qbx : qax, qy = sel ? qby : qay, qz = sel ? qbz : qaz;
-      f32x4 acc1[NTC];
+    // the query's weighted features -> wf row ql (split fp16), its neighbour count and id
+    auto flush = [&](const f32x4 (&acc)[NTC], int cnt, int ql, int qid) {
+      // C/D layout: row (kernel point) = 4*j4 + r, col = p16 <-> channels NTC*p16 + t
 #pragma unroll
-      for (int t = 0; t < NTC; ++t) acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      int cnt = 0;
-#pragma unroll 1
-      for (int b = 0; b < n_q; ++b) {
-        KP_STAMP(2);
-        const unsigned nslot = slot_off + SLOT == NS * SLOT ? 0u : slot_off + SLOT;
-        {   // k-step 0
-          const float dx = (R0.rec.x - qx) - kx, dy = (R0.rec.y - qy) - ky, dz = (R0.rec.z - qz) - kz;
-          const float w = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
-          cnt += __float_as_int(R0.rec.w);
-#ifndef SPR_KP_ABL_NOMFMA1
-#pragma unroll
-          for (int t = 0; t < NTC; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, R0.xv[t], acc1[t], 0, 0, 0);
-#else
-#pragma unroll
-          for (int t = 0; t < NTC; ++t) acc1[t][0] += w * R0.xv[t];
-#endif
+      for (int r = 0; r < 4; ++r) {
+        const int p = 4 * j4 + r;
+        typedef typename VecH<NTC>::type hv_t;
+        hv_t hh, ll;
+        if constexpr (NTC == 2) {
+          unsigned int hu, lu;
+          split_pk_s(acc[0][r], acc[1][r], sa, hu, lu);
+          hh = __builtin_bit_cast(hv_t, hu);
+          ll = __builtin_bit_cast(hv_t, lu);
+        } else {
+          typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+          unsigned int h0, l0, h1, l1;
+          split_pk_s(acc[0][r], acc[1][r], sa, h0, l0);
+          split_pk_s(acc[2][r], acc[3][r], sa, h1, l1);
+          hh = __builtin_bit_cast(hv_t, (u2_t){h0, h1});
+          ll = __builtin_bit_cast(hv_t, (u2_t){l0, l1});
         }
-        wait_item(i + 1);                   // (the last item of the tile: everything has landed)
-        R0 = ld_kstep(nslot, 0);
-        if (i + NS < n_items) issue_ids(slot_off, ids_next);   // refill the slot item i lived in
-        {   // k-step 1
-          const float dx = (R1.rec.x - qx) - kx, dy = (R1.rec.y - qy) - ky, dz = (R1.rec.z - qz) - kz;
-          const float w = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
-          cnt += __float_as_int(R1.rec.w);
-#ifndef SPR_KP_ABL_NOMFMA1
-#pragma unroll
-          for (int t = 0; t < NTC; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, R1.xv[t], acc1[t], 0, 0, 0);
-#else
-#pragma unroll
-          for (int t = 0; t < NTC; ++t) acc1[t][0] += w * R1.xv[t];
-#endif
-        }
-        R1 = ld_kstep(nslot, 1);
-        ids_next = load_ids(par, i + NS + 1);   // (past the tile's last item: unused ints of the buffer)
-        slot_off = nslot;
-        ++i;
-      }
-      // the query's weighted features -> wf row ql (split fp16), its neighbour count and id
-      {
-        const int ql = sel ? 15 - wave : wave;
-        // C/D layout: row (kernel point) = 4*j4 + r, col = p16 <-> channels NTC*p16 + t
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int p = 4 * j4 + r;
-          typedef typename VecH<NTC>::type hv_t;
-          hv_t hh, ll;
-          if constexpr (NTC == 2) {
-            unsigned int hu, lu;
-            split_pk_s(acc1[0][r], acc1[1][r], sa, hu, lu);
-            hh = __builtin_bit_cast(hv_t, hu);
-            ll = __builtin_bit_cast(hv_t, lu);
-          } else {
-            typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
-            unsigned int h0, l0, h1, l1;
-            split_pk_s(acc1[0][r], acc1[1][r], sa, h0, l0);
-            split_pk_s(acc1[2][r], acc1[3][r], sa, h1, l1);
-            hh = __builtin_bit_cast(hv_t, (u2_t){h0, h1});
-            ll = __builtin_bit_cast(hv_t, (u2_t){l0, l1});
-          }
-          if (p < kKP) {
-            *reinterpret_cast<hv_t*>(wfh + ql * SH + p * CC + NTC * p16) = hh;
-            *reinterpret_cast<hv_t*>(wfl + ql * SH + p * CC + NTC * p16) = ll;
-          }
-        }
-        int c = cnt;   // every lane of a 16-group saw the same records: one count per j4
-        c += __shfl_xor(c, 16, 64);
-        c += __shfl_xor(c, 32, 64);
-        if (lane == 0) {
-          lcnt[par * kRingTQ + ql] = c;
-          lqid[par * kRingTQ + ql] = sel ? d.y : d.x;
+        if (p < kKP) {
+          *reinterpret_cast<hv_t*>(wfh + ql * SH + p * CC + NTC * p16) = hh;
+          *reinterpret_cast<hv_t*>(wfl + ql * SH + p * CC + NTC * p16) = ll;
         }
       }
+      int c = cnt;   // every lane of a 16-group saw the same records: one count per j4
+      c += __shfl_xor(c, 16, 64);
+      c += __shfl_xor(c, 32, 64);
+      if (lane == 0) {
+        lcnt[par * kRingTQ + ql] = c;
+        lqid[par * kRingTQ + ql] = qid;
+      }
+    };
+    // One item = two k-steps.  `between` runs after the first k-step's MFMAs have been issued: the
+    // place where the previous query's flush goes, so that its conversions and LDS writes execute
+    // under the matrix pipe's work instead of behind its drain.
+    auto item = [&](f32x4 (&acc)[NTC], int& cnt, float qx, float qy, float qz, auto&& between) {
+      KP_STAMP(2);
+      const unsigned nslot = slot_off + SLOT == NS * SLOT ? 0u : slot_off + SLOT;
+      {   // k-step 0
+        const float dx = (R0.rec.x - qx) - kx, dy = (R0.rec.y - qy) - ky, dz = (R0.rec.z - qz) - kz;
+        const float w = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
+        cnt += __float_as_int(R0.rec.w);
+#ifndef SPR_KP_ABL_NOMFMA1
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, R0.xv[t], acc[t], 0, 0, 0);
+#else
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) acc[t][0] += w * R0.xv[t];
+#endif
+      }
+      wait_item(i + 1);                   // (the last item of the tile: everything has landed)
+      R0 = ld_kstep(nslot, 0);
+      if (i + NS < n_items) issue_ids(slot_off, ids_next);   // refill the slot item i lived in
+      between();
+      {   // k-step 1
+        const float dx = (R1.rec.x - qx) - kx, dy = (R1.rec.y - qy) - ky, dz = (R1.rec.z - qz) - kz;
+        const float w = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
+        cnt += __float_as_int(R1.rec.w);
+#ifndef SPR_KP_ABL_NOMFMA1
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, R1.xv[t], acc[t], 0, 0, 0);
+#else
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) acc[t][0] += w * R1.xv[t];
+#endif
+      }
+      R1 = ld_kstep(nslot, 1);
+      ids_next = load_ids(par, i + NS + 1);   // (past the tile's last item: unused ints of the buffer)
+      slot_off = nslot;
+      ++i;
+    };
+    auto nothing = [] {};
+    f32x4 accA[NTC], accB[NTC];
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) accA[t] = accB[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int cntA = 0, cntB = 0;
+#pragma unroll 1
+    for (int b = 0; b < d.z; ++b) item(accA, cntA, qax, qay, qaz, nothing);
+    if (d.w > 0) {
+      // query B's first item carries query A's flush (query A exists whenever B does)
+      item(accB, cntB, qbx, qby, qbz, [&] { flush(accA, cntA, wave, d.x); });
+#pragma unroll 1
+      for (int b = 1; b < d.w; ++b) item(accB, cntB, qbx, qby, qbz, nothing);
+      flush(accB, cntB, 15 - wave, d.y);
+    } else if (d.z > 0) {
+      flush(accA, cntA, wave, d.x);
     }
     KP_STAMP(3);
     // rows of this tile that hold no query (tail tile): mark them so that the epilogue skips them
@@ -1124,6 +1153,7 @@ __global__ __launch_bounds__(512, (RingShape<CC, COUT, NS>::MINW)) void k_kpconv
     // next tile are in LDS.  Stage those of the tile after it, then prime the ring with the next tile's
     // first items: they fly during phase 2, the barriers and the epilogue.
     if (sp == 0) flush_pending();
+    if (tid == 0) ltile[1 + par] = drawn;
     if (has_nn) stage_idx(d_nn, par);
     if (has_nxt) prime(d_nxt, par ^ 1);
     KP_STAMP(4);
@@ -1174,6 +1204,9 @@ __global__ __launch_bounds__(512, (RingShape<CC, COUT, NS>::MINW)) void k_kpconv
     KP_STAMP(8);
     d_cur = d_nxt;
     d_nxt = d_nn;
+    tile = tile_nxt;
+    tile_nxt = tile_nn;
+    tile_nn = __builtin_amdgcn_readfirstlane(ltile[1 + par]);   // published before barrier 1 of this tile
   }
   if (sp == 0) flush_pending();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1189,7 +1222,7 @@ template <int CC, int COUT, int NS>
 int launch_ring(const float* q_xyz, int nq, int ns, const int* nbr, int nbr_stride, int kmax, const float* x,
                 const _Float16* Wh, const _Float16* Wl, const float* kpts, float inv_extent, const float4* sxf,
                 const int4* desc, const int* pad_word, const float* x_parts, const float* w_parts, int n_xparts,
-                int n_wparts, float* out, hipStream_t stream) {
+                int n_wparts, int* tile_ctr, float* out, hipStream_t stream) {
   typedef RingShape<CC, COUT, NS> S;
   const int idxw = kmax <= 64 ? 64 : 128;
 #ifdef SPR_KP_RING_PROF
@@ -1207,7 +1240,7 @@ int launch_ring(const float* q_xyz, int nq, int ns, const int* nbr, int nbr_stri
   per_cu = per_cu < 1 ? 1 : (per_cu > S::MINW / 2 ? S::MINW / 2 : per_cu);
   const int grid = ntiles < n_cu * per_cu ? ntiles : n_cu * per_cu;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, q_xyz, ns, nbr, nbr_stride, kmax, x, Wh, Wl, kpts,
-                     inv_extent, sxf, desc, ntiles, pad_word, idxw, x_parts, w_parts, n_xparts, n_wparts, out);
+                     inv_extent, sxf, desc, ntiles, pad_word, idxw, x_parts, w_parts, n_xparts, n_wparts, tile_ctr, out);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -1318,6 +1351,7 @@ extern "C" int spr_kpconv_fwd_p(const float* q_xyz, int nq, const float* s_xyz, 
   float* x_parts = (float*)((char*)wl + align_up((size_t)32 * cin * cout * 2, 256));
   float* w_parts = x_parts + align_up(kAmaxParts * sizeof(float), 256) / sizeof(float);
   void* ws_plan = (char*)w_parts + align_up(kAmaxParts * sizeof(float), 256);
+  int* tile_ctr = (int*)((char*)ws_plan + spr_kpconv_plan_bytes(nq));
   SPR_REQUIRE(wplanes == nullptr || w_range != nullptr, "kpconv: prepared weight planes come with the range they were scaled by");
   if (wplanes != nullptr) {
     wh = (_Float16*)wplanes;
@@ -1337,7 +1371,7 @@ extern "C" int spr_kpconv_fwd_p(const float* q_xyz, int nq, const float* s_xyz, 
     const int c4 = cin >> 2;
     const bool wide = (cin & 3) == 0 && c4 <= 64 && (c4 & (c4 - 1)) == 0;
     const long waves = wide ? cdiv(ns, (64 / c4) * 4) : (long)ns;     // matches k_rowflag's two layouts
-    hipLaunchKernelGGL(k_rowflag, dim3(cdiv(waves * 64, 256)), dim3(256), 0, stream, x, s_xyz, ns, cin, flag, sxf);
+    hipLaunchKernelGGL(k_rowflag, dim3(cdiv(waves * 64, 256)), dim3(256), 0, stream, x, s_xyz, ns, cin, flag, sxf, tile_ctr);
   }
   SPR_LAUNCH_CHECK();
 
@@ -1369,7 +1403,7 @@ extern "C" int spr_kpconv_fwd_p(const float* q_xyz, int nq, const float* s_xyz, 
       const int* pad_word = (const int*)((const char*)plan + plan_desc_bytes(nq));
 #define SPR_RING_ARGS                                                                                       \
   q_xyz, nq, ns, nbr, nbr_stride, kmax, x, wh, wl, kernel_points, inv_extent, sxf, desc, pad_word, xp, wp, \
-      n_xp, n_wp, out, stream
+      n_xp, n_wp, tile_ctr, out, stream
       if (cin == 64 && cout == 64) return launch_ring<64, 64, SPR_KP_NS64>(SPR_RING_ARGS);
       if (cin == 64 && cout == 32) return launch_ring<64, 32, 4>(SPR_RING_ARGS);
       if (cin == 32 && cout == 32) return launch_ring<32, 32, 3>(SPR_RING_ARGS);
