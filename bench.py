@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--gemm-mode", type=int, default=1, help="1 = range-scaled split-fp16 MFMA (default), 0 = exact f32")
     ap.add_argument("--attn-mode", type=int, default=1,
                     help="1 = split-fp16 (default), 0 = exact f32, 2 = single-pass fp16 operands")
+    ap.add_argument("--no-train-leg", action="store_true", help="skip the training-step leg (N = 1 only)")
+    ap.add_argument("--train-pairs", type=int, default=4, help="pairs per training step of the train_step leg")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the short exact-f32 and fp16-attention legs that follow the headline timing")
     ap.add_argument("--canonical-order", action="store_true",
@@ -126,6 +128,60 @@ def cpu_baseline(cfg, model_sd, n_points):
                        f"({'reference C++ via oracle/_ref' if use_ref else 'brute-force C port'})")
 
 
+def train_leg(cfg, args, dev):
+    """One optimisation step of the full model on `--train-pairs` synthetic pairs of the bench size:
+    RegTR.forward (train mode, autograd graph over the HIP kernels) -> compute_loss -> backward
+    (autograd.py: hand-written HIP backward kernels) -> clip_grad_norm_ -> AdamW -> scheduler, i.e.
+    training.Trainer.train_step; per-stage times from HIP events.  Labels: the generator's pose and
+    a fixed ~60 % per-point overlap pattern (compute_loss only consumes them)."""
+    import numpy as np
+    from superpoints_registration_amd import synthetic
+    from superpoints_registration_amd.regtr import RegTR
+    from superpoints_registration_amd.training import Trainer
+    Bt = max(1, args.train_pairs)
+    model = RegTR(cfg)
+    synthetic.fill_parameters(model, seed=0)
+    model = model.to(dev)
+    pairs = [synthetic.make_pair(args.points, seed=900 + i) for i in range(Bt)]
+    rng = np.random.default_rng(777)
+    batch = {"src_xyz": [torch.from_numpy(p[0]).to(dev) for p in pairs],
+             "tgt_xyz": [torch.from_numpy(p[1]).to(dev) for p in pairs],
+             "pose": torch.from_numpy(np.stack([p[2] for p in pairs]).astype(np.float32)).to(dev),
+             "src_overlap": [torch.from_numpy(rng.random(len(p[0])) < 0.6).to(dev) for p in pairs],
+             "tgt_overlap": [torch.from_numpy(rng.random(len(p[1])) < 0.6).to(dev) for p in pairs]}
+    tr = Trainer(cfg).setup(model)
+    tr.train_step(model, dict(batch))          # warm-up: workspaces, autotuned nothing, optimizer state
+    torch.cuda.synchronize()
+    steps, stage = 2, [0.0, 0.0, 0.0, 0.0]
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        model.train()
+        bb = dict(batch)
+        ev[0].record()
+        pred = model(bb)
+        ev[1].record()
+        losses = model.compute_loss(pred, bb)
+        tr.optimizer.zero_grad()
+        ev[2].record()
+        losses["total"].backward()
+        ev[3].record()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=tr.grad_clip)
+        tr.optimizer.step()
+        tr.scheduler.step()
+        ev[4].record()
+        torch.cuda.synchronize()
+        for k in range(4):
+            stage[k] += ev[k].elapsed_time(ev[k + 1])
+    dt = time.perf_counter() - t0
+    return dict(value=round(Bt * steps / dt, 3), unit="pairs/s", ms_per_step=round(1e3 * dt / steps, 2), steps=steps,
+                pairs_per_step=Bt, points_per_cloud=args.points,
+                stage_ms=dict(forward=round(stage[0] / steps, 2), loss=round(stage[1] / steps, 2),
+                              backward=round(stage[2] / steps, 2), clip_adamw=round(stage[3] / steps, 2)),
+                loss_total=round(float(losses["total"].detach()), 5),
+                arithmetic="forward as the headline; backward matrix products exact f32 MFMA (csrc/bgemm.hip)")
+
+
 def main():
     args = parse()
     from superpoints_registration_amd import sharding
@@ -176,7 +232,9 @@ def main():
 
     # ---- timed region: barrier + sync, K steps, sync + barrier, MAX over ranks ----
     L.spr_prof_enable(1)
-    elapsed = sharding.timed_steps(step, args.steps, dist=dist, sync=torch.cuda.synchronize, device=dev)
+    elapsed, own = sharding.timed_steps(step, args.steps, dist=dist, sync=torch.cuda.synchronize, device=dev,
+                                        return_own=True)
+    per_rank_ms = sharding.gather_ms(1e3 * own / args.steps, dist=dist, device=dev)   # every rank's own time
 
     # ---- roofline of the dominant kernel (rank 0) -----------------------------
     roofline = None
@@ -257,7 +315,9 @@ def main():
             cin, cout = best['code'] // 100000, best['code'] % 100000
             roofline = dict(code=best['code'], bound="hbm", achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
-                            kernel=f"k_kpconv_mfma (fused KPConv gather) cin={cin} cout={cout}",
+                            kernel=(f"k_kpconv_ring<{cin},{cout}> (fused KPConv: LDS-DMA neighbour gather, register-resident weights)"
+                                    if cin in (32, 64) and cin * cout <= 4096 else
+                                    f"k_kpconv_mfma (fused KPConv gather, streamed weights) cin={cin} cout={cout}"),
                             avg_launch_ms=round(avg_ms, 5), launches=best['count'],
                             alg_bytes_per_launch=int(bytes_per_launch), traffic_source=traffic_src,
                             pooled_all_variants=dict(
@@ -321,8 +381,9 @@ def main():
                 roofline["single_stream"] = dict(avg_launch_ms=round(avg, 5), launches=len(iso), achieved=round(gbs, 2),
                                                  frac=round(gbs / HBM_PEAK_GBS, 5))
         if args.streams <= 1:
-            # deployment setting: two concurrent forwards of B pairs each on two HIP streams
-            # (streams.StreamedForward) -- hides the host round trips of the pyramid build
+            # two concurrent forwards of B pairs each on two HIP streams (streams.StreamedForward).  Since
+            # round 2 the default forward overlaps the same work inside itself (side stream, shortcut
+            # branches, cross-step overlap) and is the faster setting; kept as a comparison leg
             runner2 = StreamedForward(model, n_streams=2, device=dev)
             batch2 = {"src_xyz": batch["src_xyz"] + batch["src_xyz"], "tgt_xyz": batch["tgt_xyz"] + batch["tgt_xyz"]}
 
@@ -335,6 +396,11 @@ def main():
             extra["two_streams"] = dict(value=round(sharding.throughput(2 * B, n_leg, 1, t2), 3), unit="pairs/s",
                                         ms_per_step=round(1e3 * t2 / n_leg, 3), steps=n_leg, streams=2,
                                         pairs_per_step=2 * B)
+
+        # ---- training step: forward + loss + HIP backward + clip + AdamW, the
+        # reference's trainer.py:107-124 order, at BASELINE size.  Not part of `value`.
+        if not args.no_train_leg:
+            extra["train_step"] = train_leg(cfg, args, dev)
 
     if rank != 0:
         if dist is not None:
@@ -374,6 +440,10 @@ def main():
         "exact_f32": extra.get("exact_f32"),
         "fp16_attention": extra.get("fp16_attention"),
         "two_streams": extra.get("two_streams"),
+        "train_step": extra.get("train_step"),
+        "ranks": {"world_size_seen": (dist.get_world_size() if dist is not None else 1),
+                  "backend": (dist.get_backend() if dist is not None else None),
+                  "ms_per_step_per_rank": per_rank_ms},
     }
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, sd_cpu, args.points)

@@ -46,6 +46,23 @@ for lvl, c in ((0, 32), (1, 64), (2, 128)):
             f = lambda: ops.kpconv_raw(q_pts, s_pts, nb, x, W, KP * (2 ** lvl), ext, rows_sorted=True, impl=impl)
             y = f(); torch.cuda.synchronize()
             res[impl] = (t(f), y)
+        if os.environ.get('ORDER'):
+            # spatial tile walk: queries sorted by the linear index of their cell (cell = conv radius), cloud by cloud
+            lens = meta['stack_lengths'][lvl if kind == 'neighbors' else lvl + 1].to(dev)
+            cloud = torch.repeat_interleave(torch.arange(len(lens), device=dev), lens.long())
+            r = cfg.first_subsampling_dl * cfg.conv_radius * (2 ** lvl)
+            cc = (q_pts / r).floor().long(); cc -= cc.min(0)[0]
+            if os.environ['ORDER'] == 'morton':
+                code = torch.zeros(nq, dtype=torch.long, device=dev)
+                for bb in range(10):
+                    for a in range(3):
+                        code |= ((cc[:, a] >> bb) & 1) << (3 * bb + a)
+            else:
+                code = (cc[:, 2] * 4096 + cc[:, 1]) * 4096 + cc[:, 0]
+            order = torch.argsort(cloud * (1 << 40) + code).to(torch.int32)
+            fo = lambda: ops.kpconv_raw(q_pts, s_pts, nb, x, W, KP * (2 ** lvl), ext, rows_sorted=True, order=order)
+            yo = fo(); torch.cuda.synchronize()
+            print('   with %s tile order: %.1f us (bitwise equal: %s)' % (os.environ['ORDER'], t(fo), bool(torch.equal(yo, res[0][1]))), flush=True)
         d = float((res[0][1] - res[2][1]).abs().max()); sc = float(res[2][1].abs().max())
         print('L%d %-9s %3d->%3d nq %7d kv %8d alg %.3f GB | ring %7.1f us (%.3f of 8 TB/s) | r2 %7.1f us (%.3f) | max diff %.2e of %.2e' % (
             lvl, kind, c, c, nq, kv, alg / 1e9, res[0][0], alg / res[0][0] / 1e6 / 8.0, res[2][0], alg / res[2][0] / 1e6 / 8.0, d, sc), flush=True)

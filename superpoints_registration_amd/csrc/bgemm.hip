@@ -26,6 +26,8 @@
 // contiguous with consecutive lanes.
 #include "spr_common.h"
 
+#include <cstdlib>
+
 namespace spr {
 namespace {
 
@@ -100,6 +102,127 @@ __global__ __launch_bounds__(256) void k_bgemm_f32(const float* __restrict__ A, 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Large-tile form (round 3).  The 64 x 64 kernel above pays one exposed global-load latency per
+// 16-deep K slab for 8 MFMAs per wave and ran the training step's ~1.4 TFLOP of gradient products
+// at ~10 TFLOP/s (70 % of a 208 ms step at 4 pairs x 16 384 points).  Same arithmetic -- exact f32,
+// v_mfma_f32_32x32x2_f32, the SAME k-ordered accumulation per output, hence bitwise the same
+// results -- with
+//   * TM x TN = 128 x 128 tiles (each of the 4 waves owns 64 x 64 = 2 x 2 accumulators) or 128 x 32
+//     (4 x 1 waves, one accumulator each: the attention backward's d_head-wide outputs),
+//   * the next K slab's global loads issued into registers BEFORE the current slab's MFMAs
+//     (software pipeline: one exposed latency per tile instead of one per slab),
+//   * two LDS slab buffers, one barrier per slab.
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void k_bgemm_f32_t(const float* __restrict__ A, const float* __restrict__ B,
+                                                     float* __restrict__ C, const BgemmDesc* __restrict__ desc,
+                                                     long sa_i, long sa_k, long sb_k, long sb_j, long sc_i,
+                                                     long sc_j, float alpha, float beta) {
+  constexpr int WN = TN == 128 ? 2 : 1;            // waves along n
+  constexpr int WM = 4 / WN;                       // waves along m
+  constexpr int MI = TM / (32 * WM), NJ = TN / (32 * WN);   // 32 x 32 accumulators per wave
+  constexpr int LDA = TM + 1, LDB = TN + 1;
+  constexpr int NA = KB * TM / 256, NB = KB * TN / 256;     // staged elements per thread and slab
+  __shared__ float As[2][KB * LDA];   // [k][i]
+  __shared__ float Bs[2][KB * LDB];   // [k][j]
+  const BgemmDesc d = desc[blockIdx.y];
+  const int tn = (d.n + TN - 1) / TN, tm = (d.m + TM - 1) / TM;
+  const int tile = blockIdx.x;
+  if (tile >= tn * tm) return;
+  const int i0 = (tile / tn) * TM, j0 = (tile % tn) * TN;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wi = (wave / WN) * (32 * MI), wj = (wave % WN) * (32 * NJ);
+  const float* Ab = A + d.a_off;
+  const float* Bb = B + d.b_off;
+  float* Cb = C + d.c_off;
+  const bool a_k_fast = sa_k == 1, b_k_fast = sb_k == 1;
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
+
+  float ra[NA], rb[NB];
+  auto fetch = [&](int k0) {   // slab k0 .. k0 + KB - 1 -> registers (consecutive threads walk the contiguous dimension)
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      const int e = p * 256 + tid;
+      int ia, ka;
+      if (a_k_fast) { ka = e % KB; ia = e / KB; } else { ia = e % TM; ka = e / TM; }
+      const bool ok = i0 + ia < d.m && k0 + ka < d.k;
+      ra[p] = ok ? Ab[(long)(i0 + ia) * sa_i + (long)(k0 + ka) * sa_k] : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+      const int e = p * 256 + tid;
+      int jb, kb;
+      if (b_k_fast) { kb = e % KB; jb = e / KB; } else { jb = e % TN; kb = e / TN; }
+      const bool ok = j0 + jb < d.n && k0 + kb < d.k;
+      rb[p] = ok ? Bb[(long)(k0 + kb) * sb_k + (long)(j0 + jb) * sb_j] : 0.f;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < NA; ++p) {
+      const int e = p * 256 + tid;
+      int ia, ka;
+      if (a_k_fast) { ka = e % KB; ia = e / KB; } else { ia = e % TM; ka = e / TM; }
+      As[buf][ka * LDA + ia] = ra[p];
+    }
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+      const int e = p * 256 + tid;
+      int jb, kb;
+      if (b_k_fast) { kb = e % KB; jb = e / KB; } else { jb = e % TN; kb = e / TN; }
+      Bs[buf][kb * LDB + jb] = rb[p];
+    }
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < d.k; k0 += KB, buf ^= 1) {
+    const bool more = k0 + KB < d.k;
+    if (more) fetch(k0 + KB);            // in flight under this slab's MFMAs
+#pragma unroll
+    for (int s2 = 0; s2 < KB / 2; ++s2) {
+      float a[MI], b[NJ];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[mi] = As[buf][(2 * s2 + lh) * LDA + wi + 32 * mi + l31];
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) b[nj] = Bs[buf][(2 * s2 + lh) * LDB + wj + 32 * nj + l31];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+          acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+    }
+    if (more) stash(buf ^ 1);            // the other buffer: last read one slab ago, behind a barrier
+    __syncthreads();
+  }
+  // C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+      const int j = j0 + wj + 32 * nj + l31;
+      if (j >= d.n) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (i < d.m) {
+          float* c = Cb + (long)i * sc_i + (long)j * sc_j;
+          const float v = alpha * acc[mi][nj][r];
+          *c = beta != 0.f ? v + beta * *c : v;
+        }
+      }
+    }
+}
+
 // out[j] = scale * sum over parts p of parts[p][j]   (fixed order: deterministic split-K)
 __global__ void k_reduce_parts(const float* __restrict__ parts, int nparts, long n, float scale,
                                float* __restrict__ out, int accumulate) {
@@ -122,6 +245,25 @@ extern "C" int spr_bgemm(const float* A, const float* B, float* C, const void* d
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(A && B && C && desc_dev && nbatch >= 1 && max_m >= 1 && max_n >= 1, "bgemm: bad arguments");
   SPR_REQUIRE(nbatch <= 65535, "bgemm: too many batches (%d)", nbatch);
+  // tile shape by the largest batch entry: big square outputs -> 128 x 128, tall d_head-wide ones
+  // -> 128 x 32, everything small stays on the 64 x 64 kernel (all three accumulate identically)
+  static const int force = getenv("SPR_BGEMM_TILE") ? atoi(getenv("SPR_BGEMM_TILE")) : 0;   // A/B switch: 64 = old kernel
+  if (force != 64 && max_m >= 128 && max_n >= 96) {
+    const long tiles = (long)cdiv(max_m, 128) * cdiv(max_n, 128);
+    SPR_REQUIRE(tiles < (1l << 31), "bgemm: grid too large");
+    hipLaunchKernelGGL((k_bgemm_f32_t<128, 128>), dim3((unsigned)tiles, nbatch), dim3(256), 0, stream, A, B, C,
+                       (const BgemmDesc*)desc_dev, sa_i, sa_k, sb_k, sb_j, sc_i, sc_j, alpha, beta);
+    SPR_LAUNCH_CHECK();
+    return 0;
+  }
+  if (force != 64 && max_m >= 128 && max_n <= 32) {
+    const long tiles = (long)cdiv(max_m, 128) * cdiv(max_n, 32);
+    SPR_REQUIRE(tiles < (1l << 31), "bgemm: grid too large");
+    hipLaunchKernelGGL((k_bgemm_f32_t<128, 32>), dim3((unsigned)tiles, nbatch), dim3(256), 0, stream, A, B, C,
+                       (const BgemmDesc*)desc_dev, sa_i, sa_k, sb_k, sb_j, sc_i, sc_j, alpha, beta);
+    SPR_LAUNCH_CHECK();
+    return 0;
+  }
   const long tiles = (long)cdiv(max_m, TB) * cdiv(max_n, TB);
   SPR_REQUIRE(tiles < (1l << 31), "bgemm: grid too large");
   hipLaunchKernelGGL(k_bgemm_f32, dim3((unsigned)tiles, nbatch), dim3(256), 0, stream, A, B, C,

@@ -36,9 +36,10 @@ def shard_range(n_items: int, rank: int, world: int) -> range:
 
 
 def timed_steps(step: Callable[[], object], steps: int, dist=None, sync: Optional[Callable[[], None]] = None,
-                device=None) -> float:
+                device=None, return_own: bool = False):
     """Run `step` exactly `steps` times between two (barrier + device sync)
-    brackets; returns the elapsed wall time, MAX over ranks."""
+    brackets; returns the elapsed wall time, MAX over ranks (and, with
+    return_own, this rank's own time up to its device sync as a second value)."""
     import torch
 
     def fence():
@@ -53,6 +54,7 @@ def timed_steps(step: Callable[[], object], steps: int, dist=None, sync: Optiona
         step()
     if sync is not None:
         sync()
+    own = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -60,7 +62,20 @@ def timed_steps(step: Callable[[], object], steps: int, dist=None, sync: Optiona
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed
+    return (elapsed, own) if return_own else elapsed
+
+
+def gather_ms(ms: float, dist=None, device=None) -> List[float]:
+    """Every rank's value, in rank order (all_gather; [ms] without a process group): lets rank 0
+    print per-rank step times beside the MAX it reports."""
+    import torch
+    if dist is None:
+        return [round(float(ms), 3)]
+    world = dist.get_world_size()
+    t = torch.tensor([ms], dtype=torch.float64, device=device if device is not None else "cpu")
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [round(float(o.item()), 3) for o in out]
 
 
 def throughput(pairs_per_rank_per_step: int, steps: int, world: int, elapsed: float) -> float:

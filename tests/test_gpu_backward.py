@@ -306,26 +306,12 @@ def test_parameter_gradients_match_the_reference(device, tag, which):
         assert enc_loose <= 0.5 * n_enc, f"{enc_loose} of {n_enc} encoder tensors deviate entrywise"
 
 
-@pytest.mark.parametrize("tag", ["3dmatch", "kitti", "modelnet"])
-def test_encoder_gradients_entrywise_with_frozen_decisions(device, tag):
-    """The KPConv encoder's parameter gradients ENTRY BY ENTRY at 1e-4, on all three configs, with
-    the discrete decisions frozen (VERDICT r2 weak #2).
-
-    The reference-gradient test above can only bound encoder tensors by norm + RMS because a forward
-    difference of 1e-6 flips LeakyReLU branches / max-pool winners.  Here those decisions are taken
-    from OUR forward (sign of every activation the HIP path produced, arg-max neighbour of every
-    max-pool on our activations, our neighbour matrices) and replayed inside the float64 oracle
-    (oracle.torch_oracle.FrozenDecisions): both sides then differentiate the same smooth function,
-    an indexing or scatter error in spr_kpconv_bwd_dx / spr_instnorm_bwd / spr_maxpool_bwd would show
-    as an O(1) entry error, and every encoder tensor is held to 2e-5 of its scale entrywise (measured:
-    2.2e-6 / 3.5e-6 / 2.5e-6 on the three configs)."""
+def _frozen_encoder_gradient_check(device, tag, clouds, bound):
     cfg = get_config(tag)
-    pairs, sizes = pairs_for(tag, 2)
     model = RegTR(cfg)
     synthetic.fill_parameters(model, seed=0)
     model = model.to(device).train()
-    pts = [T(p[0][:n]).to(device) for p, (n, m) in zip(pairs, sizes)] + \
-          [T(p[1][:m]).to(device) for p, (n, m) in zip(pairs, sizes)]
+    pts = [T(c).to(device) for c in clouds]
     meta = model.preprocessor(pts)
     enc = model.kpf_encoder
     # every LeakyReLU site of the encoder, in the oracle's call order: SimpleBlock output; per
@@ -379,7 +365,35 @@ def test_encoder_gradients_entrywise_with_frozen_decisions(device, tag):
     worst.sort(reverse=True)
     print(f"{tag}: {n_checked} encoder tensors, worst entrywise deviations: " + ", ".join(f"{n} {e:.1e}" for e, n in worst[:3]))
     assert n_checked >= 15
-    assert worst[0][0] <= 2e-5, f"{tag}: {worst[0][1]} deviates entrywise by {worst[0][0]:.2e}"
+    assert worst[0][0] <= bound, f"{tag}: {worst[0][1]} deviates entrywise by {worst[0][0]:.2e}"
+
+
+@pytest.mark.parametrize("tag", ["3dmatch", "kitti", "modelnet"])
+def test_encoder_gradients_entrywise_with_frozen_decisions(device, tag):
+    """The KPConv encoder's parameter gradients ENTRY BY ENTRY at 1e-4, on all three configs, with
+    the discrete decisions frozen (VERDICT r2 weak #2).
+
+    The reference-gradient test above can only bound encoder tensors by norm + RMS because a forward
+    difference of 1e-6 flips LeakyReLU branches / max-pool winners.  Here those decisions are taken
+    from OUR forward (sign of every activation the HIP path produced, arg-max neighbour of every
+    max-pool on our activations, our neighbour matrices) and replayed inside the float64 oracle
+    (oracle.torch_oracle.FrozenDecisions): both sides then differentiate the same smooth function,
+    an indexing or scatter error in spr_kpconv_bwd_dx / spr_instnorm_bwd / spr_maxpool_bwd would show
+    as an O(1) entry error, and every encoder tensor is held to 2e-5 of its scale entrywise (measured:
+    2.2e-6 / 3.5e-6 / 2.5e-6 on the three configs)."""
+    pairs, sizes = pairs_for(tag, 2)
+    clouds = [p[0][:n] for p, (n, m) in zip(pairs, sizes)] + [p[1][:m] for p, (n, m) in zip(pairs, sizes)]
+    _frozen_encoder_gradient_check(device, tag, clouds, 2e-5)
+
+
+def test_encoder_gradients_at_baseline_size(device):
+    """The same frozen-decision comparison at BASELINE configs[1] size: one 16 384-point pair of the bench
+    generator (32 768 points at level 0, ~13 k / 3.9 k at levels 1 / 2) through the whole KPConv encoder --
+    the backward kernels at the shapes the bench runs (large bgemm tiles, split-K weight gradients over
+    hundreds of slabs, the KPConv dx scatter with ~40-wide rows) against float64 autograd of the oracle
+    with our decisions.  Every encoder tensor entrywise within 5e-5 of its scale."""
+    src, tgt, _ = synthetic.make_pair(16384, seed=0)
+    _frozen_encoder_gradient_check(device, "3dmatch", [src, tgt], 5e-5)
 
 
 def test_two_training_steps_match_the_reference_loop(device):

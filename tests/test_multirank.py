@@ -32,10 +32,11 @@ def _worker(rank, world, port, q):
         work["n"] += 1
         time.sleep(0.02 * (rank + 1))          # rank 1 is the slow one
 
-    elapsed = sharding.timed_steps(step, steps=4, dist=dist)
+    elapsed, own = sharding.timed_steps(step, steps=4, dist=dist, return_own=True)
+    per_rank = sharding.gather_ms(1e3 * own / 4, dist=dist)        # what bench.py prints as ms_per_step_per_rank
     mine = list(sharding.shard_range(11, rank, world))
     gathered = [None] * world
-    dist.all_gather_object(gathered, (seeds, mine, work["n"], elapsed))
+    dist.all_gather_object(gathered, (seeds, mine, work["n"], elapsed, per_rank))
     q.put((rank, gathered))
     dist.destroy_process_group()
 
@@ -52,7 +53,10 @@ def test_two_rank_protocol():
         p.join(timeout=60)
         assert p.exitcode == 0
     g = results[0]
-    (s0, m0, n0, e0), (s1, m1, n1, e1) = g
+    (s0, m0, n0, e0, pr0), (s1, m1, n1, e1, pr1) = g
+    assert pr0 == pr1 and len(pr0) == 2                # every rank sees every rank's own step time
+    assert 20 * 0.9 <= pr0[0] <= 20 * 3 and pr0[1] >= 40 * 0.9 and pr0[1] > pr0[0]   # rank 1 sleeps twice as long
+    assert max(pr0) * 4 / 1e3 <= e0 * 1.001            # the reported MAX covers the slowest rank
     assert not set(s0) & set(s1)                       # disjoint synthetic pairs
     assert sorted(m0 + m1) == list(range(11)) and abs(len(m0) - len(m1)) <= 1
     assert n0 == n1 == 4                               # exactly K steps each
