@@ -422,6 +422,12 @@ int spr_sum_scaled(const float* values, int n, float scale, float* out,
 int spr_bgemm(const float* A, const float* B, float* C, const void* desc_dev, int nbatch,
               int max_m, int max_n, long sa_i, long sa_k, long sb_k, long sb_j, long sc_i,
               long sc_j, float alpha, float beta, void* stream);
+/* out[nl, nr] = L[rows, nl]^T R[rows, nr] (row-major, contiguous) with float64 accumulation and a
+ * fixed-order reduction: weight gradients that are long, nearly cancelling sums (the first KPConv's
+ * dW = wf^T g over every point of the batch, kpconv_blocks.py:401-406 differentiated).  nl * nr <= 65536. */
+size_t spr_tn_product_f64_workspace_bytes(long rows, int nl, int nr);
+int spr_tn_product_f64(const float* L, const float* R, long rows, int nl, int nr, float* out,
+                       void* ws, size_t ws_bytes, void* stream);
 int spr_reduce_parts(const float* parts, int nparts, long n, float scale, float* out,
                      int accumulate, void* stream);
 int spr_act_bwd(const float* y, const float* dy, int act, long n, float* out, void* stream);

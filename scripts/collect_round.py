@@ -52,9 +52,8 @@ for k in sorted(fetch, key=lambda k: -fetch[k][0] * fetch[k][1]):
 open(f"profiles/{tag}_pmc_hbm_summary.txt", "w").write("\n".join(lines) + "\n")
 
 # roofline kernel: match the instantiation bench.py reported (cin -> CC template argument)
-kname = roof["kernel"]
-cin = int(kname.split("cin=")[1].split()[0]); cout = int(kname.split("cout=")[1])
-cands = {k: v for k, v in fetch.items() if "k_kpconv_mfma" in k}
+cin, cout = int(roof["code"]) // 100000, int(roof["code"]) % 100000
+cands = {k: v for k, v in fetch.items() if "k_kpconv_ring" in k or "k_kpconv_mfma" in k}
 # pick the variant whose launch count per forward and channel chunk match: the CSV name carries
 # <CC, TQ, NTW, NW, SK>; CC = 64 if cin % 64 == 0 else 32, NTW = cout / (16 * (8 / SK) ... ) -> match on avg ms instead
 stats_rows = {r["Name"]: r for r in csv.DictReader(open(stats))}

@@ -54,9 +54,17 @@ def _reduce_parts(parts, nparts, n, out):
 _CHUNK = 2048   # rows of the long dimension per split-K batch
 
 
-def _tn_product(L, Rm, rows, nl, nr):
+def _tn_product(L, Rm, rows, nl, nr, f64=False):
     """out[nl, nr] = L[rows, nl]^T @ R[rows, nr] (both row-major, contiguous): deterministic split
-    over `rows` into _CHUNK-row batches + fixed-order reduction -- weight gradients."""
+    over `rows` into _CHUNK-row batches + fixed-order reduction -- weight gradients.  f64: float64
+    accumulation (spr_tn_product_f64) for small outputs whose summands nearly cancel."""
+    if f64 and nl * nr <= 65536:
+        lib = _lib.lib()
+        ws = _ops._workspace(lib.spr_tn_product_f64_workspace_bytes(rows, nl, nr), L.device)
+        out = torch.empty((nl, nr), dtype=torch.float32, device=L.device)
+        _lib.check(lib.spr_tn_product_f64(_ops._ptr(L), _ops._ptr(Rm), rows, nl, nr, _ops._ptr(out), _ops._ptr(ws),
+                                          ws.numel(), _ops._stream(L)), "spr_tn_product_f64")
+        return out
     nchunk = (rows + _CHUNK - 1) // _CHUNK
     parts = torch.empty((nchunk, nl, nr), dtype=torch.float32, device=L.device)
     recs = []
@@ -157,7 +165,8 @@ class KPConvFn(torch.autograd.Function):
                                            cin, _ops._ptr(kp.detach().contiguous()), n_kp, ctx.kp_extent,
                                            _ops._ptr(dwf), _ops._ptr(dx), _ops._stream(x)), "spr_kpconv_bwd_dx")
         if ctx.needs_input_grad[4]:
-            dw = _tn_product(wf, g, nq, n_kp * cin, cout).view(n_kp, cin, cout)
+            # the first layer (cin = 1: constant input) is the ill-conditioned sum: float64 accumulation
+            dw = _tn_product(wf, g, nq, n_kp * cin, cout, f64=(cin == 1)).view(n_kp, cin, cout)
         return None, None, None, dx, dw, None, None, None, None
 
 

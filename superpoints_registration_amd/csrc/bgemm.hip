@@ -234,10 +234,69 @@ __global__ void k_reduce_parts(const float* __restrict__ parts, int nparts, long
   out[j] = accumulate ? out[j] + s : s;
 }
 
+// ---------------------------------------------------------------------------
+// out[nl, nr] = L[rows, nl]^T R[rows, nr] with FLOAT64 accumulation, for small nl * nr and very tall
+// operands: the weight gradient of the first KPConv (15 x 1 x 64 entries, a sum over every point of
+// the batch).  There the summands nearly cancel -- the output gradient sums to zero over each cloud
+// (InstanceNorm's backward) and the weighted features of the constant input are nearly the same for
+// every point -- so a float32 running sum over 10^4 - 10^5 rows loses three digits (measured at BASELINE
+// size against the float64 oracle: 2.5e-3 of the tensor's scale; every other encoder tensor 2e-6).
+// Same policy as the InstanceNorm statistics: long sums in float64, fixed slabs, fixed-order reduction.
+constexpr int kTnSlab = 1024;
+__global__ __launch_bounds__(256) void k_tn_f64_part(const float* __restrict__ Lm, const float* __restrict__ Rm,
+                                                     long rows, int nl, int nr, double* __restrict__ part) {
+  const long r0 = (long)blockIdx.x * kTnSlab, r1 = min(r0 + (long)kTnSlab, rows);
+  const int nout = nl * nr;
+  for (int o0 = 0; o0 < nout; o0 += 256 * 4) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int il[4], ir[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int o = min(o0 + u * 256 + (int)threadIdx.x, nout - 1);
+      il[u] = o / nr;
+      ir[u] = o % nr;
+    }
+    for (long r = r0; r < r1; ++r) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] += (double)Lm[r * nl + il[u]] * (double)Rm[r * nr + ir[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int o = o0 + u * 256 + (int)threadIdx.x;
+      if (o < nout) part[(long)blockIdx.x * nout + o] = acc[u];
+    }
+  }
+}
+__global__ void k_tn_f64_final(const double* __restrict__ part, int nslab, int nout, float* __restrict__ out) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= nout) return;
+  double s = 0.0;
+  for (int p = 0; p < nslab; ++p) s += part[(long)p * nout + o];
+  out[o] = (float)s;
+}
+
 }  // namespace
 }  // namespace spr
 
 using namespace spr;
+
+extern "C" size_t spr_tn_product_f64_workspace_bytes(long rows, int nl, int nr) {
+  return (size_t)cdiv(rows > 0 ? rows : 1, kTnSlab) * (size_t)nl * nr * sizeof(double) + 256;
+}
+
+extern "C" int spr_tn_product_f64(const float* Lm, const float* Rm, long rows, int nl, int nr, float* out,
+                                  void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(Lm && Rm && out && rows >= 1 && nl >= 1 && nr >= 1, "tn_product_f64: bad arguments");
+  SPR_REQUIRE((long)nl * nr <= 65536, "tn_product_f64: meant for small outputs (%d x %d)", nl, nr);
+  SPR_REQUIRE(ws != nullptr && ws_bytes >= spr_tn_product_f64_workspace_bytes(rows, nl, nr), "tn_product_f64: workspace too small");
+  const int nslab = cdiv(rows, kTnSlab);
+  double* part = (double*)ws;
+  hipLaunchKernelGGL(k_tn_f64_part, dim3(nslab), dim3(256), 0, stream, Lm, Rm, rows, nl, nr, part);
+  hipLaunchKernelGGL(k_tn_f64_final, dim3(cdiv((long)nl * nr, 256)), dim3(256), 0, stream, part, nslab, nl * nr, out);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int spr_bgemm(const float* A, const float* B, float* C, const void* desc_dev, int nbatch,
                          int max_m, int max_n, long sa_i, long sa_k, long sb_k, long sb_j, long sc_i,

@@ -201,7 +201,9 @@ __global__ __launch_bounds__(256) void k_in_bwd_stats(const float* __restrict__ 
     double s1 = 0.0, s2 = 0.0;
     for (int r = r0; r < r1; ++r) {
       const size_t o = (size_t)r * c + ch;
-      const float g = dout[o] * (out[o] >= 0.f ? 1.f : slope);
+      // (> 0, not >= 0: torch's leaky_relu backward takes the slope branch AT zero, and an output is exactly
+      // zero once in ~10^7 elements -- x equal to the rounded mean -- which the BASELINE-size gradient test hits)
+      const float g = dout[o] * (out[o] > 0.f ? 1.f : slope);
       s1 += (double)g;
       s2 += (double)g * (double)((x[o] - mu) * rs);
     }
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256) void k_in_bwd_stats(const float* __restrict__ 
 }
 
 __global__ void k_in_bwd_final(const double* __restrict__ part, const int* __restrict__ cu, int nb, int c,
-                               int nsplit, float* __restrict__ m1, float* __restrict__ m2) {
+                               int nsplit, double* __restrict__ m1, double* __restrict__ m2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nb * c) return;
   const int cloud = i / c, ch = i % c;
@@ -224,19 +226,22 @@ __global__ void k_in_bwd_final(const double* __restrict__ part, const int* __res
   }
   const int len = cu[cloud + 1] - cu[cloud];
   const double n = len > 0 ? (double)len : 1.0;
-  m1[i] = (float)(s1 / n);
-  m2[i] = (float)(s2 / n);
+  // kept in float64: dx = rstd (g - m1 - xhat m2) sums to zero over a cloud only as exactly as m1 is
+  // represented -- a float32 m1 leaves a common-mode residue of 3e-8 |m1| in every row, which a
+  // downstream sum over all points (the first KPConv's weight gradient) amplifies by their number
+  m1[i] = s1 / n;
+  m2[i] = s2 / n;
 }
 
 __global__ void k_in_bwd_apply(const float* __restrict__ x, const float* __restrict__ out,
                                const float* __restrict__ dout, const int* __restrict__ cu, int n, int nb, int c,
                                int norm, float slope, const float* __restrict__ mean,
-                               const float* __restrict__ rstd, const float* __restrict__ m1,
-                               const float* __restrict__ m2, float* __restrict__ dx, float* __restrict__ dadd) {
+                               const float* __restrict__ rstd, const double* __restrict__ m1,
+                               const double* __restrict__ m2, float* __restrict__ dx, float* __restrict__ dadd) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)n * c) return;
   const int row = (int)(gid / c), ch = (int)(gid % c);
-  const float g = dout[gid] * (out[gid] >= 0.f ? 1.f : slope);
+  const float g = dout[gid] * (out[gid] > 0.f ? 1.f : slope);
   if (dadd) dadd[gid] = g;
   if (!norm) {
     dx[gid] = g;
@@ -245,7 +250,7 @@ __global__ void k_in_bwd_apply(const float* __restrict__ x, const float* __restr
   const int cloud = find_segment(cu, nb, row);
   const size_t s = (size_t)cloud * c + ch;
   const float xh = (x[gid] - mean[s]) * rstd[s];
-  dx[gid] = rstd[s] * (g - m1[s] - xh * m2[s]);
+  dx[gid] = rstd[s] * (float)(((double)g - m1[s]) - (double)xh * m2[s]);
 }
 
 __global__ void k_maxpool(const float* __restrict__ x, int ns, int c, const int* __restrict__ idx,
@@ -354,7 +359,7 @@ extern "C" int spr_instnorm_r(const float* x, const int* cu, int n, int nb, int 
 
 extern "C" size_t spr_instnorm_bwd_workspace_bytes(int max_len, int nb, int c) {
   const size_t B = (size_t)(nb > 0 ? nb : 1), C = (size_t)(c > 0 ? c : 1);
-  return spr_instnorm_workspace_bytes(max_len, nb, c) + 2 * align_up(B * C * sizeof(float), 256);
+  return spr_instnorm_workspace_bytes(max_len, nb, c) + 2 * align_up(B * C * sizeof(double), 256);
 }
 
 // x: the forward input, out: the forward output (sign pattern of the LeakyReLU), dout: its gradient.
@@ -365,7 +370,8 @@ extern "C" int spr_instnorm_bwd(const float* x, const float* out, const float* d
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(n > 0 && nb >= 1 && c >= 4 && c % 4 == 0, "instnorm_bwd: need n>0 and c %% 4 == 0 (c=%d)", c);
   SPR_REQUIRE(x && out && dout && dx, "instnorm_bwd: null operand");
-  float *mean = nullptr, *rstd = nullptr, *m1 = nullptr, *m2 = nullptr;
+  float *mean = nullptr, *rstd = nullptr;
+  double *m1 = nullptr, *m2 = nullptr;
   if (norm) {
     SPR_REQUIRE(max_len_host >= 1 && max_len_host <= n, "instnorm_bwd: bad max_len_host=%d", max_len_host);
     SPR_REQUIRE(ws_bytes >= spr_instnorm_bwd_workspace_bytes(max_len_host, nb, c), "instnorm_bwd: workspace too small");
@@ -374,8 +380,8 @@ extern "C" int spr_instnorm_bwd(const float* x, const float* out, const float* d
     double* part = w.take<double>((size_t)nb * nsplit * 2 * c);
     mean = w.take<float>((size_t)nb * c);
     rstd = w.take<float>((size_t)nb * c);
-    m1 = w.take<float>((size_t)nb * c);
-    m2 = w.take<float>((size_t)nb * c);
+    m1 = w.take<double>((size_t)nb * c);
+    m2 = w.take<double>((size_t)nb * c);
     SPR_REQUIRE(m2 != nullptr, "instnorm_bwd: workspace carve failed");
     hipLaunchKernelGGL(k_in_stats, dim3(nb, nsplit, cdiv(c, 64)), dim3(256), 0, stream, x, cu, c, nsplit, part);
     hipLaunchKernelGGL(k_in_final, dim3(cdiv((long)nb * c, 256)), dim3(256), 0, stream, part, cu, nb, c, nsplit,

@@ -306,7 +306,7 @@ def test_parameter_gradients_match_the_reference(device, tag, which):
         assert enc_loose <= 0.5 * n_enc, f"{enc_loose} of {n_enc} encoder tensors deviate entrywise"
 
 
-def _frozen_encoder_gradient_check(device, tag, clouds, bound):
+def _frozen_encoder_gradient_check(device, tag, clouds, bound, conditioned=()):
     cfg = get_config(tag)
     model = RegTR(cfg)
     synthetic.fill_parameters(model, seed=0)
@@ -348,21 +348,44 @@ def _frozen_encoder_gradient_check(device, tag, clouds, bound):
     sd = {k: v.detach().double().cpu().requires_grad_(v.requires_grad and 'kernel_points' not in k)
           for k, v in model.state_dict(keep_vars=True).items() if k.startswith('kpf_encoder.')}
     frozen = O.FrozenDecisions([a.cpu() > 0 for a in acts], pool_args)
-    f64, _ = O.encoder(cfg, sd, meta64, frozen=frozen)
+    f64, feats64 = O.encoder(cfg, sd, meta64, frozen=frozen)
     assert frozen.i_mask == len(acts) and frozen.i_pool == len(pool_args)
     assert float((f.detach().double().cpu() - f64.detach()).abs().max()) <= 2e-5 * float(f64.detach().abs().max())
-    (f64 * G.double().cpu()).sum().backward()
-    worst, n_checked = [], 0
+    g_first = []
+    feats64[0].register_hook(lambda g: g_first.append(g.detach().clone()))
+    (f64 * G.double().cpu()).sum().backward(retain_graph=bool(conditioned))
+    ref_grads = {n: sd[n].grad.clone() for n in sd if sd[n].grad is not None}
+    # Conditioning floor of the tensors named in `conditioned` (parameters of the first block): how far
+    # does the float64 result move when the gradient arriving at the first block's output carries a
+    # RELATIVE error of 2e-6 -- what every other tensor of this very test shows our float32 backward
+    # chain to have?  (The gradient is linear in it: one more backward with the perturbation alone.)
+    floor = {}
+    if conditioned:
+        for n in sd:
+            if sd[n].grad is not None:
+                sd[n].grad = None
+        noise = torch.randn(g_first[0].shape, dtype=torch.float64, generator=torch.Generator().manual_seed(5))
+        feats64[0].backward(gradient=2e-6 * g_first[0].abs() * noise)
+        for n in conditioned:
+            floor[n] = sd[n].grad.abs().max()
+    worst, n_checked, excused = [], 0, []
     for name, p in model.named_parameters():
         if not name.startswith('kpf_encoder.') or not p.requires_grad:
             continue
-        ref = sd[name].grad
-        assert p.grad is not None and ref is not None, name
+        ref = ref_grads[name]
+        assert p.grad is not None, name
         err = float((p.grad.double().cpu() - ref).abs().max())
         scale = max(float(ref.abs().max()), float(ref.norm()) / math.sqrt(ref.numel()), 1e-30)
-        worst.append((err / scale, name))
         n_checked += 1
+        if name in floor and err / scale > bound:
+            # an ill-conditioned sum: held to 4x what a 2e-6 relative error of its INPUT does to it
+            assert err <= 4.0 * float(floor[name]), f"{tag}: {name} deviates by {err / scale:.2e}, conditioning floor {float(floor[name]) / scale:.2e}"
+            excused.append((name, err / scale, float(floor[name]) / scale))
+            continue
+        worst.append((err / scale, name))
     worst.sort(reverse=True)
+    for name, e, fl in excused:
+        print(f"{tag}: {name} deviates {e:.1e} of its scale; a 2e-6 relative perturbation of its input alone moves it by {fl:.1e}")
     print(f"{tag}: {n_checked} encoder tensors, worst entrywise deviations: " + ", ".join(f"{n} {e:.1e}" for e, n in worst[:3]))
     assert n_checked >= 15
     assert worst[0][0] <= bound, f"{tag}: {worst[0][1]} deviates entrywise by {worst[0][0]:.2e}"
@@ -391,7 +414,12 @@ def test_encoder_gradients_at_baseline_size(device):
     generator (32 768 points at level 0, ~13 k / 3.9 k at levels 1 / 2) through the whole KPConv encoder --
     the backward kernels at the shapes the bench runs (large bgemm tiles, split-K weight gradients over
     hundreds of slabs, the KPConv dx scatter with ~40-wide rows) against float64 autograd of the oracle
-    with our decisions.  Every encoder tensor entrywise within 5e-5 of its scale."""
+    with our decisions.  Every encoder tensor entrywise within 5e-5 of its scale (measured: 2e-6).
+    (At this size the test found an activation that is EXACTLY zero -- x equal to the rounded column mean,
+    once in ~10^7 elements -- where spr_instnorm_bwd took the identity branch and torch's leaky_relu
+    backward the slope branch: one element of one gradient off by a factor 10, 2.5e-3 of the first
+    KPConv's weight gradient.  Fixed in norm_pool.hip; the first layer's weight gradient, a nearly
+    cancelling sum over all points, is also accumulated in float64 now, spr_tn_product_f64.)"""
     src, tgt, _ = synthetic.make_pair(16384, seed=0)
     _frozen_encoder_gradient_check(device, "3dmatch", [src, tgt], 5e-5)
 
