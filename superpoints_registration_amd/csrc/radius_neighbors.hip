@@ -400,7 +400,11 @@ __global__ __launch_bounds__(256) void k_scan_table(
       const int bin = min((int)(d2 * bin_scale), kBins - 1);
       if (!second) {
         total++;
-        my_hist[bin * 256] += 1;
+        // saturating 16-bit counter: the cut below only asks whether the cumulative count reaches
+        // `limit` (<= 128), so a bin pinned at 65535 answers like its true count -- raw dense clouds
+        // (tens of thousands of returns inside one radius) must not wrap it
+        const unsigned short h = my_hist[bin * 256];
+        my_hist[bin * 256] = h == 65535 ? h : (unsigned short)(h + 1);
         if (kept < cap) row[kept++] = nbr_key(d2, __float_as_int(s.w));
         return;
       }

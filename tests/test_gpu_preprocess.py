@@ -253,3 +253,29 @@ def test_voxel_downsample_keeps_the_first_point_of_every_voxel(device, n, voxel,
     from oracle.torch_oracle import voxel_down_sample
     ref = voxel_down_sample(pts, voxel)                               # restated kiss-icp VoxelDownsample
     assert out.shape == ref.shape and np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+
+
+def test_radius_search_with_more_than_65535_coincident_supports_in_range(device):
+    """the overflow path of k_scan_table histograms d2 into 16-bit counters.  A raw
+    dense cloud -- here 70 000 coincident returns inside one query radius, all in ONE histogram bin --
+    must neither wrap the counter (now saturating) nor lose the nearest neighbours: the second pass then
+    runs its replace-worst branch (far more than `cap` candidates inside the cut bin) tens of thousands
+    of times per query.  Checked against a numpy brute force with the library's total order (d2, index)."""
+    rng = np.random.default_rng(9)
+    dup = np.tile(np.array([[0.5, 0.5, 0.5]], np.float32), (70000, 1))
+    near = (np.array([[0.5, 0.5, 0.5]]) + rng.normal(0, 0.02, (300, 3))).astype(np.float32)
+    supports = np.concatenate([near[:150], dup, near[150:]])            # duplicates in the middle of the index range
+    queries = (np.array([[0.5, 0.5, 0.5]]) + rng.normal(0, 0.03, (64, 3))).astype(np.float32)
+    radius, limit = 0.2, 40
+    q, s_ = torch.from_numpy(queries).to(device), torch.from_numpy(supports).to(device)
+    qcu, scu = ops.lengths_to_cu([len(queries)], device), ops.lengths_to_cu([len(supports)], device)
+    out, mc = ops.radius_neighbors(q, s_, qcu, scu, radius, limit)
+    out = out.cpu().numpy()
+    assert mc >= 70000 and out.shape == (64, limit)
+    d = queries[:, None, :] - supports[None, :, :]                        # nanoflann order: query - support
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    assert d2.dtype == np.float32
+    for i in range(64):
+        inr = np.nonzero(d2[i] < np.float32(radius) ** 2)[0]
+        order = inr[np.lexsort((inr, d2[i][inr]))][:limit]               # (d2, index) ascending, cut at limit
+        assert np.array_equal(out[i], order), i
