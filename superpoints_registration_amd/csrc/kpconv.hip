@@ -146,6 +146,14 @@ __global__ void k_kpconv_simple(const float* __restrict__ q_xyz, int nq,
   out[(size_t)n * cout + o] = acc / (float)max(cnt, 1);
 }
 
+// Support records for the Cin == 1 kernel: {x, y, z, feature} in one 16-byte load per neighbour
+// instead of three coordinate loads and a feature load.
+__global__ __launch_bounds__(256) void k_records_cin1(const float* __restrict__ x, const float* __restrict__ s_xyz,
+                                                      int ns, float4* __restrict__ sxf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ns) sxf[i] = make_float4(s_xyz[3 * (size_t)i], s_xyz[3 * (size_t)i + 1], s_xyz[3 * (size_t)i + 2], x[i]);
+}
+
 // ---------------------------------------------------------------------------
 // Cin == 1 (first block: features are a column of ones, qk_regtr_full.py:157).
 // A wave owns 16 queries.  Lane (q = lane & 15, g = lane >> 4) accumulates the
@@ -156,7 +164,7 @@ __global__ void k_kpconv_simple(const float* __restrict__ q_xyz, int nq,
 __global__ __launch_bounds__(256) void k_kpconv_cin1(
     const float* __restrict__ q_xyz, int nq, const float* __restrict__ s_xyz, int ns,
     const int* __restrict__ nbr, int nbr_stride, int kmax, int rows_sorted,
-    const float* __restrict__ x, const float* __restrict__ W, int cout,
+    const float4* __restrict__ sxf, const float* __restrict__ W, int cout,
     const float* __restrict__ kpts, int n_kp, float inv_extent, float* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qv = lane & 15, g = lane >> 4;
@@ -182,9 +190,10 @@ __global__ __launch_bounds__(256) void k_kpconv_cin1(
     const bool ok = idx >= 0 && idx < ns;
     if (rows_sorted && __ballot(ok) == 0ull) break;   // only trailing shadow entries left
     const size_t id = ok ? (size_t)idx : 0;
-    const float xv = ok ? x[id] : 0.f;
+    const float4 rec = sxf[id];          // {x, y, z, feature}: one 16-byte load (the four kernel-point groups of a query share it)
+    const float xv = ok ? rec.w : 0.f;
     cnt += xv > 0.f ? 1 : 0;
-    const float rx = s_xyz[3 * id] - qx, ry = s_xyz[3 * id + 1] - qy, rz = s_xyz[3 * id + 2] - qz;
+    const float rx = rec.x - qx, ry = rec.y - qy, rz = rec.z - qz;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const float dx = rx - kx[s], dy = ry - ky[s], dz = rz - kz[s];
@@ -1360,9 +1369,10 @@ extern "C" int spr_kpconv_fwd_p(const float* q_xyz, int nq, const float* s_xyz, 
   const float inv_extent = 1.0f / kp_extent;
 
   if (cin == 1 && (impl == 0 || impl == 2) && n_kp <= 16) {
+    hipLaunchKernelGGL(k_records_cin1, dim3(cdiv(ns, 256)), dim3(256), 0, stream, x, s_xyz, ns, sxf);
     ProfScope prof(stream, cin * 100000 + cout, nq);
     hipLaunchKernelGGL(k_kpconv_cin1, dim3(cdiv(nq, 64)), dim3(256), 0, stream, q_xyz, nq, s_xyz, ns, nbr,
-                       nbr_stride, kmax, rows_sorted, x, weights, cout, kernel_points, n_kp, inv_extent, out);
+                       nbr_stride, kmax, rows_sorted, sxf, weights, cout, kernel_points, n_kp, inv_extent, out);
     SPR_LAUNCH_CHECK();
     return 0;
   }

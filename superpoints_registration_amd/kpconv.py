@@ -239,6 +239,10 @@ class Preprocessor(nn.Module):
                 return
             meta['_i32'][(key, level)] = idx
             meta[key].append(idx)                 # converted to index_dtype on first read
+            if key != 'upsamples':                # conv / pool matrices feed KPConvs: tile plan built here, off the main stream
+                ops.kpconv_plan_prefetch(idx, plan_ns[0])
+
+        plan_ns = [0]                             # supports of the matrices being published (= points of the current level)
 
         def open_level(l, points, lens_host, cu):
             meta['points'].append(points)
@@ -250,6 +254,7 @@ class Preprocessor(nn.Module):
         open_level(0, points, lens_host, cu)
         for l, lv in enumerate(levels):
             conv = pool = up = None
+            plan_ns[0] = points.shape[0]
             if lv.has_conv:
                 conv, _ = ops.radius_neighbors(points, points, cu, cu, lv.radius, lv.limit)
             publish('neighbors', l, conv)

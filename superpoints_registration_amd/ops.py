@@ -315,6 +315,17 @@ def _kpconv_plan(nbr: torch.Tensor, nq: int, ns: int, stride: int, kmax: int, ro
     return plan
 
 
+def kpconv_plan_prefetch(nbr: torch.Tensor, ns: int, rows_sorted: bool = True) -> None:
+    """Builds (and caches on the tensor) the ring KPConv's tile plan of a neighbour matrix on the CURRENT
+    stream: the pyramid builder calls it right behind each radius search on its side stream, so the plan
+    kernel runs beside the encoder instead of in front of the first convolution that uses the matrix."""
+    if nbr is None or not nbr.is_cuda or nbr.dtype != torch.int32 or nbr.dim() != 2 or nbr.shape[1] < 1:
+        return
+    if nbr.stride(1) != 1 or nbr.shape[1] > 128 or nbr.shape[0] < 1:
+        return
+    _kpconv_plan(nbr, nbr.shape[0], int(ns), int(nbr.stride(0)), nbr.shape[1], bool(rows_sorted))
+
+
 def _kpconv_wplanes(weights: torch.Tensor, wr: torch.Tensor, wr_n: int) -> torch.Tensor:
     """Split-fp16 fragment-order planes of a KPConv weight tensor (spr_kpconv_prep_weights), cached per
     weight version next to its range."""
