@@ -262,8 +262,9 @@ __global__ __launch_bounds__(256) void k_grid_dims(const float* __restrict__ xyz
   }
 }
 
-__global__ void k_grid_offsets(GridCloud* info, int nb, long long cap, int* err) {
+__global__ void k_grid_offsets(GridCloud* info, int nb, long long cap, int* err, int* max_count) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  *max_count = 0;   // (k_scan_table raises it with atomicMax: zeroed here instead of by a memset node)
   long long off = 0;
   for (int c = 0; c < nb; ++c) {
     info[c].off = off;
@@ -561,6 +562,7 @@ extern "C" size_t spr_radius_neighbors_workspace_bytes(int nq, int ns, int nb) {
   b += align_up(sizeof(GridCloud) * B, 256);
   b += 3 * align_up(4 * (cap + 1), 256);  // count, start, cursor
   b += align_up(4 * N, 256);              // cell_of
+  b += 256;                               // error flags of the cell-table path (zeroed together with count and cursor)
   b += scan_temp_bytes(cap + 1);
   const size_t Q = (size_t)(nq > 0 ? nq : 1);
   b += align_up(8 * Q * 128, 256);        // unsorted (d2, id) key rows, nbr_row_cap(limit) <= 128
@@ -596,23 +598,24 @@ extern "C" int spr_radius_neighbors(const float* q_xyz, const int* q_cu, int nq,
   const float cell = radius * (1.0f + 1.0f / 256.0f);
   const float inv_cell = 1.0f / cell;
 
-  SPR_HIP_CHECK(hipMemsetAsync(err, 0, 16 * sizeof(int), stream));
-  SPR_HIP_CHECK(hipMemsetAsync(max_count, 0, sizeof(int), stream));
   const int TB = 256;
   if (algo == 0) {
+    // one memset node for everything this path needs zeroed: error flags, cell counts, scatter cursors
+    // (carved back to back); max_count is zeroed by k_grid_offsets.  (Four memsets per search were
+    // 28 of the 53 fill kernels of a forward.)
     const size_t cap = table_cap_cells(ns);
-    GridCloud* ginfo = w.take<GridCloud>(nb);
+    err = w.take<int>(64);
     int* count = w.take<int>(cap + 1);
-    int* start = w.take<int>(cap + 1);
     int* cursor = w.take<int>(cap + 1);
+    GridCloud* ginfo = w.take<GridCloud>(nb);
+    int* start = w.take<int>(cap + 1);
     int* cell_of = w.take<int>(N);
     const size_t stemp_bytes = scan_temp_bytes(cap + 1);
     void* stemp = w.take<char>(stemp_bytes);
     SPR_REQUIRE(stemp != nullptr, "radius_neighbors: workspace carve failed (table)");
-    SPR_HIP_CHECK(hipMemsetAsync(count, 0, (cap + 1) * sizeof(int), stream));
-    SPR_HIP_CHECK(hipMemsetAsync(cursor, 0, (cap + 1) * sizeof(int), stream));
+    SPR_HIP_CHECK(hipMemsetAsync(err, 0, (size_t)((char*)(cursor + cap + 1) - (char*)err), stream));
     hipLaunchKernelGGL(k_grid_dims, dim3(nb), dim3(256), 0, stream, s_xyz, s_cu, inv_cell, ginfo, err);
-    hipLaunchKernelGGL(k_grid_offsets, dim3(1), dim3(64), 0, stream, ginfo, nb, (long long)cap, err);
+    hipLaunchKernelGGL(k_grid_offsets, dim3(1), dim3(64), 0, stream, ginfo, nb, (long long)cap, err, max_count);
     hipLaunchKernelGGL(k_cell_count, dim3(cdiv(ns, TB)), dim3(TB), 0, stream, s_xyz, s_cu, ns, nb,
                        inv_cell, ginfo, err, count, cell_of);
     SPR_LAUNCH_CHECK();
@@ -637,6 +640,8 @@ extern "C" int spr_radius_neighbors(const float* q_xyz, const int* q_cu, int nq,
     SPR_LAUNCH_CHECK();
     return 0;
   }
+  SPR_HIP_CHECK(hipMemsetAsync(err, 0, 16 * sizeof(int), stream));
+  SPR_HIP_CHECK(hipMemsetAsync(max_count, 0, sizeof(int), stream));
   hipLaunchKernelGGL(k_min, dim3(nb), dim3(256), 0, stream, s_xyz, s_cu, info);
   hipLaunchKernelGGL(k_cellkeys, dim3(cdiv(ns, TB)), dim3(TB), 0, stream, s_xyz, s_cu, ns, nb,
                      inv_cell, info, keys, vals, err);
