@@ -124,6 +124,35 @@ int spr_instnorm(const float* x, const int* cu, int n, int nb, int max_len_host,
                  int c, float eps, int norm, const float* add, float slope,
                  float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- a5: tail of a ResNet bottleneck block, fused -----------------------------
+ * Replaces the last three statements of ResnetBottleneckBlock.forward
+ * (kpconv_blocks.py:733-741): unary2 (Linear without bias -> per-cloud
+ * InstanceNorm, :556-561), unary_shortcut (the same, or the identity) and
+ * leaky_relu(x + shortcut):
+ *   out = lrelu(IN(xa wa^T) + (kb > 0 ? IN(xb wb^T) : add), slope)
+ * xa [n,ka], wa [n_out,ka]; xb [n,kb], wb [n_out,kb] (kb = 0: xb = wb = NULL and
+ * add [n,n_out] or NULL is added instead); cu [nb+1].  The projections are computed
+ * twice (statistics pass, output pass) and never written: only `out` goes to memory.
+ * Split-fp16 product mode only (spr_set_gemm_mode(1)); ranges as in spr_linear_r
+ * (NULL: measured here); out_range as in spr_instnorm_r.
+ * spr_block_tail_tile_rows: rows per statistics tile of a supported (ka, kb, n_out), 0 if
+ * the shape has no kernel (the caller then uses spr_linear_r + spr_instnorm_r);
+ * spr_block_tail_tiles: the tile table of a batch (int32 [spr_block_tail_tiles_len], 16-byte
+ * aligned): the exclusive prefix of ceil(len / tile_rows) per cloud and one {first row, valid
+ * rows, cloud} record per tile -- tiles start at each cloud's first row, so a cloud's result
+ * never depends on its batch mates.  Depends on cu and tile_rows only: build once per level.
+ */
+int spr_block_tail_tile_rows(int ka, int kb, int n_out);
+size_t spr_block_tail_tiles_len(int n, int nb, int tile_rows);
+int spr_block_tail_tiles(const int* cu, int n, int nb, int tile_rows, int* tiles, void* stream);
+size_t spr_block_tail_workspace_bytes(int n, int nb, int kb, int n_out, int tile_rows);
+int spr_block_tail(const float* xa, int ka, const float* wa, const float* xb, int kb,
+                   const float* wb, const float* add, const int* cu, const int* tiles, int n,
+                   int nb, int n_out, float eps, float slope, float* out,
+                   const float* xa_range, int xa_range_n, const float* wa_range, int wa_range_n,
+                   const float* xb_range, int xb_range_n, const float* wb_range, int wb_range_n,
+                   float* out_range, int out_range_n, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- a5: strided max pooling ----------------------------------------------
  * Replaces max_pool(x, inds) (kpconv_blocks.py:127-143): max over the pooling
  * neighbours, shadow index ns reads a zero row.  idx [nq, idx_stride], first

@@ -1,9 +1,10 @@
-import csv, sys, glob
-f = sys.argv[1]
-nfwd = float(sys.argv[2]) if len(sys.argv) > 2 else 7
-rows = list(csv.DictReader(open(f)))
-tot = sum(int(r['TotalDurationNs']) for r in rows)
-print(f'total kernel ms {tot/1e6:.2f}; per forward {tot/1e6/nfwd:.2f} ms')
-for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 22]:
-    n = r['Name'].replace('spr::(anonymous namespace)::', '').replace('void ', '')
-    print(f"{n[:58]:58s} calls {int(r['Calls']):5d} tot {int(r['TotalDurationNs'])/1e6:8.2f} ms avg {float(r['AverageNs'])/1e3:8.1f} us {float(r['Percentage']):5.1f}%")
+"""Prints the top rows of a rocprofv3 kernel_stats.csv found under a directory: name, calls, average us, total ms."""
+import csv, glob, sys
+d = sys.argv[1]; top = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+div = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
+fs = sorted(glob.glob(d + "/**/*kernel_stats.csv", recursive=True), key=lambda f: -sum(1 for _ in open(f)))
+rows = list(csv.DictReader(open(fs[0])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print("total %.3f ms (/%g = %.3f)" % (tot / 1e6, div, tot / 1e6 / div))
+for r in rows[:top]:
+    print("%-110s %6s %9.1f us %8.3f ms" % (r["Name"][:110], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6 / div))

@@ -48,6 +48,12 @@ SIGNATURES = {
     "spr_kpconv_fwd_p": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp,
                               _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "spr_instnorm_r": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _f, _vp, _vp, _i, _vp, _sz, _vp]),
+    "spr_block_tail_tile_rows": (_i, [_i, _i, _i]),
+    "spr_block_tail_tiles_len": (_sz, [_i, _i, _i]),
+    "spr_block_tail_tiles": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "spr_block_tail_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "spr_block_tail": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _i, _vp, _i,
+                            _vp, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
     "spr_maxpool_gather_r": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "spr_layernorm_range_count": (_i, [_i]),
     "spr_layernorm_r": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),

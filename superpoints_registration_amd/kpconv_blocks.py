@@ -264,15 +264,23 @@ class ResnetBottleneckBlock(nn.Module):
             neighb_inds = _idx_of(batch, 'neighbors', li)
             stack_lengths_post, cu_post, ml_post = batch['stack_lengths'][li], _cu_of(batch, li), ml_pre
 
+        strided = 'strided' in self.block_name
+        projected = isinstance(self.unary_shortcut, UnaryBlock)
+        # Inference: unary2, the shortcut projection, both norms, the add and the LeakyReLU are ONE fused
+        # operator that never writes the un-normalised projections (ops.block_tail; csrc/block_tail.hip).
+        mid = self.unary2.in_dim
+        fused = (features.is_cuda and not torch.is_grad_enabled() and self.use_bn
+                 and ops.block_tail_tile_rows(mid, self.in_dim if projected else 0, self.out_dim) > 0)
+
         def shortcut_branch():
-            sc = max_pool(features, neighb_inds) if 'strided' in self.block_name else features
-            if isinstance(self.unary_shortcut, UnaryBlock):
+            sc = max_pool(features, neighb_inds) if strided else features
+            if projected and not fused:
                 sc = self.unary_shortcut(sc, stack_lengths_post, cu=cu_post, max_len=ml_post)
             return sc
 
         # The shortcut branch (max-pool gather, projection, norm) depends on the block input only:
         # in inference it runs on its own stream beside unary1 -> KPConv -> norm and joins at unary2.
-        has_work = 'strided' in self.block_name or isinstance(self.unary_shortcut, UnaryBlock)
+        has_work = strided or (projected and not fused)
         fork = (has_work and features.is_cuda and not torch.is_grad_enabled()
                 and _concurrency.active(features.device))
         if fork:
@@ -298,6 +306,12 @@ class ResnetBottleneckBlock(nn.Module):
             shortcut.record_stream(main)
         else:
             shortcut = shortcut_branch()
+        if fused:
+            if projected:
+                return ops.block_tail(x, self.unary2.mlp.weight, cu_post, xb=shortcut,
+                                      wb=self.unary_shortcut.mlp.weight, eps=self.unary2.batch_norm.eps, slope=0.1)
+            return ops.block_tail(x, self.unary2.mlp.weight, cu_post, add=shortcut,
+                                  eps=self.unary2.batch_norm.eps, slope=0.1)
         # unary2 (no relu) + shortcut, then LeakyReLU: fused into unary2's norm pass
         return self.unary2(x, stack_lengths_post, cu=cu_post, add=shortcut, final_slope=0.1,
                            max_len=ml_post)

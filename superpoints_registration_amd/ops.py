@@ -380,6 +380,80 @@ def instnorm_raw(x, cu, eps: float = 1e-5, norm: bool = True, add=None, slope: f
     return out
 
 
+_BLOCK_TAIL = os.environ.get("SPR_NO_BLOCK_TAIL", "0") != "1"   # experiment switch (A/B timing)
+
+
+def block_tail_tile_rows(ka: int, kb: int, n_out: int) -> int:
+    """Rows per statistics tile of the fused block tail for this shape; 0 = no kernel (use the separate
+    operators).  Also 0 outside the split-fp16 product mode and under SPR_NO_BLOCK_TAIL=1."""
+    if not _BLOCK_TAIL or _modes["gemm"] != 1:
+        return 0
+    return int(_lib.lib().spr_block_tail_tile_rows(int(ka), int(kb), int(n_out)))
+
+
+def _tail_tiles(cu: torch.Tensor, n: int, tr: int) -> torch.Tensor:
+    """tile table of spr_block_tail for a cu_seqlens tensor, cached on it (one per pyramid level and tile
+    height; the pyramid hands the same cu tensor to every block of a level) and guarded for readers on
+    other streams like the KPConv plans."""
+    key = (cu.data_ptr(), cu._version, n, tr, _range_epoch[0])
+    cache = getattr(cu, '_spr_tail_tiles', None)
+    if cache is None:
+        cache = {}
+        cu._spr_tail_tiles = cache
+    c = cache.get(tr)
+    if c is not None and c[0] == key:
+        c[2].acquire()
+        return c[1]
+    L = _lib.lib()
+    t = torch.empty((L.spr_block_tail_tiles_len(n, cu.numel() - 1, tr),), dtype=torch.int32, device=cu.device)
+    _lib.check(L.spr_block_tail_tiles(_ptr(cu), n, cu.numel() - 1, tr, _ptr(t), _stream(cu)), "spr_block_tail_tiles")
+    cache[tr] = (key, t, _StreamGuard(t))
+    return t
+
+
+def block_tail(xa, wa, cu, xb=None, wb=None, add=None, eps: float = 1e-5, slope: float = 0.1) -> torch.Tensor:
+    """a5, inference: lrelu(IN(xa wa^T) + (IN(xb wb^T) | add), slope) without the un-normalised
+    projections ever being written (spr_block_tail).  The caller checks block_tail_tile_rows first."""
+    xa = _dev(xa, "xa", torch.float32)
+    wa = _dev(wa, "wa", torch.float32)
+    cu = _dev(cu, "cu", torch.int32)
+    n, ka = xa.shape
+    n_out = wa.shape[0]
+    assert wa.shape[1] == ka
+    kb = 0
+    if xb is not None:
+        xb = _dev(xb, "xb", torch.float32)
+        wb = _dev(wb, "wb", torch.float32)
+        kb = xb.shape[1]
+        assert xb.shape[0] == n and wb.shape == (n_out, kb) and add is None
+    if add is not None:
+        add = _dev(add, "add", torch.float32)
+        assert add.shape == (n, n_out)
+    nb = cu.numel() - 1
+    L = _lib.lib()
+    tr = L.spr_block_tail_tile_rows(ka, kb, n_out)
+    if tr <= 0:
+        raise RuntimeError(f"block_tail: no kernel for ka={ka} kb={kb} n_out={n_out}")
+    tiles = _tail_tiles(cu, n, tr)
+    out = torch.empty((n, n_out), dtype=torch.float32, device=xa.device)
+    ws = _workspace(L.spr_block_tail_workspace_bytes(n, nb, kb, n_out, tr), xa.device)
+    xar, xar_n = _get_range(xa)
+    war, war_n = _static_range(wa)
+    xbr, xbr_n, wbr, wbr_n = None, 0, None, 0
+    if kb > 0:
+        xbr, xbr_n = _get_range(xb)
+        wbr, wbr_n = _static_range(wb)
+    cnt = _STREAM_SLOTS
+    rng = _zero_slots(cnt, xa.device) if _HANDOVER else None
+    _lib.check(L.spr_block_tail(_ptr(xa), ka, _ptr(wa), _ptr(xb), kb, _ptr(wb), _ptr(add), _ptr(cu), _ptr(tiles),
+                                n, nb, n_out, float(eps), float(slope), _ptr(out), _ptr(xar), int(xar_n),
+                                _ptr(war), int(war_n), _ptr(xbr), int(xbr_n), _ptr(wbr), int(wbr_n),
+                                _ptr(rng), cnt, _ptr(ws), ws.numel(), _stream(xa)), "spr_block_tail")
+    if rng is not None:
+        _set_range(out, rng, cnt)
+    return out
+
+
 def maxpool(x, idx) -> torch.Tensor:
     if _wants_grad(x):
         from .autograd import MaxPoolFn
