@@ -88,6 +88,25 @@ int spr_radius_neighbors(const float* q_xyz, const int* q_cu, int nq,
                          float radius, int limit, int algo, int* out_idx,
                          int* max_count, void* ws, size_t ws_bytes, void* stream);
 
+/* Cell table of spr_radius_neighbors (algo 0) as an object: built once per (supports, radius),
+ * queried several times -- the pyramid runs the conv search, the pool search and the previous
+ * level's up-sampling search against the same supports with the same radius (kpconv.py:352,
+ * :377, :384).  Rows are those of spr_radius_neighbors, entry for entry.
+ *   table: spr_radius_table_bytes(ns, nb) bytes, 256-byte aligned, owned by the caller;
+ *   self != 0: the queries are the table's supports (same array and cu) -> cell-order walk;
+ *   slot in [0, spr_radius_table_slots()): one per query call against a build (its max row count);
+ *   *max_count as in spr_radius_neighbors (-2: geometry too large for the table -> algo 1).
+ */
+size_t spr_radius_table_bytes(int ns, int nb);
+size_t spr_radius_table_build_workspace_bytes(int ns, int nb);
+size_t spr_radius_table_query_workspace_bytes(int nq);
+int spr_radius_table_slots(void);
+int spr_radius_table_build(const float* s_xyz, const int* s_cu, int ns, int nb, float radius,
+                           void* table, size_t table_bytes, void* ws, size_t ws_bytes, void* stream);
+int spr_radius_table_query(const float* q_xyz, const int* q_cu, int nq, int self, int ns, int nb,
+                           float radius, int limit, int slot, const void* table, int* out_idx,
+                           int* max_count, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- a4: KPConv forward ---------------------------------------------------
  * Replaces KPConv.forward(q_pts, s_pts, neighb_inds, x)
  * (models/backbone_kpconv/kpconv_blocks.py:269-414; rigid kernel, linear

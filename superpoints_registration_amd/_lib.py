@@ -28,6 +28,12 @@ SIGNATURES = {
     "spr_voxel_downsample": (_i, [_vp, _i, ctypes.c_double, _vp, _vp, _vp, _sz, _vp]),
     "spr_radius_neighbors_workspace_bytes": (_sz, [_i, _i, _i]),
     "spr_radius_neighbors": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "spr_radius_table_bytes": (_sz, [_i, _i]),
+    "spr_radius_table_build_workspace_bytes": (_sz, [_i, _i]),
+    "spr_radius_table_query_workspace_bytes": (_sz, [_i]),
+    "spr_radius_table_slots": (_i, []),
+    "spr_radius_table_build": (_i, [_vp, _vp, _i, _i, _f, _vp, _sz, _vp, _sz, _vp]),
+    "spr_radius_table_query": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "spr_kpconv_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "spr_kpconv_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp,
                             _i, _vp, _sz, _vp]),

@@ -262,9 +262,14 @@ __global__ __launch_bounds__(256) void k_grid_dims(const float* __restrict__ xyz
   }
 }
 
-__global__ void k_grid_offsets(GridCloud* info, int nb, long long cap, int* err, int* max_count) {
+// Table header (ints): [0] error flags, [1] cells in use, [8 .. 8 + kTableSlots) max row count of the
+// queries run against the table (k_scan_table raises its slot with atomicMax; zeroed here, at build).
+constexpr int kTableSlots = 8;
+constexpr int kHdrErr = 0, kHdrCells = 1, kHdrSlot0 = 8;
+__global__ void k_grid_offsets(GridCloud* info, int nb, long long cap, int* hdr) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  *max_count = 0;   // (k_scan_table raises it with atomicMax: zeroed here instead of by a memset node)
+  int* err = hdr + kHdrErr;
+  for (int k = 0; k < kTableSlots; ++k) hdr[kHdrSlot0 + k] = 0;
   long long off = 0;
   for (int c = 0; c < nb; ++c) {
     info[c].off = off;
@@ -274,6 +279,88 @@ __global__ void k_grid_offsets(GridCloud* info, int nb, long long cap, int* err,
       off = 0;
     }
   }
+  hdr[kHdrCells] = (int)off;
+}
+
+// The cell table is sized for the worst geometry the fast path accepts (64 cells per support point + 2^20),
+// a few per cent of which a voxelised cloud uses: 1 M of 34.6 M cells for 32 clouds of 16 384 points.
+// Zeroing and scanning the whole capacity (hipMemsetAsync + rocPRIM scan: 0.28 GB of traffic per search
+// at that size) is replaced by kernels launched over the capacity whose workgroups leave at once when
+// their block of kScanBlock cells lies beyond the cells in use (a device-side count: no host round trip).
+constexpr int kScanBlock = 4096;   // cells per workgroup: 256 threads x 16
+__global__ __launch_bounds__(256) void k_table_zero(const int* __restrict__ hdr, int* __restrict__ count) {
+  const long base = (long)blockIdx.x * kScanBlock;
+  if (base > (long)hdr[kHdrCells]) return;          // cells [0, total] are used (entry `total` receives the sum)
+  int4* p = reinterpret_cast<int4*>(count + base) + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) p[u * 256] = make_int4(0, 0, 0, 0);
+}
+
+__device__ __forceinline__ int block_sum_256(int v, int* sh /*[4]*/) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const int r = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_table_bsum(const int* __restrict__ hdr, const int* __restrict__ count,
+                                                    int* __restrict__ bsum) {
+  __shared__ int sh[4];
+  const long base = (long)blockIdx.x * kScanBlock;
+  if (base > (long)hdr[kHdrCells]) return;
+  const int4* p = reinterpret_cast<const int4*>(count + base) + threadIdx.x;
+  int v = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int4 q = p[u * 256];
+    v += q.x + q.y + q.z + q.w;
+  }
+  v = block_sum_256(v, sh);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = v;
+}
+
+// in-place exclusive scan: count[] -> start[]; the block's offset is the sum of the block sums before it
+__global__ __launch_bounds__(256) void k_table_scan(const int* __restrict__ hdr, int* __restrict__ count,
+                                                    const int* __restrict__ bsum) {
+  __shared__ int sh[4];
+  __shared__ int wsum[4];
+  const long base = (long)blockIdx.x * kScanBlock;
+  if (base > (long)hdr[kHdrCells]) return;
+  int off = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) off += bsum[b];
+  off = block_sum_256(off, sh);
+  // thread t owns cells base + 16 t .. + 15
+  int4* p = reinterpret_cast<int4*>(count + base) + 4 * threadIdx.x;
+  int4 q[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) q[u] = p[u];
+  int mine = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) mine += q[u].x + q[u].y + q[u].z + q[u].w;
+  // exclusive prefix of `mine` over the 256 threads
+  int incl = mine;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int run = off + incl - mine;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wsum[w];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    int4 o4;
+    o4.x = run; run += q[u].x;
+    o4.y = run; run += q[u].y;
+    o4.z = run; run += q[u].z;
+    o4.w = run; run += q[u].w;
+    p[u] = o4;
+  }
 }
 
 __device__ __forceinline__ long long grid_cell(const GridCloud& g, int cx, int cy, int cz) {
@@ -282,7 +369,7 @@ __device__ __forceinline__ long long grid_cell(const GridCloud& g, int cx, int c
 
 __global__ void k_cell_count(const float* __restrict__ xyz, const int* __restrict__ cu, int n, int nb,
                              float inv_cell, const GridCloud* __restrict__ info,
-                             const int* __restrict__ err, int* count, int* cell_of) {
+                             const int* __restrict__ err, int* count, int* cell_of, int* rank) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || *err) return;
   const int c = find_segment(cu, nb, i);
@@ -295,16 +382,16 @@ __global__ void k_cell_count(const float* __restrict__ xyz, const int* __restric
   cz = min(max(cz, 0), g.dim[2] - 1);
   const long long L = grid_cell(g, cx, cy, cz);
   cell_of[i] = (int)L;
-  atomicAdd(&count[L], 1);
+  rank[i] = atomicAdd(&count[L], 1);   // arrival rank inside the cell: the scatter needs no second counter table
 }
 
 __global__ void k_cell_scatter(const float* __restrict__ xyz, int n, const int* __restrict__ err,
                                const int* __restrict__ cell_of, const int* __restrict__ start,
-                               int* cursor, float4* rec) {
+                               const int* __restrict__ rank, float4* rec) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || *err) return;
   const int L = cell_of[i];
-  const int pos = start[L] + atomicAdd(&cursor[L], 1);
+  const int pos = start[L] + rank[i];
   rec[pos] = make_float4(xyz[3 * (size_t)i + 0], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2],
                          __int_as_float(i));
 }
@@ -518,17 +605,91 @@ __global__ __launch_bounds__(BLOCK) void k_sort_rows(const unsigned long long* _
   for (int k = kept; k < limit; ++k) row[k] = ns;
 }
 
-__global__ void k_nbr_err2(const int* err, int* max_count) {
-  if (*err & 1) *max_count = -1;       // extent / radius too large
-  else if (*err & 2) *max_count = -2;  // cell table overflow -> caller retries with algo 1
+__global__ void k_nbr_err2(const int* hdr, int slot, int* max_count) {
+  const int err = hdr[kHdrErr];
+  if (err & 1) *max_count = -1;       // extent / radius too large
+  else if (err & 2) *max_count = -2;  // cell table overflow -> caller retries with algo 1
+  else *max_count = hdr[kHdrSlot0 + slot];
 }
 
 size_t table_cap_cells(int ns) { return (size_t)64 * (size_t)(ns > 0 ? ns : 1) + ((size_t)1 << 20); }
 
-size_t scan_temp_bytes(size_t n) {
-  size_t sb = 0;
-  (void)rocprim::exclusive_scan(nullptr, sb, (int*)nullptr, (int*)nullptr, 0, n, rocprim::plus<int>());
-  return align_up(sb, 256) + 256;
+// ---- cell table as an object of its own: built once per (supports, radius), queried several times -------
+// (the pyramid asks for the conv, the pool and the previous level's up-sampling neighbours against the
+// same supports with the same radius: kpconv.py:352, :377, :384 of the reference)
+// blob: header int[64] | GridCloud[nb] | start int[cells_alloc] | records float4[ns]
+size_t table_cells_alloc(int ns) { return align_up(table_cap_cells(ns) + 1, kScanBlock); }
+struct TableView {
+  int* hdr;
+  GridCloud* ginfo;
+  int* start;
+  float4* rec;
+};
+size_t table_bytes(int ns, int nb) {
+  return align_up(64 * sizeof(int), 256) + align_up(sizeof(GridCloud) * (size_t)(nb > 0 ? nb : 1), 256) +
+         align_up(4 * table_cells_alloc(ns), 256) + align_up(16 * (size_t)(ns > 0 ? ns : 1), 256);
+}
+TableView table_view(void* blob, int ns, int nb) {
+  Workspace w(blob, table_bytes(ns, nb));
+  TableView t;
+  t.hdr = w.take<int>(64);
+  t.ginfo = w.take<GridCloud>(nb > 0 ? nb : 1);
+  t.start = w.take<int>(table_cells_alloc(ns));
+  t.rec = w.take<float4>(ns > 0 ? ns : 1);
+  return t;
+}
+size_t table_build_ws_bytes(int ns) {
+  return 2 * align_up(4 * (size_t)(ns > 0 ? ns : 1), 256) + align_up(4 * (table_cells_alloc(ns) / kScanBlock), 256);
+}
+size_t table_query_ws_bytes(int nq) {
+  const size_t Q = (size_t)(nq > 0 ? nq : 1);
+  return align_up(8 * Q * 128, 256) + align_up(4 * Q, 256);   // unsorted (d2, id) key rows (cap <= 128), kept counts
+}
+
+int table_build(const float* s_xyz, const int* s_cu, int ns, int nb, float radius, void* blob, void* ws,
+                size_t ws_bytes, hipStream_t stream) {
+  const TableView t = table_view(blob, ns, nb);
+  Workspace w(ws, ws_bytes);
+  int* cell_of = w.take<int>((size_t)ns);
+  int* rank = w.take<int>((size_t)ns);
+  const int nblk = (int)(table_cells_alloc(ns) / kScanBlock);
+  int* bsum = w.take<int>((size_t)nblk);
+  SPR_REQUIRE(bsum != nullptr, "radius table: workspace carve failed");
+  const float inv_cell = 1.0f / (radius * (1.0f + 1.0f / 256.0f));
+  const int TB = 256;
+  SPR_HIP_CHECK(hipMemsetAsync(t.hdr, 0, 8 * sizeof(int), stream));
+  hipLaunchKernelGGL(k_grid_dims, dim3(nb), dim3(256), 0, stream, s_xyz, s_cu, inv_cell, t.ginfo, t.hdr + kHdrErr);
+  hipLaunchKernelGGL(k_grid_offsets, dim3(1), dim3(64), 0, stream, t.ginfo, nb, (long long)table_cap_cells(ns), t.hdr);
+  hipLaunchKernelGGL(k_table_zero, dim3(nblk), dim3(256), 0, stream, t.hdr, t.start);
+  hipLaunchKernelGGL(k_cell_count, dim3(cdiv(ns, TB)), dim3(TB), 0, stream, s_xyz, s_cu, ns, nb, inv_cell, t.ginfo,
+                     t.hdr + kHdrErr, t.start, cell_of, rank);
+  hipLaunchKernelGGL(k_table_bsum, dim3(nblk), dim3(256), 0, stream, t.hdr, t.start, bsum);
+  hipLaunchKernelGGL(k_table_scan, dim3(nblk), dim3(256), 0, stream, t.hdr, t.start, bsum);
+  hipLaunchKernelGGL(k_cell_scatter, dim3(cdiv(ns, TB)), dim3(TB), 0, stream, s_xyz, ns, t.hdr + kHdrErr, cell_of,
+                     t.start, rank, t.rec);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+int table_query(const float* q_xyz, const int* q_cu, int nq, int self, int ns, int nb, float radius, int limit,
+                int slot, const void* blob, int* out_idx, int* max_count, void* ws, size_t ws_bytes,
+                hipStream_t stream) {
+  const TableView t = table_view(const_cast<void*>(blob), ns, nb);
+  Workspace w(ws, ws_bytes);
+  const int rcap = nbr_row_cap(limit);
+  unsigned long long* tmp_key = w.take<unsigned long long>((size_t)nq * rcap);
+  int* kept = w.take<int>((size_t)nq);
+  SPR_REQUIRE(kept != nullptr, "radius query: workspace carve failed");
+  const float r2 = radius * radius;  // neighbors.cpp:226 (float32)
+  const float inv_cell = 1.0f / (radius * (1.0f + 1.0f / 256.0f));
+  hipLaunchKernelGGL(k_scan_table, dim3(cdiv(nq, 256)), dim3(256), 0, stream, q_xyz, q_cu, nq, nb, t.ginfo, t.start,
+                     t.rec, t.hdr + kHdrErr, r2, inv_cell, rcap, limit, self, tmp_key, kept, t.hdr + kHdrSlot0 + slot);
+  constexpr int BLOCK = 64;   // cap <= 128 -> at most 64 KB of LDS
+  hipLaunchKernelGGL(k_sort_rows<BLOCK>, dim3(cdiv(nq, BLOCK)), dim3(BLOCK), (size_t)rcap * 8 * BLOCK, stream, tmp_key,
+                     kept, t.hdr + kHdrErr, nq, ns, limit, rcap, out_idx);
+  hipLaunchKernelGGL(k_nbr_err2, dim3(1), dim3(1), 0, stream, t.hdr, slot, max_count);
+  SPR_LAUNCH_CHECK();
+  return 0;
 }
 
 __global__ void k_nbr_err(const int* err, int* max_count) {
@@ -557,16 +718,8 @@ extern "C" size_t spr_radius_neighbors_workspace_bytes(int nq, int ns, int nb) {
   b += align_up(16 * N, 256);
   b += 256;
   b += nbr_sort_temp_bytes(ns);
-  // cell-table path
-  const size_t cap = table_cap_cells(ns);
-  b += align_up(sizeof(GridCloud) * B, 256);
-  b += 3 * align_up(4 * (cap + 1), 256);  // count, start, cursor
-  b += align_up(4 * N, 256);              // cell_of
-  b += 256;                               // error flags of the cell-table path (zeroed together with count and cursor)
-  b += scan_temp_bytes(cap + 1);
-  const size_t Q = (size_t)(nq > 0 ? nq : 1);
-  b += align_up(8 * Q * 128, 256);        // unsorted (d2, id) key rows, nbr_row_cap(limit) <= 128
-  b += align_up(4 * Q, 256);              // kept counts
+  // cell-table path: the table itself, its build scratch, the query scratch
+  b += table_bytes(ns, nb) + table_build_ws_bytes(ns) + table_query_ws_bytes(nq);
   return b;
 }
 
@@ -594,52 +747,19 @@ extern "C" int spr_radius_neighbors(const float* q_xyz, const int* q_cu, int nq,
   void* temp = w.take<char>(temp_bytes);
   SPR_REQUIRE(temp != nullptr, "radius_neighbors: workspace carve failed");
 
-  const float r2 = radius * radius;  // neighbors.cpp:226 (float32)
-  const float cell = radius * (1.0f + 1.0f / 256.0f);
-  const float inv_cell = 1.0f / cell;
-
   const int TB = 256;
   if (algo == 0) {
-    // one memset node for everything this path needs zeroed: error flags, cell counts, scatter cursors
-    // (carved back to back); max_count is zeroed by k_grid_offsets.  (Four memsets per search were
-    // 28 of the 53 fill kernels of a forward.)
-    const size_t cap = table_cap_cells(ns);
-    err = w.take<int>(64);
-    int* count = w.take<int>(cap + 1);
-    int* cursor = w.take<int>(cap + 1);
-    GridCloud* ginfo = w.take<GridCloud>(nb);
-    int* start = w.take<int>(cap + 1);
-    int* cell_of = w.take<int>(N);
-    const size_t stemp_bytes = scan_temp_bytes(cap + 1);
-    void* stemp = w.take<char>(stemp_bytes);
-    SPR_REQUIRE(stemp != nullptr, "radius_neighbors: workspace carve failed (table)");
-    SPR_HIP_CHECK(hipMemsetAsync(err, 0, (size_t)((char*)(cursor + cap + 1) - (char*)err), stream));
-    hipLaunchKernelGGL(k_grid_dims, dim3(nb), dim3(256), 0, stream, s_xyz, s_cu, inv_cell, ginfo, err);
-    hipLaunchKernelGGL(k_grid_offsets, dim3(1), dim3(64), 0, stream, ginfo, nb, (long long)cap, err, max_count);
-    hipLaunchKernelGGL(k_cell_count, dim3(cdiv(ns, TB)), dim3(TB), 0, stream, s_xyz, s_cu, ns, nb,
-                       inv_cell, ginfo, err, count, cell_of);
-    SPR_LAUNCH_CHECK();
-    size_t sb = stemp_bytes;
-    SPR_HIP_CHECK(rocprim::exclusive_scan(stemp, sb, count, start, 0, cap + 1, rocprim::plus<int>(),
-                                          stream));
-    hipLaunchKernelGGL(k_cell_scatter, dim3(cdiv(ns, TB)), dim3(TB), 0, stream, s_xyz, ns, err, cell_of,
-                       start, cursor, rec);
-    const int rcap = nbr_row_cap(limit);
-    unsigned long long* tmp_key = w.take<unsigned long long>((size_t)nq * rcap);
-    int* kept = w.take<int>((size_t)nq);
-    SPR_REQUIRE(kept != nullptr, "radius_neighbors: workspace carve failed (rows)");
-    hipLaunchKernelGGL(k_scan_table, dim3(cdiv(nq, 256)), dim3(256), 0, stream, q_xyz, q_cu, nq, nb, ginfo,
-                       start, rec, err, r2, inv_cell, rcap, limit, (q_xyz == s_xyz && q_cu == s_cu && nq == ns) ? 1 : 0,
-                       tmp_key, kept, max_count);
-    {
-      constexpr int BLOCK = 64;   // cap <= 128 -> at most 64 KB of LDS
-      hipLaunchKernelGGL(k_sort_rows<BLOCK>, dim3(cdiv(nq, BLOCK)), dim3(BLOCK), (size_t)rcap * 8 * BLOCK,
-                         stream, tmp_key, kept, err, nq, ns, limit, rcap, out_idx);
-    }
-    hipLaunchKernelGGL(k_nbr_err2, dim3(1), dim3(1), 0, stream, err, max_count);
-    SPR_LAUNCH_CHECK();
-    return 0;
+    void* blob = w.take<char>(table_bytes(ns, nb));
+    const size_t bws = table_build_ws_bytes(ns), qws = table_query_ws_bytes(nq);
+    void* build_ws = w.take<char>(bws);
+    void* query_ws = w.take<char>(qws);
+    SPR_REQUIRE(query_ws != nullptr, "radius_neighbors: workspace carve failed (table)");
+    if (int rc = table_build(s_xyz, s_cu, ns, nb, radius, blob, build_ws, bws, stream)) return rc;
+    return table_query(q_xyz, q_cu, nq, (q_xyz == s_xyz && q_cu == s_cu && nq == ns) ? 1 : 0, ns, nb, radius, limit, 0,
+                       blob, out_idx, max_count, query_ws, qws, stream);
   }
+  const float r2 = radius * radius;  // neighbors.cpp:226 (float32)
+  const float inv_cell = 1.0f / (radius * (1.0f + 1.0f / 256.0f));
   SPR_HIP_CHECK(hipMemsetAsync(err, 0, 16 * sizeof(int), stream));
   SPR_HIP_CHECK(hipMemsetAsync(max_count, 0, sizeof(int), stream));
   hipLaunchKernelGGL(k_min, dim3(nb), dim3(256), 0, stream, s_xyz, s_cu, info);
@@ -667,4 +787,35 @@ extern "C" int spr_radius_neighbors(const float* q_xyz, const int* q_cu, int nq,
   hipLaunchKernelGGL(k_nbr_err, dim3(1), dim3(1), 0, stream, err, max_count);
   SPR_LAUNCH_CHECK();
   return 0;
+}
+
+// ---- cell table built once, queried several times (Preprocessor: conv / pool / up-sampling searches that share
+// supports and radius).  Results are those of spr_radius_neighbors (algo 0), row for row. ----------------------
+extern "C" size_t spr_radius_table_bytes(int ns, int nb) { return table_bytes(ns, nb); }
+extern "C" size_t spr_radius_table_build_workspace_bytes(int ns, int nb) { (void)nb; return table_build_ws_bytes(ns); }
+extern "C" size_t spr_radius_table_query_workspace_bytes(int nq) { return table_query_ws_bytes(nq); }
+extern "C" int spr_radius_table_slots(void) { return kTableSlots; }
+
+extern "C" int spr_radius_table_build(const float* s_xyz, const int* s_cu, int ns, int nb, float radius, void* table,
+                                      size_t table_bytes_, void* ws, size_t ws_bytes, void* stream_) {
+  SPR_REQUIRE(s_xyz && s_cu && table && ns > 0 && nb >= 1 && nb < 65536, "radius_table_build: bad arguments");
+  SPR_REQUIRE(radius > 0.f, "radius_table_build: radius must be > 0");
+  SPR_REQUIRE(table_bytes_ >= table_bytes(ns, nb) && ((uintptr_t)table & 255) == 0, "radius_table_build: table too small or misaligned");
+  SPR_REQUIRE(ws != nullptr && ws_bytes >= table_build_ws_bytes(ns), "radius_table_build: workspace too small");
+  return table_build(s_xyz, s_cu, ns, nb, radius, table, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+// self != 0: the queries ARE the table's supports (same array, same cu) -> cell-order walk.  slot in
+// [0, spr_radius_table_slots()): one per query call against this table build (its max row count).
+// *max_count as in spr_radius_neighbors (-1 extent too large, -2 table overflow: use algo 1).
+extern "C" int spr_radius_table_query(const float* q_xyz, const int* q_cu, int nq, int self, int ns, int nb,
+                                      float radius, int limit, int slot, const void* table, int* out_idx,
+                                      int* max_count, void* ws, size_t ws_bytes, void* stream_) {
+  SPR_REQUIRE(q_xyz && q_cu && table && out_idx && max_count && nq > 0 && ns > 0 && nb >= 1, "radius_table_query: bad arguments");
+  SPR_REQUIRE(limit >= 1 && limit <= 128, "radius_table_query: limit must be in [1,128], got %d", limit);
+  SPR_REQUIRE(slot >= 0 && slot < kTableSlots, "radius_table_query: slot out of range");
+  SPR_REQUIRE(!self || nq == ns, "radius_table_query: a self search has nq == ns");
+  SPR_REQUIRE(ws != nullptr && ws_bytes >= table_query_ws_bytes(nq), "radius_table_query: workspace too small");
+  return table_query(q_xyz, q_cu, nq, self ? 1 : 0, ns, nb, radius, limit, slot, table, out_idx, max_count, ws, ws_bytes,
+                     (hipStream_t)stream_);
 }

@@ -250,13 +250,22 @@ class Preprocessor(nn.Module):
             meta['_cu'][l] = cu
             meta['_lens_host'].append(lens_host)
 
+        # One cell table per (supports, radius): a level's conv and pool searches and the previous level's
+        # up-sampling search (radius 2 r = the next level's r) all look into the same one.
+        table = [None]
+
+        def search(queries, q_cu, supports, s_cu, radius, limit):
+            if table[0] is None or not table[0].matches(supports, s_cu, radius):
+                table[0] = ops.RadiusTable(supports, s_cu, radius)
+            return table[0].query(queries, q_cu, limit)[0]
+
         cu = ops.lengths_to_cu(lens_host, device)
         open_level(0, points, lens_host, cu)
         for l, lv in enumerate(levels):
             conv = pool = up = None
             plan_ns[0] = points.shape[0]
             if lv.has_conv:
-                conv, _ = ops.radius_neighbors(points, points, cu, cu, lv.radius, lv.limit)
+                conv = search(points, cu, points, cu, lv.radius, lv.limit)
             publish('neighbors', l, conv)
             yield meta, 'conv', l
             if lv.down:
@@ -264,10 +273,9 @@ class Preprocessor(nn.Module):
                 sub_points, sub_lens = ops.grid_subsample(points, cu, dl, order=self.order)
                 sub_lens_host = sub_lens.tolist()
                 sub_cu = ops.lengths_to_cu(sub_lens_host, device)
-                pool, _ = ops.radius_neighbors(sub_points, points, sub_cu, cu, lv.radius, lv.limit)
+                pool = search(sub_points, sub_cu, points, cu, lv.radius, lv.limit)
                 if self.compute_upsamples:
-                    up, _ = ops.radius_neighbors(points, sub_points, cu, sub_cu, 2 * lv.radius,
-                                                 lv.limit)
+                    up = search(points, cu, sub_points, sub_cu, 2 * lv.radius, lv.limit)
             publish('pools', l, pool)
             publish('upsamples', l, up)
             if lv.down:

@@ -229,6 +229,55 @@ def radius_neighbors(queries: torch.Tensor, supports: torch.Tensor, q_cu: torch.
     return out[:, :min(m, limit)], m
 
 
+class RadiusTable:
+    """Cell table of one support set at one radius (spr_radius_table_build), queried by several neighbour
+    searches.  The pyramid builds one per level: the conv search, the pool search and the previous level's
+    up-sampling search share supports and radius (reference kpconv.py:352, :377, :384)."""
+
+    def __init__(self, supports: torch.Tensor, s_cu: torch.Tensor, radius: float):
+        self.supports = _dev(supports, "supports", torch.float32)
+        self.s_cu = _dev(s_cu, "s_cu", torch.int32)
+        self.radius = float(radius)
+        self.ns, self.nb = self.supports.shape[0], self.s_cu.numel() - 1
+        L = _lib.lib()
+        self.blob = torch.empty((L.spr_radius_table_bytes(self.ns, self.nb),), dtype=torch.uint8, device=supports.device)
+        ws = _workspace(L.spr_radius_table_build_workspace_bytes(self.ns, self.nb), supports.device)
+        _lib.check(L.spr_radius_table_build(_ptr(self.supports), _ptr(self.s_cu), self.ns, self.nb, self.radius,
+                                            _ptr(self.blob), self.blob.numel(), _ptr(ws), ws.numel(),
+                                            _stream(self.supports)), "spr_radius_table_build")
+        self._slot = 0
+        self._slots = L.spr_radius_table_slots()
+
+    def matches(self, supports: torch.Tensor, s_cu: torch.Tensor, radius: float) -> bool:
+        return (supports.data_ptr() == self.supports.data_ptr() and supports.shape[0] == self.ns
+                and s_cu.data_ptr() == self.s_cu.data_ptr() and float(radius) == self.radius
+                and self._slot < self._slots)
+
+    def query(self, queries: torch.Tensor, q_cu: torch.Tensor, limit: int) -> Tuple[torch.Tensor, int]:
+        """int32 [Nq, min(max_count, limit)] and the untruncated max count, like radius_neighbors."""
+        queries = _dev(queries, "queries", torch.float32)
+        q_cu = _dev(q_cu, "q_cu", torch.int32)
+        nq = queries.shape[0]
+        self_search = int(queries.data_ptr() == self.supports.data_ptr() and nq == self.ns
+                          and q_cu.data_ptr() == self.s_cu.data_ptr())
+        L = _lib.lib()
+        ws = _workspace(L.spr_radius_table_query_workspace_bytes(nq), queries.device)
+        out = torch.empty((nq, limit), dtype=torch.int32, device=queries.device)
+        mc = torch.empty((1,), dtype=torch.int32, device=queries.device)
+        slot, self._slot = self._slot, self._slot + 1
+        _lib.check(L.spr_radius_table_query(_ptr(queries), _ptr(q_cu), nq, self_search, self.ns, self.nb, self.radius,
+                                            int(limit), slot, _ptr(self.blob), _ptr(out), _ptr(mc), _ptr(ws),
+                                            ws.numel(), _stream(queries)), "spr_radius_table_query")
+        m = int(mc.item())
+        if m == -2:     # cell table too small for this geometry: exact same result, slower path
+            return radius_neighbors(queries, self.supports, q_cu, self.s_cu, self.radius, limit, True, algo=1)
+        if m < 0:
+            raise RuntimeError("spr_radius_neighbors: cloud extent / radius exceeds 8191 cells per axis")
+        if m < 1:  # cpp_neighbors/wrapper.cpp:201-205
+            raise RuntimeError("Error")
+        return out[:, :min(m, limit)], m
+
+
 def _wants_grad(*tensors) -> bool:
     """True when the call must go through autograd.py (gradients enabled and asked for)."""
     return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
