@@ -234,20 +234,23 @@ __global__ void k_emit_canonical(const float* __restrict__ bary,
   out[3 * o + 2] = bary[3 * (size_t)v + 2];
 }
 
-// Sort keys for the insertion sequence: (cloud, first point index).
-__global__ void k_inskeys(const unsigned long long* __restrict__ vkey,
-                          const int* __restrict__ vfirst,
-                          const int* __restrict__ nvox_p, int n,
-                          unsigned long long* skey, int* sval) {
+// Insertion sequence of the voxels = ascending (cloud, first point index) = ascending first point
+// index (clouds are contiguous): every voxel marks its first point, a scan over the points ranks the
+// marks, a compaction emits the voxel ids in that order.  (A 64-bit pair sort did this before: 17
+// merge-sort launches per subsampling.)
+__global__ void k_mark_first(const int* __restrict__ vfirst, const int* __restrict__ nvox_p, int* __restrict__ mark,
+                             int* __restrict__ who) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= n) return;
-  if (v < *nvox_p) {
-    skey[v] = ((vkey[v] >> kKeyBits) << 32) | (unsigned int)vfirst[v];
-    sval[v] = v;
-  } else {
-    skey[v] = ~0ull;
-    sval[v] = -1;
-  }
+  if (v >= *nvox_p) return;
+  const int f = vfirst[v];
+  mark[f] = 1;
+  who[f] = v;
+}
+__global__ void k_compact_first(const int* __restrict__ mark, const int* __restrict__ pos, const int* __restrict__ who,
+                                int n, int* __restrict__ ins) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !mark[i]) return;
+  ins[pos[i]] = who[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -289,13 +292,26 @@ __device__ void block_inclusive_scan(int* data, int m, int* lds /*[1024]*/) {
   __syncthreads();
 }
 
+// k % nbk for k < 2^40 (voxel keys), nbk < 2^32: quotient estimate in double (off by at most one), exact fix-up.
+__device__ __forceinline__ int fast_mod(unsigned long long k, unsigned int nbk, double inv) {
+  const unsigned long long q = (unsigned long long)((double)k * inv);
+  long long r = (long long)k - (long long)(q * (unsigned long long)nbk);
+  if (r < 0) r += nbk;
+  else if (r >= (long long)nbk) r -= nbk;
+  return (int)r;
+}
+
+// bucket tables (first arrival, count, chain head) of an epoch live in LDS while 3 * nbk ints fit
+constexpr int kUmapLdsInts = 31744;   // 124 KB: every epoch up to 10 273 buckets (clouds of <= 10 273 voxels)
+
 __global__ __launch_bounds__(1024) void k_umap_order(
     const unsigned long long* __restrict__ vkey, const int* __restrict__ ins,
     const int* __restrict__ vcu, const int* __restrict__ cu, int nsched, SchedArg sched,
     int* listA, int* listB, int* tfirst, int* tcnt, int* thead, int* nxt,
-    int* scan, const float* __restrict__ bary, const int* __restrict__ out_cu,
+    int* scan, int* bucket, const float* __restrict__ bary, const int* __restrict__ out_cu,
     const int* __restrict__ out_lens, float* out) {
   __shared__ int lds[1024];
+  extern __shared__ int lds_tab[];
   const int c = blockIdx.x;
   const int base = vcu[c];
   const int m = vcu[c + 1] - base;
@@ -305,10 +321,8 @@ __global__ __launch_bounds__(1024) void k_umap_order(
   int* lb = listB + base;
   int* nx = nxt + base;
   int* sc = scan + base;
+  int* bk = bucket + base;
   const size_t toff = 3 * (size_t)cu[c] + 16 * (size_t)c;
-  int* tf = tfirst + toff;
-  int* tc = tcnt + toff;
-  int* th = thead + toff;
   const int t = threadIdx.x, T = blockDim.x;
 
   int done = 0;  // elements already in the list
@@ -321,42 +335,43 @@ __global__ __launch_bounds__(1024) void k_umap_order(
     const int nbk = (int)sched.v[e];
     const int upto = min(m, nbk);
     const int len = upto;  // arrival sequence length = done + (upto - done)
-    for (int b = t; b < nbk; b += T) {
-      tf[b] = 0x7fffffff;
-      tc[b] = 0;
-      th[b] = -1;
-    }
-    // new arrivals are elements done..upto-1 (insertion order)
-    for (int p = done + t; p < upto; p += T) cur[p] = p;
-    __syncthreads();
-    for (int p = t; p < len; p += T) {
-      const int el = cur[p];
-      const unsigned long long k = vkey[ins[base + el]] & kKeyMask;
-      const int b = (int)(k % (unsigned long long)nbk);
-      atomicMin(&tf[b], p);
-      atomicAdd(&tc[b], 1);
-      nx[p] = atomicExch(&th[b], p);
-    }
-    __syncthreads();
-    for (int p = t; p < len; p += T) {
-      const int el = cur[p];
-      const unsigned long long k = vkey[ins[base + el]] & kKeyMask;
-      const int b = (int)(k % (unsigned long long)nbk);
-      sc[p] = (tf[b] == p) ? tc[b] : 0;
-    }
-    __syncthreads();
-    block_inclusive_scan(sc, len, lds);
-    const int total = len;  // sum of all bucket counts
-    for (int p = t; p < len; p += T) {
-      const int el = cur[p];
-      const unsigned long long k = vkey[ins[base + el]] & kKeyMask;
-      const int b = (int)(k % (unsigned long long)nbk);
-      int greater = 0;
-      for (int q = th[b]; q != -1; q = nx[q]) greater += (q > p) ? 1 : 0;
-      const int pos = (total - sc[tf[b]]) + greater;
-      nxtl[pos] = el;
-    }
-    __syncthreads();
+    const double inv = 1.0 / (double)nbk;
+    auto epoch = [&](int* tf, int* tc, int* th) {
+      for (int b = t; b < nbk; b += T) {
+        tf[b] = 0x7fffffff;
+        tc[b] = 0;
+        th[b] = -1;
+      }
+      // new arrivals are elements done..upto-1 (insertion order)
+      for (int p = done + t; p < upto; p += T) cur[p] = p;
+      __syncthreads();
+      for (int p = t; p < len; p += T) {
+        const int el = cur[p];
+        const int b = fast_mod(vkey[ins[base + el]] & kKeyMask, (unsigned int)nbk, inv);
+        bk[p] = b;
+        atomicMin(&tf[b], p);
+        atomicAdd(&tc[b], 1);
+        nx[p] = atomicExch(&th[b], p);
+      }
+      __syncthreads();
+      for (int p = t; p < len; p += T) {
+        const int b = bk[p];
+        sc[p] = (tf[b] == p) ? tc[b] : 0;
+      }
+      __syncthreads();
+      block_inclusive_scan(sc, len, lds);
+      const int total = len;  // sum of all bucket counts
+      for (int p = t; p < len; p += T) {
+        const int b = bk[p];
+        int greater = 0;
+        for (int q = th[b]; q != -1; q = nx[q]) greater += (q > p) ? 1 : 0;
+        const int pos = (total - sc[tf[b]]) + greater;
+        nxtl[pos] = cur[p];
+      }
+      __syncthreads();
+    };
+    if (3 * nbk <= kUmapLdsInts) epoch(lds_tab, lds_tab + nbk, lds_tab + 2 * nbk);
+    else epoch(tfirst + toff, tcnt + toff, thead + toff);
     int* tmp = cur;
     cur = nxtl;
     nxtl = tmp;
@@ -397,8 +412,7 @@ extern "C" size_t spr_grid_subsample_workspace_bytes(int n, int nb) {
   const size_t N = (size_t)(n > 0 ? n : 1), B = (size_t)(nb > 0 ? nb : 1);
   size_t b = 0;
   b += align_up(sizeof(CloudInfo) * B, 256);
-  b += 4 * align_up(8 * N, 256);           // keys in/out, vkey, skey(+out)
-  b += align_up(8 * N, 256);               // skey out
+  b += 3 * align_up(8 * N, 256);           // keys in/out, vkey
   b += 10 * align_up(4 * N, 256);          // vals in/out, flags, vid, vstart, vfirst, sval x2, listA, listB
   b += 2 * align_up(4 * N, 256);           // nxt, scan
   b += align_up(12 * N, 256);              // bary
@@ -427,8 +441,6 @@ extern "C" int spr_grid_subsample(const float* xyz, const int* cu, int n, int nb
   unsigned long long* keys = w.take<unsigned long long>(N);
   unsigned long long* keys2 = w.take<unsigned long long>(N);
   unsigned long long* vkey = w.take<unsigned long long>(N);
-  unsigned long long* skey = w.take<unsigned long long>(N);
-  unsigned long long* skey2 = w.take<unsigned long long>(N);
   int* vals = w.take<int>(N);
   int* vals2 = w.take<int>(N);
   int* flags = w.take<int>(N);
@@ -488,13 +500,16 @@ extern "C" int spr_grid_subsample(const float* xyz, const int* cu, int n, int nb
     for (int i = 0; i < kMaxSched; ++i)
       sched.v[i] = i < (int)s.buckets.size() ? s.buckets[i] : 0xffffffffu;
     const int nsched = (int)(s.buckets.size() < (size_t)kMaxSched ? s.buckets.size() : kMaxSched);
-    hipLaunchKernelGGL(k_inskeys, dim3(cdiv(n, TB)), dim3(TB), 0, stream, vkey, vfirst,
-                       nvox, n, skey, sval);
+    // insertion order: flags / vid / vstart are free again after k_bary (mark, who, rank)
+    SPR_HIP_CHECK(hipMemsetAsync(flags, 0, N * sizeof(int), stream));
+    hipLaunchKernelGGL(k_mark_first, dim3(cdiv(n, TB)), dim3(TB), 0, stream, vfirst, nvox, flags, vid);
     tb = temp_bytes;
-    SPR_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, skey, skey2, sval, sval2,
-                                            (unsigned int)n, 0, 64, stream));
-    hipLaunchKernelGGL(k_umap_order, dim3(nb), dim3(1024), 0, stream, vkey, sval2, vcu, cu,
-                       nsched, sched, listA, listB, tfirst, tcnt, thead, nxt, scan, bary, out_cu,
+    SPR_HIP_CHECK(rocprim::exclusive_scan(temp, tb, flags, vstart, 0, (size_t)n, rocprim::plus<int>(), stream));
+    hipLaunchKernelGGL(k_compact_first, dim3(cdiv(n, TB)), dim3(TB), 0, stream, flags, vstart, vid, n, sval2);
+    const int umap_lds = kUmapLdsInts * (int)sizeof(int);
+    if (int rc = ensure_dyn_lds((const void*)k_umap_order, umap_lds)) return rc;
+    hipLaunchKernelGGL(k_umap_order, dim3(nb), dim3(1024), umap_lds, stream, vkey, sval2, vcu, cu,
+                       nsched, sched, listA, listB, tfirst, tcnt, thead, nxt, scan, sval, bary, out_cu,
                        out_lens, out_xyz);
   }
   hipLaunchKernelGGL(k_check_err, dim3(1), dim3(1), 0, stream, err, out_total);
