@@ -402,10 +402,22 @@ __global__ void k_cell_scatter(const float* __restrict__ xyz, int n, const int* 
 // (fire-and-forget stores); only a query whose row is already full (more than
 // `limit` supports in range) pays for reads: it replaces the current worst
 // entry and rescans its row for the new worst.
-__device__ __forceinline__ int pick9(int k, const int (&a)[9]) {
-  int v = a[0];
-#pragma unroll
-  for (int u = 1; u < 9; ++u) v = (k == u) ? a[u] : v;
+// The nine record runs of a query live in NAMED registers (a nine-element array indexed by the running
+// run number is demoted to scratch memory by the compiler: a scratch load in the address chain of every
+// record load).  Run k as a packed (begin, end) pair picked by a select chain.
+struct Runs9 {
+  int2 r0, r1, r2, r3, r4, r5, r6, r7, r8;
+};
+__device__ __forceinline__ int2 pick9(int k, const Runs9& a) {
+  int2 v = a.r0;
+  v = (k == 1) ? a.r1 : v;
+  v = (k == 2) ? a.r2 : v;
+  v = (k == 3) ? a.r3 : v;
+  v = (k == 4) ? a.r4 : v;
+  v = (k == 5) ? a.r5 : v;
+  v = (k == 6) ? a.r6 : v;
+  v = (k == 7) ? a.r7 : v;
+  v = (k == 8) ? a.r8 : v;
   return v;
 }
 
@@ -449,16 +461,18 @@ __global__ __launch_bounds__(256) void k_scan_table(
     const int cy = cell_coord(qy, g.mn[1], inv_cell);
     const int cz = cell_coord(qz, g.mn[2], inv_cell);
     const int xlo = max(cx - 1, 0), xhi = min(cx + 1, g.dim[0] - 1);
-    int rb[9], re[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
+    auto run_of = [&](int k) -> int2 {
       const int z = cz + k / 3 - 1, y = cy + k % 3 - 1;
       const bool in = xlo <= xhi && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
       const long long L0 = in ? grid_cell(g, xlo, y, z) : 0;
       const long long L1 = in ? grid_cell(g, xhi, y, z) + 1 : 0;
-      rb[k] = start[L0];
-      re[k] = in ? start[L1] : rb[k];
-    }
+      const int b = start[L0];
+      return make_int2(b, in ? start[L1] : b);
+    };
+    Runs9 runs;
+    runs.r0 = run_of(0); runs.r1 = run_of(1); runs.r2 = run_of(2);
+    runs.r3 = run_of(3); runs.r4 = run_of(4); runs.r5 = run_of(5);
+    runs.r6 = run_of(6); runs.r7 = run_of(7); runs.r8 = run_of(8);
     // scratch row of `cap` >= limit entries: a query with more than `limit` (but at most cap)
     // supports in range keeps them all and k_sort_rows cuts the row.  A query with MORE than cap
     // in range (dense regions: LiDAR ground near the sensor has 100-150 points within the first
@@ -526,7 +540,7 @@ __global__ __launch_bounds__(256) void k_scan_table(
     };
     // the 9 record runs as ONE candidate sequence, 8 records in flight
     auto scan = [&]() {
-      int k = 0, j = rb[0], e = re[0];
+      int k = 0, j = runs.r0.x, e = runs.r0.y;
       while (k < 9) {
         float4 s8[8];
         bool v8[8];
@@ -534,8 +548,9 @@ __global__ __launch_bounds__(256) void k_scan_table(
         for (int u = 0; u < 8; ++u) {
           while (k < 9 && j >= e) {
             ++k;
-            j = pick9(k, rb);
-            e = pick9(k, re);
+            const int2 r = pick9(k, runs);
+            j = r.x;
+            e = r.y;
           }
           v8[u] = k < 9;
           s8[u] = rec[v8[u] ? j : 0];
@@ -572,14 +587,16 @@ __global__ __launch_bounds__(256) void k_scan_table(
 
 // Sort kernel: one thread per query row; keys staged slot-major in LDS
 // (conflict-free) and ordered by ranking, four ranks per pass over the row so
-// each LDS read feeds four compares.  (Measured alternative: no LDS, rows re-read from the
-// slot-major global scratch at full occupancy -- 136 vs 92 us per call.)
+// each LDS read feeds four compares.  LDS holds the first `lslots` (= limit) entries of a row -- the
+// occupancy of this kernel is set by its LDS, and most rows are shorter than `limit`; the entries
+// beyond are re-read from the slot-major scratch.  (Measured alternative: no LDS at all, every pass
+// from the scratch at full occupancy -- 136 vs 92 us per call.)
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_sort_rows(const unsigned long long* __restrict__ tmp_key,
                                                      const int* __restrict__ kept_in,
                                                      const int* __restrict__ qid_in,
                                                      const int* __restrict__ err, int nq, int ns,
-                                                     int limit, int cap, int* __restrict__ out) {
+                                                     int limit, int lslots, int* __restrict__ out) {
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned long long* l_key = (unsigned long long*)smem;
   const int t = threadIdx.x;
@@ -587,17 +604,27 @@ __global__ __launch_bounds__(BLOCK) void k_sort_rows(const unsigned long long* _
   if (*err || i >= nq) return;
   const int kept = kept_in[i];
   const unsigned long long* src = tmp_key + i;          // slot-major scratch of k_scan_table's thread i
-  for (int k = 0; k < kept; ++k) l_key[k * BLOCK + t] = src[(size_t)k * nq];
+  const size_t rs = (size_t)nq;
+  const int staged = min(kept, lslots);
+  for (int k = 0; k < staged; ++k) l_key[k * BLOCK + t] = src[rs * k];
+  auto key_at = [&](int k) { return k < lslots ? l_key[k * BLOCK + t] : src[rs * k]; };
   int* row = out + (size_t)qid_in[i] * limit;
   constexpr unsigned long long kInf = ~0ull;
   for (int a = 0; a < kept; a += 4) {
-    const unsigned long long k0 = l_key[a * BLOCK + t];
-    const unsigned long long k1 = a + 1 < kept ? l_key[(a + 1) * BLOCK + t] : kInf;
-    const unsigned long long k2 = a + 2 < kept ? l_key[(a + 2) * BLOCK + t] : kInf;
-    const unsigned long long k3 = a + 3 < kept ? l_key[(a + 3) * BLOCK + t] : kInf;
+    const unsigned long long k0 = key_at(a);
+    const unsigned long long k1 = a + 1 < kept ? key_at(a + 1) : kInf;
+    const unsigned long long k2 = a + 2 < kept ? key_at(a + 2) : kInf;
+    const unsigned long long k3 = a + 3 < kept ? key_at(a + 3) : kInf;
     int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-    for (int b = 0; b < kept; ++b) {
+    for (int b = 0; b < staged; ++b) {
       const unsigned long long kb = l_key[b * BLOCK + t];
+      r0 += kb < k0 ? 1 : 0;
+      r1 += kb < k1 ? 1 : 0;
+      r2 += kb < k2 ? 1 : 0;
+      r3 += kb < k3 ? 1 : 0;
+    }
+    for (int b = staged; b < kept; ++b) {
+      const unsigned long long kb = src[rs * b];
       r0 += kb < k0 ? 1 : 0;
       r1 += kb < k1 ? 1 : 0;
       r2 += kb < k2 ? 1 : 0;
@@ -692,9 +719,9 @@ int table_query(const float* q_xyz, const int* q_cu, int nq, int self, int ns, i
   const float inv_cell = 1.0f / (radius * (1.0f + 1.0f / 256.0f));
   hipLaunchKernelGGL(k_scan_table, dim3(cdiv(nq, 256)), dim3(256), 0, stream, q_xyz, q_cu, nq, nb, t.ginfo, t.start,
                      t.rec, t.hdr + kHdrErr, r2, inv_cell, rcap, limit, self, tmp_key, kept, qid, t.hdr + kHdrSlot0 + slot);
-  constexpr int BLOCK = 64;   // cap <= 128 -> at most 64 KB of LDS
-  hipLaunchKernelGGL(k_sort_rows<BLOCK>, dim3(cdiv(nq, BLOCK)), dim3(BLOCK), (size_t)rcap * 8 * BLOCK, stream, tmp_key,
-                     kept, qid, t.hdr + kHdrErr, nq, ns, limit, rcap, out_idx);
+  constexpr int BLOCK = 64;   // limit <= 128 -> at most 64 KB of LDS
+  hipLaunchKernelGGL(k_sort_rows<BLOCK>, dim3(cdiv(nq, BLOCK)), dim3(BLOCK), (size_t)limit * 8 * BLOCK, stream, tmp_key,
+                     kept, qid, t.hdr + kHdrErr, nq, ns, limit, limit, out_idx);
   hipLaunchKernelGGL(k_nbr_err2, dim3(1), dim3(1), 0, stream, t.hdr, slot, max_count);
   SPR_LAUNCH_CHECK();
   return 0;
