@@ -53,12 +53,16 @@ open(f"profiles/{tag}_pmc_hbm_summary.txt", "w").write("\n".join(lines) + "\n")
 
 # roofline kernel: match the instantiation bench.py reported (cin -> CC template argument)
 cin, cout = int(roof["code"]) // 100000, int(roof["code"]) % 100000
-cands = {k: v for k, v in fetch.items() if "k_kpconv_ring" in k or "k_kpconv_mfma" in k}
-# pick the variant whose launch count per forward and channel chunk match: the CSV name carries
-# <CC, TQ, NTW, NW, SK>; CC = 64 if cin % 64 == 0 else 32, NTW = cout / (16 * (8 / SK) ... ) -> match on avg ms instead
+# the ring kernel's mangled name carries <CC = cin, COUT, NS> (k_kpconv_ringILi64ELi64ELi4EE...); shapes served by
+# the streamed kernel (k_kpconv_mfma<CC, TQ, ...>) are matched on the average launch time instead
 stats_rows = {r["Name"]: r for r in csv.DictReader(open(stats))}
-target_ns = roof["avg_launch_ms"] * 1e6
-pick = min(cands, key=lambda k: abs(float(stats_rows[k]["AverageNs"]) - target_ns) if k in stats_rows else 1e30)
+ring = [k for k in fetch if f"k_kpconv_ringILi{cin}ELi{cout}E" in k]
+if ring:
+    pick = ring[0]
+else:
+    cands = {k: v for k, v in fetch.items() if "k_kpconv_mfma" in k}
+    target_ns = roof["avg_launch_ms"] * 1e6
+    pick = min(cands, key=lambda k: abs(float(stats_rows[k]["AverageNs"]) - target_ns) if k in stats_rows else 1e30)
 f, c = fetch[pick]
 w = write.get(pick, (0.0, 0))[0]
 out = dict(tag=tag, collected_utc=datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%M:%SZ"),
