@@ -331,6 +331,19 @@ int spr_attn_inproj_varlen_fwd(const float* x_qk, const float* x_v, int t,
                                float scale, float* out, int o_stride, void* ws,
                                size_t ws_bytes, void* stream);
 
+/* Backward of spr_attn_varlen_fwd (the graph torch autograd builds for the attention core of
+ * nn.MultiheadAttention, transformers.py:198-227), flash style: the Lq x Lk matrices are recomputed
+ * tile by tile and never written.  out = the forward's output, dout = its gradient; kv_seg must be a
+ * permutation of the segments, q_seg its inverse.  Exact f32 MFMA, fixed summation order (bitwise
+ * reproducible).  dq, dk, dv [t, nhead * 32] contiguous, fully written.  head_dim = 32.
+ */
+size_t spr_attn_bwd_workspace_bytes(int t, int nhead);
+int spr_attn_varlen_bwd(const float* q, int q_stride, const float* k, int k_stride, const float* v,
+                        int v_stride, const float* out, int o_stride, const float* dout,
+                        int do_stride, const int* cu, const int* kv_seg, const int* q_seg, int t,
+                        int nseg, int max_len_host, int nhead, int head_dim, float scale,
+                        float* dq, float* dk, float* dv, void* ws, size_t ws_bytes, void* stream);
+
 /* Arithmetic of the attention core:
  *   1 (default) = split-fp16 MFMA (Q, K, V and the probabilities carried as fp16
  *     hi + lo; Q/K balanced and V scaled by powers of two derived from measured

@@ -277,75 +277,27 @@ class GatherRowsFn(torch.autograd.Function):
 
 
 class AttentionFn(torch.autograd.Function):
-    """Varlen multi-head attention core (spr_attn_varlen_fwd).  Backward recomputes the
-    probabilities per (segment, head) into scratch (nothing of size Lq x Lk is kept from the
-    forward) and forms dV = P^T dO, dP = dO V^T, dS = P (dP - rowsum(P dP)), dQ = dS K / sqrt(d),
-    dK = dS^T Q / sqrt(d) with batched spr_bgemm calls over the (segment, head) pairs."""
+    """Varlen multi-head attention core (spr_attn_varlen_fwd).  Backward = spr_attn_varlen_bwd: the
+    probabilities are recomputed tile by tile inside two kernels (dQ; dK and dV) -- nothing of size
+    Lq x Lk is kept from the forward or written by the backward."""
 
     @staticmethod
     def forward(ctx, q, k, v, cu, kv_seg, max_len, nhead, lens_host, kv_seg_host):
         with torch.no_grad():
             out = _ops.attention_raw(q, k, v, cu, kv_seg, max_len, nhead)
-        ctx.meta = (int(nhead), [int(x) for x in lens_host], [int(x) for x in kv_seg_host])
-        ctx.save_for_backward(q, k, v)
+        kvs = [int(x) for x in kv_seg_host]
+        if sorted(kvs) != list(range(len(kvs))):
+            raise NotImplementedError("attention backward needs kv_seg to be a permutation of the segments")
+        ctx.meta = (int(nhead), int(max_len), kvs)
+        ctx.save_for_backward(q, k, v, out, cu)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        q, k, v = ctx.saved_tensors
-        nhead, lens, kvs = ctx.meta
-        if sorted(kvs) != list(range(len(lens))):
-            raise NotImplementedError("attention backward needs kv_seg to be a permutation of the segments")
-        dev = q.device
-        T, d = q.shape
-        hd = d // nhead
-        scale = 1.0 / math.sqrt(hd)
-        dout = dout.contiguous()
-        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        qs, ks, vs = q.stride(0), k.stride(0), v.stride(0)
-        # scratch matrices, one per (segment, head)
-        moff, total = [], 0
-        for s, lq in enumerate(lens):
-            lk = lens[kvs[s]]
-            for h in range(nhead):
-                moff.append(total)
-                total += lq * lk
-        P = torch.empty((max(total, 1),), dtype=torch.float32, device=dev)
-        dP = torch.empty_like(P)
-        dq = torch.zeros((T, d), dtype=torch.float32, device=dev)
-        dk = torch.zeros((T, d), dtype=torch.float32, device=dev)
-        dv = torch.zeros((T, d), dtype=torch.float32, device=dev)
-        qd, kd, vd = q.detach(), k.detach(), v.detach()
-        # row stride of the scratch matrix differs per batch (= lk): fold it by launching per distinct lk
-        by_lk = {}
-        i = 0
-        for s, lq in enumerate(lens):
-            ksg = kvs[s]
-            lk = lens[ksg]
-            for h in range(nhead):
-                by_lk.setdefault(lk, []).append((int(offs[s]), int(offs[ksg]), lq, lk, h * hd, moff[i]))
-                i += 1
-        L = _lib.lib()
-        for lk, items in by_lk.items():
-            max_lq = max(it[2] for it in items)
-            # S
-            bgemm(qd, kd, P, [(qo * qs + ho, ko * ks + ho, mo, lq, lk, hd) for qo, ko, lq, _, ho, mo in items],
-                  (qs, 1), (1, ks), (lk, 1), alpha=scale)
-            dsc = _desc([(0, 0, mo, lq, lk, 0) for _, _, lq, _, _, mo in items], dev)
-            _lib.check(L.spr_softmax_rows(_ops._ptr(P), _ops._ptr(dsc), len(items), max_lq, _ops._stream(q)), "spr_softmax_rows")
-            # dV[keys, head] = P^T dO
-            bgemm(P, dout, dv, [(mo, qo * d + ho, ko * d + ho, lk, hd, lq) for qo, ko, lq, _, ho, mo in items],
-                  (1, lk), (d, 1), (d, 1))
-            # dP = dO V^T
-            bgemm(dout, vd, dP, [(qo * d + ho, ko * vs + ho, mo, lq, lk, hd) for qo, ko, lq, _, ho, mo in items],
-                  (d, 1), (1, vs), (lk, 1))
-            _lib.check(L.spr_softmax_bwd_rows(_ops._ptr(P), _ops._ptr(dP), _ops._ptr(dsc), len(items), max_lq,
-                                              _ops._stream(q)), "spr_softmax_bwd_rows")
-            # dQ = scale dS K ; dK = scale dS^T Q
-            bgemm(dP, kd, dq, [(mo, ko * ks + ho, qo * d + ho, lq, hd, lk) for qo, ko, lq, _, ho, mo in items],
-                  (lk, 1), (ks, 1), (d, 1), alpha=scale)
-            bgemm(dP, qd, dk, [(mo, qo * qs + ho, ko * d + ho, lk, hd, lq) for qo, ko, lq, _, ho, mo in items],
-                  (1, lk), (qs, 1), (d, 1), alpha=scale)
+        q, k, v, out, cu = ctx.saved_tensors
+        nhead, max_len, kvs = ctx.meta
+        dq, dk, dv = _ops.attention_bwd(q.detach(), k.detach(), v.detach(), out.detach(), dout.contiguous(), cu, kvs,
+                                        max_len, nhead)
         return dq, dk, dv, None, None, None, None, None, None
 
 

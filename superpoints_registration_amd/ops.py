@@ -655,6 +655,45 @@ def attention_raw(q, k, v, cu, kv_seg, max_len: int, nhead: int, out=None) -> to
     return out
 
 
+_seg_perm_cache = {}
+
+
+def _segment_perms(kv_seg_host, device):
+    """(kv_seg, inverse) as int32 device tensors for a host-side permutation (cached: a model uses two --
+    the identity for self attention and the src <-> tgt swap for cross attention)."""
+    key = (tuple(int(x) for x in kv_seg_host), str(device))
+    c = _seg_perm_cache.get(key)
+    if c is None:
+        kv = np.asarray(key[0], dtype=np.int32)
+        inv = np.empty_like(kv)
+        inv[kv] = np.arange(kv.size, dtype=np.int32)
+        c = (torch.from_numpy(kv).to(device), torch.from_numpy(inv).to(device))
+        _seg_perm_cache[key] = c
+    return c
+
+
+def attention_bwd(q, k, v, out, dout, cu, kv_seg_host, max_len: int, nhead: int):
+    """Gradients (dq, dk, dv) of attention_raw (spr_attn_varlen_bwd: flash-style, exact f32 MFMA)."""
+    for t, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout")):
+        if not t.is_cuda or t.dtype != torch.float32 or t.stride(1) != 1:
+            raise RuntimeError(f"attention_bwd: {nm} must be a float32 device tensor with unit inner stride")
+    T, d = q.shape
+    hd = d // nhead
+    cu = _dev(cu, "cu", torch.int32)
+    nseg = cu.numel() - 1
+    kv, inv = _segment_perms(kv_seg_host, q.device)
+    dq = torch.empty((T, d), dtype=torch.float32, device=q.device)
+    dk = torch.empty_like(dq)
+    dv = torch.empty_like(dq)
+    L = _lib.lib()
+    ws = _workspace(L.spr_attn_bwd_workspace_bytes(T, nhead), q.device)
+    _lib.check(L.spr_attn_varlen_bwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(out),
+                                     out.stride(0), _ptr(dout), dout.stride(0), _ptr(cu), _ptr(kv), _ptr(inv), T, nseg,
+                                     int(max_len), nhead, hd, 1.0 / math.sqrt(hd), _ptr(dq), _ptr(dk), _ptr(dv),
+                                     _ptr(ws), ws.numel(), _stream(q)), "spr_attn_varlen_bwd")
+    return dq, dk, dv
+
+
 def inproj_prepare(w_in: torch.Tensor):
     """Weight-side inputs of the fused in-projection (max |w| partials + row L1 norms), measured
     once per weight version and cached on the tensor like _static_range."""

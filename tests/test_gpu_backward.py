@@ -134,6 +134,37 @@ def test_attention_backward(device):
     assert _rel(dq.grad, cq.grad) <= 2e-5, f"attention dqkv {_rel(dq.grad, cq.grad):.2e}"
 
 
+def test_attention_backward_many_tiles_and_reproducible(device):
+    """Several 64-row tiles per segment on both sides, self and cross segments of different lengths; two runs
+    must agree bit for bit (fixed summation order: no atomics in spr_attn_varlen_bwd)."""
+    lens, kv_seg = [450, 321, 64, 577], [1, 0, 3, 2]
+    tot = sum(lens)
+    q0, k0, v0 = (synthetic.rand((tot, 256), s, -2.0, 2.0) for s in (21, 22, 23))
+    go = synthetic.rand((tot, 256), 24)
+    cu = ops.lengths_to_cu(lens, device)
+    seg = torch.tensor(kv_seg, dtype=torch.int32, device=device)
+    grads = []
+    for _ in range(2):
+        lq, lk, lv = _leaf(q0, device), _leaf(k0, device), _leaf(v0, device)
+        ops.attention(lq, lk, lv, cu, seg, max(lens), 8, lens_host=lens, kv_seg_host=kv_seg).backward(go.to(device))
+        grads.append((lq.grad.clone(), lk.grad.clone(), lv.grad.clone()))
+    for a, b in zip(grads[0], grads[1]):
+        assert torch.equal(a, b)
+    cq, ck, cv = (t.double().requires_grad_(True) for t in (q0, k0, v0))
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    outs = []
+    for s in range(4):
+        ks = kv_seg[s]
+        q = cq[offs[s]:offs[s + 1]].view(-1, 8, 32).transpose(0, 1)
+        k = ck[offs[ks]:offs[ks + 1]].view(-1, 8, 32).transpose(0, 1)
+        v = cv[offs[ks]:offs[ks + 1]].view(-1, 8, 32).transpose(0, 1)
+        a = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(32), -1)
+        outs.append((a @ v).transpose(0, 1).reshape(-1, 256))
+    torch.cat(outs).backward(go.double())
+    for got, ref, nm in zip(grads[0], (cq.grad, ck.grad, cv.grad), "qkv"):
+        assert _rel(got, ref) <= 2e-5, f"attention d{nm} {_rel(got, ref):.2e}"      # exact-f32 products, fp32 softmax
+
+
 def test_procrustes_backward(device):
     inp = ops_inputs()
     a, b, w = inp["rt.a"].reshape(-1, 3), inp["rt.b"].reshape(-1, 3), inp["rt.w"].reshape(-1)
