@@ -114,8 +114,13 @@ class LinearFn(torch.autograd.Function):
         n = w.shape[0]
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((m, k), dtype=torch.float32, device=x.device)
-            bgemm(g, w.detach().contiguous(), dx, [(0, 0, 0, m, k, n)], (n, 1), (k, 1), (k, 1))
+            if _ops._modes["gemm"] == 1 and n % 32 == 0 and k >= 16:
+                # dX = g W = g (W^T)^T: the forward's NT product (range-scaled split-fp16 MFMA, the arithmetic the
+                # forward itself ran in) on a transposed copy of the weight kept per weight version
+                dx = _ops.linear_raw(g, _ops.weight_transposed(w))
+            else:
+                dx = torch.empty((m, k), dtype=torch.float32, device=x.device)
+                bgemm(g, w.detach().contiguous(), dx, [(0, 0, 0, m, k, n)], (n, 1), (k, 1), (k, 1))
         if ctx.needs_input_grad[1]:
             dw = _tn_product(g, x.detach().contiguous(), m, n, k)
         if ctx.has_bias and ctx.needs_input_grad[2]:

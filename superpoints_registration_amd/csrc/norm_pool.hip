@@ -186,30 +186,62 @@ __global__ __launch_bounds__(256) void k_in_apply(const float* __restrict__ x, c
 // g = dout * (out >= 0 ? 1 : slope);  d add = g;
 // d x = rstd * (g - mean_n(g) - xhat * mean_n(g xhat)),  xhat = (x - mean) rstd   (per cloud, channel)
 // Same deterministic slicing as the forward statistics: partial sums of g and g*xhat in float64.
+// grid (cloud, split, channel block of <= 64 channels) like k_in_stats: (256 / CW4) row lanes x CW4 float4
+// columns, float64 partial sums per thread, row lanes combined through LDS in a fixed order.  (The first
+// form -- one thread per channel walking its 512 rows -- used 32..128 threads of a workgroup: 5.5 ms per
+// training step.)
 __global__ __launch_bounds__(256) void k_in_bwd_stats(const float* __restrict__ x, const float* __restrict__ out,
                                                       const float* __restrict__ dout, const int* __restrict__ cu,
                                                       int c, int nsplit, float slope,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       double* __restrict__ part /*[nb][nsplit][2][c]*/) {
-  const int cloud = blockIdx.x, split = blockIdx.y;
+  const int cloud = blockIdx.x, split = blockIdx.y, cb = blockIdx.z * 64;
   const int beg = cu[cloud], end = cu[cloud + 1];
   const int r0 = beg + split * kSliceRows;
   const int r1 = min(r0 + kSliceRows, end);
-  // thread -> channel (strided), rows sequential: simple and deterministic
-  for (int ch = threadIdx.x; ch < c; ch += 256) {
-    const float mu = mean[(size_t)cloud * c + ch], rs = rstd[(size_t)cloud * c + ch];
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = r0; r < r1; ++r) {
-      const size_t o = (size_t)r * c + ch;
+  const int cw = min(c - cb, 64);
+  const int cw4 = cw >> 2;
+  const int rl = 256 / cw4;  // row lanes
+  const int tc = threadIdx.x % cw4, tr = threadIdx.x / cw4;
+  __shared__ double sh[8][256];
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (tr < rl) {
+    const int col = cb + 4 * tc;
+    const float4 mu = *reinterpret_cast<const float4*>(mean + (size_t)cloud * c + col);
+    const float4 rs = *reinterpret_cast<const float4*>(rstd + (size_t)cloud * c + col);
+    for (int r = r0 + tr; r < r1; r += rl) {
+      const size_t o = (size_t)r * c + col;
+      const float4 xv = *reinterpret_cast<const float4*>(x + o);
+      const float4 ov = *reinterpret_cast<const float4*>(out + o);
+      const float4 dv = *reinterpret_cast<const float4*>(dout + o);
       // (> 0, not >= 0: torch's leaky_relu backward takes the slope branch AT zero, and an output is exactly
       // zero once in ~10^7 elements -- x equal to the rounded mean -- which the BASELINE-size gradient test hits)
-      const float g = dout[o] * (out[o] > 0.f ? 1.f : slope);
-      s1 += (double)g;
-      s2 += (double)g * (double)((x[o] - mu) * rs);
+      const float g0 = dv.x * (ov.x > 0.f ? 1.f : slope), g1 = dv.y * (ov.y > 0.f ? 1.f : slope);
+      const float g2 = dv.z * (ov.z > 0.f ? 1.f : slope), g3 = dv.w * (ov.w > 0.f ? 1.f : slope);
+      s1[0] += (double)g0; s2[0] += (double)g0 * (double)((xv.x - mu.x) * rs.x);
+      s1[1] += (double)g1; s2[1] += (double)g1 * (double)((xv.y - mu.y) * rs.y);
+      s1[2] += (double)g2; s2[2] += (double)g2 * (double)((xv.z - mu.z) * rs.z);
+      s1[3] += (double)g3; s2[3] += (double)g3 * (double)((xv.w - mu.w) * rs.w);
     }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    sh[k][threadIdx.x] = s1[k];
+    sh[4 + k][threadIdx.x] = s2[k];
+  }
+  __syncthreads();
+  if (tr == 0) {
     double* p = part + (((size_t)cloud * nsplit + split) * 2) * c;
-    p[ch] = s1;
-    p[c + ch] = s2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double a = s1[k], b = s2[k];
+      for (int q = 1; q < rl; ++q) {
+        a += sh[k][q * cw4 + tc];
+        b += sh[4 + k][q * cw4 + tc];
+      }
+      p[cb + 4 * tc + k] = a;
+      p[c + cb + 4 * tc + k] = b;
+    }
   }
 }
 
@@ -386,7 +418,7 @@ extern "C" int spr_instnorm_bwd(const float* x, const float* out, const float* d
     hipLaunchKernelGGL(k_in_stats, dim3(nb, nsplit, cdiv(c, 64)), dim3(256), 0, stream, x, cu, c, nsplit, part);
     hipLaunchKernelGGL(k_in_final, dim3(cdiv((long)nb * c, 256)), dim3(256), 0, stream, part, cu, nb, c, nsplit,
                        eps, mean, rstd);
-    hipLaunchKernelGGL(k_in_bwd_stats, dim3(nb, nsplit), dim3(256), 0, stream, x, out, dout, cu, c, nsplit, slope,
+    hipLaunchKernelGGL(k_in_bwd_stats, dim3(nb, nsplit, cdiv(c, 64)), dim3(256), 0, stream, x, out, dout, cu, c, nsplit, slope,
                        mean, rstd, part);
     hipLaunchKernelGGL(k_in_bwd_final, dim3(cdiv((long)nb * c, 256)), dim3(256), 0, stream, part, cu, nb, c, nsplit,
                        m1, m2);

@@ -131,6 +131,18 @@ def _static_range(w: torch.Tensor):
     return parts, n
 
 
+def weight_transposed(w: torch.Tensor) -> torch.Tensor:
+    """Contiguous W^T of a [n, k] weight, kept on the tensor per (storage, version) like its range (the
+    backward's dX = g W runs as the forward's NT product on it); guarded for readers on other streams."""
+    c = getattr(w, '_spr_wt', None)
+    if c is not None and c[1] == w._version and c[2] == w.data_ptr() and c[3] == _range_epoch[0]:
+        c[4].acquire()
+        return c[0]
+    wt = w.detach().t().contiguous()
+    w._spr_wt = (wt, w._version, w.data_ptr(), _range_epoch[0], _StreamGuard(wt))
+    return wt
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only scratch buffer per device+stream (stream-ordered reuse)."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
