@@ -502,17 +502,22 @@ size_t spr_instnorm_bwd_workspace_bytes(int max_len_host, int nb, int c);
 int spr_instnorm_bwd(const float* x, const float* out, const float* dout, const int* cu, int n,
                      int nb, int max_len_host, int c, float eps, int norm, float slope,
                      float* dx, float* dadd, void* ws, size_t ws_bytes, void* stream);
+/* The three scatter-adds of the backward (max-pool, row gather, KPConv neighbour gather) sum in 64-bit
+ * fixed point with integer atomics -- order independent, bitwise reproducible -- and WRITE dx in full
+ * (no pre-zeroing); ws: spr_scatter_workspace_bytes(rows of dx, channels). */
+size_t spr_scatter_workspace_bytes(long rows, int c);
 int spr_maxpool_bwd(const float* x, int ns, int c, const int* idx, int nq, int idx_stride, int k,
-                    const float* dy, float* dx, void* stream);
+                    const float* dy, float* dx, void* ws, size_t ws_bytes, void* stream);
 int spr_scatter_rows_add(const float* dy, const int* idx, int n, int c, int n_src, float* dx,
-                         void* stream);
+                         void* ws, size_t ws_bytes, void* stream);
 int spr_kpconv_weighted_features(const float* q_xyz, int nq, const float* s_xyz, int ns,
                                  const int* nbr, int nbr_stride, int kmax, const float* x, int cin,
                                  const float* kernel_points, int n_kp, float kp_extent,
                                  float* wf, float* cnt, void* stream);
 int spr_kpconv_bwd_dx(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
                       int nbr_stride, int kmax, int cin, const float* kernel_points, int n_kp,
-                      float kp_extent, const float* dwf, float* dx, void* stream);
+                      float kp_extent, const float* dwf, float* dx, void* ws, size_t ws_bytes,
+                      void* stream);
 int spr_softmax_rows(float* mat, const void* desc_dev, int nbatch, int max_m, void* stream);
 int spr_softmax_bwd_rows(const float* p, float* dp, const void* desc_dev, int nbatch, int max_m,
                          void* stream);

@@ -106,10 +106,11 @@ SIGNATURES = {
     "spr_layernorm_bwd": (_i, [_vp, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "spr_instnorm_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "spr_instnorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _f, _vp, _vp, _vp, _sz, _vp]),
-    "spr_maxpool_bwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    "spr_scatter_rows_add": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "spr_scatter_workspace_bytes": (_sz, [_l, _i]),
+    "spr_maxpool_bwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "spr_scatter_rows_add": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "spr_kpconv_weighted_features": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp]),
-    "spr_kpconv_bwd_dx": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp]),
+    "spr_kpconv_bwd_dx": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "spr_softmax_rows": (_i, [_vp, _vp, _i, _i, _vp]),
     "spr_softmax_bwd_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "spr_bce_logits_mean_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),

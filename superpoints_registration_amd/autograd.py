@@ -165,10 +165,12 @@ class KPConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[3]:
             dwf = torch.empty((nq, n_kp * cin), dtype=torch.float32, device=x.device)
             bgemm(g, wflat, dwf, [(0, 0, 0, nq, n_kp * cin, cout)], (cout, 1), (1, cout), (n_kp * cin, 1))
-            dx = torch.zeros((ns, cin), dtype=torch.float32, device=x.device)
+            dx = torch.empty((ns, cin), dtype=torch.float32, device=x.device)
+            ws = _ops._workspace(L.spr_scatter_workspace_bytes(ns, cin), x.device)
             _lib.check(L.spr_kpconv_bwd_dx(_ops._ptr(q_pts), nq, _ops._ptr(s_pts), ns, _ops._ptr(nbr32), int(stride), kmax,
                                            cin, _ops._ptr(kp.detach().contiguous()), n_kp, ctx.kp_extent,
-                                           _ops._ptr(dwf), _ops._ptr(dx), _ops._stream(x)), "spr_kpconv_bwd_dx")
+                                           _ops._ptr(dwf), _ops._ptr(dx), _ops._ptr(ws), ws.numel(), _ops._stream(x)),
+                       "spr_kpconv_bwd_dx")
         if ctx.needs_input_grad[4]:
             # the first layer (cin = 1: constant input) is the ill-conditioned sum: float64 accumulation
             dw = _tn_product(wf, g, nq, n_kp * cin, cout, f64=(cin == 1)).view(n_kp, cin, cout)
@@ -256,9 +258,12 @@ class MaxPoolFn(torch.autograd.Function):
             idx32 = idx32.contiguous()
         ns, c = x.shape
         nq, k = idx32.shape
-        dx = torch.zeros_like(x)
-        _lib.check(_lib.lib().spr_maxpool_bwd(_ops._ptr(x.detach()), ns, c, _ops._ptr(idx32), nq, int(idx32.stride(0)), k,
-                                              _ops._ptr(dy.contiguous()), _ops._ptr(dx), _ops._stream(x)), "spr_maxpool_bwd")
+        dx = torch.empty_like(x)
+        L = _lib.lib()
+        ws = _ops._workspace(L.spr_scatter_workspace_bytes(ns, c), x.device)
+        _lib.check(L.spr_maxpool_bwd(_ops._ptr(x.detach()), ns, c, _ops._ptr(idx32), nq, int(idx32.stride(0)), k,
+                                     _ops._ptr(dy.contiguous()), _ops._ptr(dx), _ops._ptr(ws), ws.numel(), _ops._stream(x)),
+                   "spr_maxpool_bwd")
         return dx, None
 
 
@@ -275,9 +280,11 @@ class GatherRowsFn(torch.autograd.Function):
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
         n_src, c = ctx.shape
-        dx = torch.zeros(ctx.shape, dtype=torch.float32, device=dy.device)
-        _lib.check(_lib.lib().spr_scatter_rows_add(_ops._ptr(dy.contiguous()), _ops._ptr(idx), idx.numel(), c, n_src,
-                                                   _ops._ptr(dx), _ops._stream(dy)), "spr_scatter_rows_add")
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        L = _lib.lib()
+        ws = _ops._workspace(L.spr_scatter_workspace_bytes(n_src, c), dy.device)
+        _lib.check(L.spr_scatter_rows_add(_ops._ptr(dy.contiguous()), _ops._ptr(idx), idx.numel(), c, n_src, _ops._ptr(dx),
+                                          _ops._ptr(ws), ws.numel(), _ops._stream(dy)), "spr_scatter_rows_add")
         return dx, None
 
 

@@ -99,11 +99,40 @@ __global__ __launch_bounds__(256) void k_layernorm_bwd(const float* __restrict__
   }
 }
 
+// ---- order-independent scatter-adds ----------------------------------------------------------------
+// Several queries send a contribution to the same (row, channel) of a gradient (max-pool, row gather, the
+// KPConv's neighbour gather).  Float atomics made those sums depend on the arrival order (run-to-run
+// differences at rounding level).  Here a contribution is converted to 64-bit FIXED POINT -- scaled by a
+// power of two 2^fx derived from the measured maximum of the incoming gradient, so that the largest
+// contribution sits near 2^40 -- and added with integer atomics: integer addition is associative, the
+// result does not depend on the order.  Resolution 2^-40 of the largest contribution (finer than the
+// 2^-24 of a float running sum); 2^22 maximal contributions fit before overflow.  k_fx_to_float converts.
+__device__ __forceinline__ int fx_exp(const float* __restrict__ parts, float* sh, float factor) {
+  return pow2_exp_for(block_absmax(parts, sh) * factor) + 25;    // max |v| 2^fx in [2^39, 2^40)
+}
+__device__ __forceinline__ void fx_add(unsigned long long* acc, float v, int fx) {
+  // v * 2^fx exactly (two exact power-of-two factors keep the intermediate in float range)
+  const float sc = (v * pow2f(fx / 2)) * pow2f(fx - fx / 2);
+  atomicAdd(acc, (unsigned long long)__float2ll_rn(sc));
+}
+__global__ void k_fx_to_float(const unsigned long long* __restrict__ acc, long n, const float* __restrict__ parts,
+                              float factor, float* __restrict__ out) {
+  __shared__ float sh[17];
+  const int fx = fx_exp(parts, sh, factor);
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double inv = (double)pow2f(-(fx / 2)) * (double)pow2f(-(fx - fx / 2));
+  out[i] = (float)((double)(long long)acc[i] * inv);
+}
+
 // ---- max-pool backward (kpconv_blocks.py:127-143): dy goes to the arg-max source row of every
 // (query, channel); the shadow row (index ns) receives nothing.  First maximum wins, like
 // torch.max's index on ties.
-__global__ void k_maxpool_bwd(const float* __restrict__ x, int ns, int c, const int* __restrict__ idx, int nq,
-                              int idx_stride, int k, const float* __restrict__ dy, float* __restrict__ dx) {
+__global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ x, int ns, int c, const int* __restrict__ idx,
+                                                     int nq, int idx_stride, int k, const float* __restrict__ dy,
+                                                     const float* __restrict__ parts, unsigned long long* __restrict__ acc) {
+  __shared__ float sh[17];
+  const int fx = fx_exp(parts, sh, 1.0f);
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)nq * c) return;
   const int row = (int)(gid / c), ch = (int)(gid % c);
@@ -119,17 +148,20 @@ __global__ void k_maxpool_bwd(const float* __restrict__ x, int ns, int c, const 
       bi = ok ? id : -1;
     }
   }
-  if (bi >= 0) atomicAdd(dx + (size_t)bi * c + ch, dy[gid]);
+  if (bi >= 0) fx_add(acc + (size_t)bi * c + ch, dy[gid], fx);
 }
 
 // rows gathered forward (spr_gather_rows) -> scatter-add backward
-__global__ void k_scatter_rows_add(const float* __restrict__ dy, const int* __restrict__ idx, int n, int c,
-                                   int n_src, float* __restrict__ dx) {
+__global__ __launch_bounds__(256) void k_scatter_rows_add(const float* __restrict__ dy, const int* __restrict__ idx, int n,
+                                                          int c, int n_src, const float* __restrict__ parts,
+                                                          unsigned long long* __restrict__ acc) {
+  __shared__ float sh[17];
+  const int fx = fx_exp(parts, sh, 1.0f);
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)n * c) return;
   const int row = (int)(gid / c), ch = (int)(gid % c);
   const int id = idx[row];
-  if (id >= 0 && id < n_src) atomicAdd(dx + (size_t)id * c + ch, dy[gid]);
+  if (id >= 0 && id < n_src) fx_add(acc + (size_t)id * c + ch, dy[gid], fx);
 }
 
 // ---- KPConv backward helpers (kpconv_blocks.py:309-412) --------------------------------------
@@ -146,8 +178,14 @@ __global__ __launch_bounds__(256) void k_kpconv_aux(const float* __restrict__ q_
                                                     const float* __restrict__ x, int cin,
                                                     const float* __restrict__ kpts, int n_kp, float inv_extent,
                                                     const float* __restrict__ dwf, float* __restrict__ wf,
-                                                    float* __restrict__ cnt_out, float* __restrict__ dx) {
+                                                    float* __restrict__ cnt_out, const float* __restrict__ parts,
+                                                    unsigned long long* __restrict__ dx_acc) {
   __shared__ float infl[4][kKPmax];
+  int fx = 0;
+  if (DX) {   // |sum_p infl[p] dwf[p]| <= n_kp max |dwf|
+    __shared__ float sh[17];
+    fx = fx_exp(parts, sh, (float)n_kp);
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + wave;
   if (n >= nq) return;   // whole wave
@@ -186,7 +224,7 @@ __global__ __launch_bounds__(256) void k_kpconv_aux(const float* __restrict__ q_
 #pragma unroll
         for (int p = 0; p < kKPmax; ++p)
           if (p < n_kp) v += infl[wave][p] * dw[p];
-        if (cok && v != 0.f) atomicAdd(dx + (size_t)id * cin + c, v);
+        if (cok && v != 0.f) fx_add(dx_acc + (size_t)id * cin + c, v, fx);
       } else {
         const float xv = cok ? x[(size_t)id * cin + c] : 0.f;
 #pragma unroll
@@ -293,22 +331,56 @@ extern "C" int spr_layernorm_bwd(const float* x, int m, int c, const float* gamm
   return spr_reduce_parts(db, kLnBlocks, c, 1.0f, dbeta, 0, stream_);
 }
 
+// scratch of the order-independent scatter-adds: the fixed-point accumulators + the range partials of the
+// incoming gradient
+extern "C" size_t spr_scatter_workspace_bytes(long rows, int c) {
+  return align_up((size_t)(rows > 0 ? rows : 1) * (size_t)(c > 0 ? c : 1) * sizeof(unsigned long long), 256) +
+         align_up(kAmaxParts * sizeof(float), 256);
+}
+namespace {
+struct FxScratch {
+  unsigned long long* acc;
+  float* parts;
+};
+int fx_scratch(void* ws, size_t ws_bytes, long rows, int c, hipStream_t stream, FxScratch* out) {
+  SPR_REQUIRE(ws != nullptr && ws_bytes >= spr_scatter_workspace_bytes(rows, c), "scatter: workspace too small");
+  Workspace w(ws, ws_bytes);
+  out->acc = w.take<unsigned long long>((size_t)rows * c);
+  out->parts = w.take<float>(kAmaxParts);
+  SPR_REQUIRE(out->parts != nullptr, "scatter: workspace carve failed");
+  SPR_HIP_CHECK(hipMemsetAsync(out->acc, 0, (size_t)rows * c * sizeof(unsigned long long), stream));
+  return 0;
+}
+}  // namespace
+
+// dx [ns, c] is fully written (ws: spr_scatter_workspace_bytes(ns, c))
 extern "C" int spr_maxpool_bwd(const float* x, int ns, int c, const int* idx, int nq, int idx_stride, int k,
-                               const float* dy, float* dx, void* stream_) {
+                               const float* dy, float* dx, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(nq > 0 && ns > 0 && c >= 1 && k >= 1 && k <= idx_stride, "maxpool_bwd: bad arguments");
+  FxScratch f;
+  if (int rc = fx_scratch(ws, ws_bytes, ns, c, stream, &f)) return rc;
+  if (int rc = launch_absmax(dy, nq, c, c, f.parts, stream)) return rc;
   hipLaunchKernelGGL(k_maxpool_bwd, dim3(cdiv((long)nq * c, 256)), dim3(256), 0, stream, x, ns, c, idx, nq,
-                     idx_stride, k, dy, dx);
+                     idx_stride, k, dy, f.parts, f.acc);
+  hipLaunchKernelGGL(k_fx_to_float, dim3(cdiv((long)ns * c, 256)), dim3(256), 0, stream, f.acc, (long)ns * c, f.parts,
+                     1.0f, dx);
   SPR_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int spr_scatter_rows_add(const float* dy, const int* idx, int n, int c, int n_src, float* dx,
-                                    void* stream_) {
+// dx [n_src, c] is fully written (ws: spr_scatter_workspace_bytes(n_src, c))
+extern "C" int spr_scatter_rows_add(const float* dy, const int* idx, int n, int c, int n_src, float* dx, void* ws,
+                                    size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(n > 0 && c >= 1 && n_src > 0, "scatter_rows_add: bad arguments");
+  FxScratch f;
+  if (int rc = fx_scratch(ws, ws_bytes, n_src, c, stream, &f)) return rc;
+  if (int rc = launch_absmax(dy, n, c, c, f.parts, stream)) return rc;
   hipLaunchKernelGGL(k_scatter_rows_add, dim3(cdiv((long)n * c, 256)), dim3(256), 0, stream, dy, idx, n, c, n_src,
-                     dx);
+                     f.parts, f.acc);
+  hipLaunchKernelGGL(k_fx_to_float, dim3(cdiv((long)n_src * c, 256)), dim3(256), 0, stream, f.acc, (long)n_src * c,
+                     f.parts, 1.0f, dx);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -322,20 +394,27 @@ extern "C" int spr_kpconv_weighted_features(const float* q_xyz, int nq, const fl
                   kmax <= nbr_stride, "kpconv_weighted_features: bad arguments");
   hipLaunchKernelGGL(k_kpconv_aux<false>, dim3(cdiv(nq, 4)), dim3(256), 0, stream, q_xyz, nq, s_xyz, ns, nbr,
                      nbr_stride, kmax, x, cin, kernel_points, n_kp, 1.0f / kp_extent, (const float*)nullptr, wf, cnt,
-                     (float*)nullptr);
+                     (const float*)nullptr, (unsigned long long*)nullptr);
   SPR_LAUNCH_CHECK();
   return 0;
 }
 
+// dx [ns, cin] is fully written (ws: spr_scatter_workspace_bytes(ns, cin)); order-independent sums
 extern "C" int spr_kpconv_bwd_dx(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
                                  int nbr_stride, int kmax, int cin, const float* kernel_points, int n_kp,
-                                 float kp_extent, const float* dwf, float* dx, void* stream_) {
+                                 float kp_extent, const float* dwf, float* dx, void* ws, size_t ws_bytes,
+                                 void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(nq > 0 && ns > 0 && cin >= 1 && n_kp >= 1 && n_kp <= kKPmax && kp_extent > 0.f && kmax >= 1 &&
                   kmax <= nbr_stride, "kpconv_bwd_dx: bad arguments");
+  FxScratch f;
+  if (int rc = fx_scratch(ws, ws_bytes, ns, cin, stream, &f)) return rc;
+  if (int rc = launch_absmax(dwf, nq, n_kp * cin, n_kp * cin, f.parts, stream)) return rc;
   hipLaunchKernelGGL(k_kpconv_aux<true>, dim3(cdiv(nq, 4)), dim3(256), 0, stream, q_xyz, nq, s_xyz, ns, nbr,
                      nbr_stride, kmax, (const float*)nullptr, cin, kernel_points, n_kp, 1.0f / kp_extent, dwf,
-                     (float*)nullptr, (float*)nullptr, dx);
+                     (float*)nullptr, (float*)nullptr, f.parts, f.acc);
+  hipLaunchKernelGGL(k_fx_to_float, dim3(cdiv((long)ns * cin, 256)), dim3(256), 0, stream, f.acc, (long)ns * cin,
+                     f.parts, (float)n_kp, dx);
   SPR_LAUNCH_CHECK();
   return 0;
 }

@@ -271,6 +271,24 @@ def _train_step(tag, device, which):
     return g, model, losses
 
 
+def test_backward_is_bitwise_reproducible(device):
+    """Every sum of the backward has a fixed order -- deterministic split-K partials, the flash-style attention
+    backward, and 64-bit fixed-point integer atomics for the three scatter-adds (max-pool, row gather, KPConv
+    neighbour gather: float atomics before round 3) -- so two runs of the same step give the same bits in
+    every parameter gradient."""
+    _, m1, _ = _train_step("3dmatch", device, "total")
+    _, m2, _ = _train_step("3dmatch", device, "total")
+    n = 0
+    for (k1, p1), (k2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert k1 == k2
+        if p1.grad is None:
+            assert p2.grad is None
+            continue
+        assert torch.equal(p1.grad, p2.grad), k1
+        n += 1
+    assert n > 100
+
+
 @pytest.mark.parametrize("which", ["fo", "total"])
 @pytest.mark.parametrize("tag", ["3dmatch", "kitti", "modelnet"])
 def test_parameter_gradients_match_the_reference(device, tag, which):
