@@ -51,12 +51,20 @@ def _reduce_parts(parts, nparts, n, out):
     return out
 
 
-_CHUNK = 2048   # rows of the long dimension per split-K batch
+def _tn_chunk(rows, nl, nr):
+    """Rows of the long dimension per split-K batch: enough batches that tiles x batches fills the chip
+    (a [256, 256] weight gradient is FOUR 128 x 128 tiles: with 2 048-row batches a 15 k-token product ran
+    on 32 of 256 CUs), but at least 256 rows per batch.  A fixed function of the shapes, so the summation
+    order -- and with it the result, bit for bit -- does not depend on anything else."""
+    tiles = ((nl + 127) // 128) * ((nr + 127) // 128 if nr > 32 else 1)
+    nchunk = max(1, min(rows // 256, max(1, 512 // tiles)))
+    chunk = (rows + nchunk - 1) // nchunk
+    return (chunk + 15) // 16 * 16       # whole K slabs
 
 
 def _tn_product(L, Rm, rows, nl, nr, f64=False):
     """out[nl, nr] = L[rows, nl]^T @ R[rows, nr] (both row-major, contiguous): deterministic split
-    over `rows` into _CHUNK-row batches + fixed-order reduction -- weight gradients.  f64: float64
+    over `rows` into batches (_tn_chunk) + fixed-order reduction -- weight gradients.  f64: float64
     accumulation (spr_tn_product_f64) for small outputs whose summands nearly cancel."""
     if f64 and nl * nr <= 65536:
         lib = _lib.lib()
@@ -65,12 +73,13 @@ def _tn_product(L, Rm, rows, nl, nr, f64=False):
         _lib.check(lib.spr_tn_product_f64(_ops._ptr(L), _ops._ptr(Rm), rows, nl, nr, _ops._ptr(out), _ops._ptr(ws),
                                           ws.numel(), _ops._stream(L)), "spr_tn_product_f64")
         return out
-    nchunk = (rows + _CHUNK - 1) // _CHUNK
+    chunk = _tn_chunk(rows, nl, nr)
+    nchunk = (rows + chunk - 1) // chunk
     parts = torch.empty((nchunk, nl, nr), dtype=torch.float32, device=L.device)
     recs = []
     for c in range(nchunk):
-        r0 = c * _CHUNK
-        recs.append((r0 * nl, r0 * nr, c * nl * nr, nl, nr, min(_CHUNK, rows - r0)))
+        r0 = c * chunk
+        recs.append((r0 * nl, r0 * nr, c * nl * nr, nl, nr, min(chunk, rows - r0)))
     bgemm(L, Rm, parts, recs, (1, nl), (nr, 1), (nr, 1))
     if nchunk == 1:
         return parts[0]
