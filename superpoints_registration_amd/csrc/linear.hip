@@ -870,7 +870,9 @@ int launch_gemm(const float* x, int m, int k, const float* w, int n, const float
       if (op && out_n) *out_n = ntiles;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds(128, 256), stream, x, m, w, n, bias, out,
                          a_parts, n_aparts, w_parts, n_wparts, op, ntiles);
-    } else if (n >= 256 && m >= 256) {
+    } else if (n >= 256 && m >= 256 && cdiv(n, 256) * cdiv(m, 256) >= 128) {
+      // (fewer than 128 such tiles -- a training batch of 15 k tokens and N = 256 gives 61 -- leave most of the
+      // chip idle: the 128x64 tiles below then win although they move more operand bytes)
       // 256x256 tiles, 8 waves of 64x128: ~64 flop per operand byte fetched from
       // L2 (the 128-wide tiles below need 2-4x the L2 traffic and are bound by it)
       auto kern = spr::k_gemm_nt_h3<256, 256, 4, 2, ACT, RES>;
@@ -881,9 +883,12 @@ int launch_gemm(const float* x, int m, int k, const float* w, int n, const float
       hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds(256, 256), stream, x, m, k,
                          w, n, bias, residual, out, spr::AttnPlanes(), 0, a_parts, n_aparts, w_parts, op, (const spr::GemmGroup*)nullptr, n_wparts);
     } else if (n > 32) {
-      hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 64, 4, 1, ACT, RES>), dim3(cdiv(n, 64) * cdiv(m, 128)),
+      const int grid = cdiv(n, 64) * cdiv(m, 128);
+      float* op = (out_parts && grid <= out_cap) ? out_parts : nullptr;   // range published only if it fits
+      if (op && out_n) *out_n = grid;
+      hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 64, 4, 1, ACT, RES>), dim3(grid),
                          dim3(256), lds(128, 64), stream, x, m, k, w, n, bias, residual, out, spr::AttnPlanes(), 0,
-                         a_parts, n_aparts, w_parts, (float*)nullptr, (const spr::GemmGroup*)nullptr, n_wparts);
+                         a_parts, n_aparts, w_parts, op, (const spr::GemmGroup*)nullptr, n_wparts);
     } else {
       hipLaunchKernelGGL((spr::k_gemm_nt_h3<128, 32, 4, 1, ACT, RES>), dim3(cdiv(n, 32) * cdiv(m, 128)),
                          dim3(256), lds(128, 32), stream, x, m, k, w, n, bias, residual, out, spr::AttnPlanes(), 0,
