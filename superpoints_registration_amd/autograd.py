@@ -33,10 +33,15 @@ def _desc(records, device):
     return torch.from_numpy(arr.view(np.uint8).copy()).to(device)
 
 
+_BGEMM_LOG = None   # experiment hook: a list collects (batches, m, n, k, strides) of every call
+
+
 def bgemm(A, B, C, records, sa, sb, sc, alpha=1.0, beta=0.0):
     """C_b(i,j) = alpha sum_k A_b(i,k) B_b(k,j) + beta C_b(i,j); sa = (sa_i, sa_k), sb = (sb_k, sb_j),
     sc = (sc_i, sc_j) element strides; records = per-batch (a_off, b_off, c_off, m, n, k)."""
     d = _desc(records, A.device)
+    if _BGEMM_LOG is not None:
+        _BGEMM_LOG.append((len(records), records[0][3], records[0][4], records[0][5], tuple(sa), tuple(sb)))
     max_m = max(r[3] for r in records)
     max_n = max(r[4] for r in records)
     _lib.check(_lib.lib().spr_bgemm(_ops._ptr(A), _ops._ptr(B), _ops._ptr(C), _ops._ptr(d), len(records), max_m, max_n,
@@ -513,10 +518,10 @@ class InfoNCEFn(torch.autograd.Function):
         bgemm(dl, p, dt, [(0, 0, 0, n, d, m)], (m, 1), (d, 1), (d, 1))
         da = torch.empty((n, d), dtype=torch.float32, device=dev)          # dA = dt W_sym^T = dt W_sym
         bgemm(dt, wsym, da, [(0, 0, 0, n, d, d)], (d, 1), (d, 1), (d, 1))
-        dp = torch.empty((m, d), dtype=torch.float32, device=dev)          # dB = dl^T t
-        bgemm(dl, t, dp, [(0, 0, 0, m, d, n)], (1, m), (d, 1), (d, 1))
-        dws = torch.empty((d, d), dtype=torch.float32, device=dev)         # dW_sym = A^T dt
-        bgemm(a, dt, dws, [(0, 0, 0, d, d, n)], (1, d), (d, 1), (d, 1))
+        # dB = dl^T t and dW_sym = A^T dt contract over the n anchors into small outputs ([m, d], [d, d] = 24 and 4
+        # tiles): split-K batches like the weight gradients (as single products they ran on 24 / 4 CUs, 0.3 ms each)
+        dp = _tn_product(dl, t, n, m, d)
+        dws = _tn_product(a, dt, n, d, d)
         dW = torch.empty((d, d), dtype=torch.float32, device=dev)
         _lib.check(L.spr_wsym_bwd(_ops._ptr(dws), d, _ops._ptr(dW), _ops._stream(a)), "spr_wsym_bwd")
         return da, dp, None, None, None, dW, None, None
