@@ -587,10 +587,10 @@ __global__ __launch_bounds__(256) void k_scan_table(
 
 // Sort kernel: one thread per query row; keys staged slot-major in LDS
 // (conflict-free) and ordered by ranking, four ranks per pass over the row so
-// each LDS read feeds four compares.  LDS holds the first `lslots` (= limit) entries of a row -- the
-// occupancy of this kernel is set by its LDS, and most rows are shorter than `limit`; the entries
-// beyond are re-read from the slot-major scratch.  (Measured alternative: no LDS at all, every pass
-// from the scratch at full occupancy -- 136 vs 92 us per call.)
+// each LDS read feeds four compares.  LDS holds the first `lslots` entries of a row (the launcher passes the
+// scratch capacity: whole rows); entries beyond would be re-read from the slot-major scratch.  (Measured
+// alternatives: no LDS at all, every pass from the scratch at full occupancy -- 136 vs 92 us per call;
+// lslots = limit -- 88 vs 92 us on voxelised clouds, 1.9 ms per call on LiDAR-shaped scans.)
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_sort_rows(const unsigned long long* __restrict__ tmp_key,
                                                      const int* __restrict__ kept_in,
@@ -719,9 +719,11 @@ int table_query(const float* q_xyz, const int* q_cu, int nq, int self, int ns, i
   const float inv_cell = 1.0f / (radius * (1.0f + 1.0f / 256.0f));
   hipLaunchKernelGGL(k_scan_table, dim3(cdiv(nq, 256)), dim3(256), 0, stream, q_xyz, q_cu, nq, nb, t.ginfo, t.start,
                      t.rec, t.hdr + kHdrErr, r2, inv_cell, rcap, limit, self, tmp_key, kept, qid, t.hdr + kHdrSlot0 + slot);
-  constexpr int BLOCK = 64;   // limit <= 128 -> at most 64 KB of LDS
-  hipLaunchKernelGGL(k_sort_rows<BLOCK>, dim3(cdiv(nq, BLOCK)), dim3(BLOCK), (size_t)limit * 8 * BLOCK, stream, tmp_key,
-                     kept, qid, t.hdr + kHdrErr, nq, ns, limit, limit, out_idx);
+  constexpr int BLOCK = 64;   // cap <= 128 -> at most 64 KB of LDS
+  // whole rows in LDS: staging only the first `limit` entries gave 4 % on voxelised clouds (most rows are
+  // shorter than `limit`) but 1.9 ms per call on LiDAR-shaped scans, whose rows fill the 2 * limit scratch
+  hipLaunchKernelGGL(k_sort_rows<BLOCK>, dim3(cdiv(nq, BLOCK)), dim3(BLOCK), (size_t)rcap * 8 * BLOCK, stream, tmp_key,
+                     kept, qid, t.hdr + kHdrErr, nq, ns, limit, rcap, out_idx);
   hipLaunchKernelGGL(k_nbr_err2, dim3(1), dim3(1), 0, stream, t.hdr, slot, max_count);
   SPR_LAUNCH_CHECK();
   return 0;
