@@ -177,3 +177,33 @@ def test_streamed_encoder_launches_every_block_as_soon_as_its_level_exists():
         want = ('down', bp.level) if bp.down else ('conv', bp.level)
         assert seen == want, (i, seen, want)                         # launched at the first possible event
     assert len(skips) == len(enc.encoder_skips)
+
+
+def test_split_k_batches_fill_the_chip_and_depend_on_shapes_only():
+    """autograd._tn_chunk: rows per split-K batch of a weight gradient L[rows, nl]^T R[rows, nr].  Enough batches
+    that 128 x 128 tiles x batches reaches the CU count, at least 256 rows each, whole 16-deep K slabs -- and a
+    pure function of the shapes (the summation order, hence the gradient bits, depends on nothing else)."""
+    from superpoints_registration_amd.autograd import _tn_chunk
+    for rows, nl, nr in ((15432, 256, 256), (15432, 1024, 256), (131072, 480, 32), (52994, 960, 64), (700, 256, 256),
+                         (100, 64, 64), (61745, 256, 1024)):
+        c = _tn_chunk(rows, nl, nr)
+        assert c % 16 == 0 and c == _tn_chunk(rows, nl, nr)
+        nchunk = (rows + c - 1) // c
+        tiles = ((nl + 127) // 128) * ((nr + 127) // 128 if nr > 32 else 1)
+        assert nchunk >= 1 and (nchunk - 1) * c < rows <= nchunk * c
+        if rows >= 512:
+            assert c >= 256                                     # never batches shorter than 256 rows ...
+            assert tiles * nchunk >= min(200, tiles * (rows // 512))    # ... and a filled chip when the rows allow
+        assert tiles * nchunk <= 1024
+    assert _tn_chunk(15432, 256, 256) < 2048                    # (round 2 used 2 048-row batches: 32 workgroups)
+
+
+def test_segment_permutation_and_its_inverse():
+    """ops._segment_perms: kv_seg of the cross-attention (src <-> tgt swap) and its inverse, the query segment
+    of every key segment, which the dK/dV kernel of the attention backward walks."""
+    from superpoints_registration_amd import ops
+    kv, inv = ops._segment_perms([4, 5, 6, 7, 0, 1, 2, 3], torch.device("cpu"))
+    assert kv.dtype == torch.int32 and kv.tolist() == [4, 5, 6, 7, 0, 1, 2, 3] and inv.tolist() == kv.tolist()
+    kv, inv = ops._segment_perms([2, 0, 3, 1], "cpu")
+    assert inv.tolist() == [1, 3, 0, 2] and all(kv[inv[k]] == k for k in range(4))
+    assert ops._segment_perms([2, 0, 3, 1], "cpu")[0] is kv     # cached per permutation and device
