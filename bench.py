@@ -43,13 +43,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs-per-step", type=int, default=16)
+    ap.add_argument("--pairs-per-step", type=int, default=32,
+                    help="pairs per forward and rank (round 3: 32 -- 3 % above 16 on the same box, 48 another 2 %: the "
+                         "N = 256 products of the transformer then run two rounds of tiles per CU instead of one)")
     ap.add_argument("--no-cross-step-overlap", action="store_true",
                     help="make every forward's pyramid wait for the previous forward's tail (default: inputs "
                          "are resident, so consecutive steps pipeline on the GPU)")
     ap.add_argument("--streams", type=int, default=1,
                     help="concurrent group forwards per step, each on its own HIP stream (streams.py); 2 with "
-                         "--pairs-per-step 32 is the highest-throughput setting, but co-running kernels "
+                         "--pairs-per-step 32 was the highest-throughput setting of round 1, but co-running kernels "
                          "stretch each other, so the per-kernel roofline leg is only meaningful at 1")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--config", default="3dmatch")
