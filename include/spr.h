@@ -486,6 +486,13 @@ int spr_bgemm(const float* A, const float* B, float* C, const void* desc_dev, in
 /* out[nl, nr] = L[rows, nl]^T R[rows, nr] (row-major, contiguous) with float64 accumulation and a
  * fixed-order reduction: weight gradients that are long, nearly cancelling sums (the first KPConv's
  * dW = wf^T g over every point of the batch, kpconv_blocks.py:401-406 differentiated).  nl * nr <= 65536. */
+/* dW = dY^T X in the forward's arithmetic (range-scaled split-fp16 MFMA, fp32 accumulation): per-batch partial
+ * products parts[b][nl][nr] over `chunk` rows each, summed by spr_reduce_parts (fixed order).  L [rows, nl],
+ * R [rows, nr] row-major; nl, nr multiples of 4, chunk a multiple of 16; ranges as in spr_linear_r. */
+size_t spr_tn_product_split_workspace_bytes(void);
+int spr_tn_product_split(const float* L, const float* R, long rows, int nl, int nr, int chunk,
+                         const float* l_range, int l_range_n, const float* r_range, int r_range_n,
+                         float* parts, void* ws, size_t ws_bytes, void* stream);
 size_t spr_tn_product_f64_workspace_bytes(long rows, int nl, int nr);
 int spr_tn_product_f64(const float* L, const float* R, long rows, int nl, int nr, float* out,
                        void* ws, size_t ws_bytes, void* stream);

@@ -96,6 +96,8 @@ SIGNATURES = {
     "spr_sum_scaled": (_i, [_vp, _i, _f, _vp, _vp]),
     "spr_gather_rows": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp]),
     "spr_bgemm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _l, _l, _l, _l, _l, _l, _f, _f, _vp]),
+    "spr_tn_product_split_workspace_bytes": (_sz, []),
+    "spr_tn_product_split": (_i, [_vp, _vp, _l, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "spr_tn_product_f64_workspace_bytes": (_sz, [_l, _i, _i]),
     "spr_tn_product_f64": (_i, [_vp, _vp, _l, _i, _i, _vp, _vp, _sz, _vp]),
     "spr_reduce_parts": (_i, [_vp, _i, _l, _f, _vp, _i, _vp]),

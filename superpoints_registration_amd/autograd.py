@@ -81,6 +81,19 @@ def _tn_product(L, Rm, rows, nl, nr, f64=False):
     chunk = _tn_chunk(rows, nl, nr)
     nchunk = (rows + chunk - 1) // chunk
     parts = torch.empty((nchunk, nl, nr), dtype=torch.float32, device=L.device)
+    if _ops._modes["gemm"] == 1 and nl % 4 == 0 and nr % 4 == 0 and nl >= 32 and nr >= 32 and nchunk <= 65535:
+        # the forward's arithmetic (range-scaled split-fp16 MFMA): spr_tn_product_split + the same fixed-order sum
+        lib = _lib.lib()
+        ws = _ops._workspace(lib.spr_tn_product_split_workspace_bytes(), L.device)
+        lr, lr_n = _ops._get_range(L)
+        rr, rr_n = _ops._get_range(Rm)
+        _lib.check(lib.spr_tn_product_split(_ops._ptr(L), _ops._ptr(Rm), rows, nl, nr, chunk, _ops._ptr(lr), int(lr_n),
+                                            _ops._ptr(rr), int(rr_n), _ops._ptr(parts), _ops._ptr(ws), ws.numel(),
+                                            _ops._stream(L)), "spr_tn_product_split")
+        if nchunk == 1:
+            return parts[0]
+        out = torch.empty((nl, nr), dtype=torch.float32, device=L.device)
+        return _reduce_parts(parts, nchunk, nl * nr, out)
     recs = []
     for c in range(nchunk):
         r0 = c * chunk

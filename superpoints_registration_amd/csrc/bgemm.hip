@@ -317,6 +317,160 @@ extern "C" int spr_tn_product_f64(const float* Lm, const float* Rm, long rows, i
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Weight gradients in the forward's arithmetic (round 3): parts[b][i][j] = sum over the rows t of batch b of
+// L[t, i] R[t, j]  (L = dY [rows, nl], R = X [rows, nr], both row-major) with range-scaled split-fp16 operands
+// and v_mfma_f32_32x32x16_f16 -- three MFMAs per product, fp32 accumulation -- instead of the exact-f32 MFMA
+// of spr_bgemm (1/5 of its matrix-pipe time).  The contraction runs over the ROW index of both operands, so a
+// slab of 32 rows is transposed on its way into LDS: a thread loads a 4 (rows) x 4 (columns) block, splits it
+// and writes, per column, the 4 consecutive-row halves as one 8-byte word into the [column][row] image the
+// MFMA fragments read (8 consecutive k per lane); lanes are mapped row-quad fastest so that the 16 lanes of a
+// ds_write_b64 group cover all banks.  128 x 128 outputs per workgroup of 4 waves (64 x 64 each), slab-deep
+// register prefetch, one workgroup per (tile, row batch); the batches are summed by spr_reduce_parts.
+namespace spr {
+namespace {
+typedef _Float16 th8 __attribute__((ext_vector_type(8)));
+constexpr int TNT = 128;       // output tile edge
+constexpr int TNK = 32;        // rows (contraction) per slab
+constexpr int TNS = 40;        // LDS row stride in halves (32 + 8 pad: conflict-free ds_read_b128)
+
+__global__ __launch_bounds__(256) void k_gemm_tn_h3(const float* __restrict__ Lm, const float* __restrict__ Rm, long rows,
+                                                    int nl, int nr, int chunk, const float* __restrict__ l_parts,
+                                                    int n_lp, const float* __restrict__ r_parts, int n_rp,
+                                                    float* __restrict__ parts) {
+  __shared__ __align__(16) _Float16 Ah[TNT * TNS], Al[TNT * TNS], Bh[TNT * TNS], Bl[TNT * TNS];
+  __shared__ float shf[17];
+  const int tn = (nr + TNT - 1) / TNT;
+  const int i0 = (blockIdx.x / tn) * TNT, j0 = (blockIdx.x % tn) * TNT;
+  const long r_beg = (long)blockIdx.y * chunk;
+  const long r_end = r_beg + chunk < rows ? r_beg + chunk : rows;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wi = (wave >> 1) * 64, wj = (wave & 1) * 64;
+  const int ka = pow2_exp_for(block_absmax(l_parts, shf, n_lp));
+  const int kb = pow2_exp_for(block_absmax(r_parts, shf, n_rp));
+  const float sa = pow2f(ka), sb = pow2f(kb), unscale = pow2f(-ka - kb);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging role: row quad tq (rows 4 tq .. 4 tq + 3 of the slab), column quad n4 (columns 4 n4 .. + 3 of the tile)
+  const int tq = tid & 7, n4 = tid >> 3;
+  const int la = min(i0 + 4 * n4, nl - 4), lb = min(j0 + 4 * n4, nr - 4);   // clamped: columns past the edge are never stored
+  float4 ra[4], rb[4];
+  auto fetch = [&](long t0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long t = t0 + 4 * tq + e;
+      ra[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[e] = ra[e];
+      if (t < r_end) {
+        ra[e] = *reinterpret_cast<const float4*>(Lm + t * nl + la);
+        rb[e] = *reinterpret_cast<const float4*>(Rm + t * nr + lb);
+      }
+    }
+  };
+  auto put = [&](const float4 (&v)[4], float sc, _Float16* hi, _Float16* lo) {
+    const float c[4][4] = {{v[0].x, v[1].x, v[2].x, v[3].x}, {v[0].y, v[1].y, v[2].y, v[3].y},
+                           {v[0].z, v[1].z, v[2].z, v[3].z}, {v[0].w, v[1].w, v[2].w, v[3].w}};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {       // column 4 n4 + q: its four consecutive rows
+      unsigned int h0, l0, h1, l1;
+      split_pk_s(c[q][0], c[q][1], sc, h0, l0);
+      split_pk_s(c[q][2], c[q][3], sc, h1, l1);
+      const int o = (4 * n4 + q) * TNS + 4 * tq;
+      *reinterpret_cast<uint2*>(hi + o) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(lo + o) = make_uint2(l0, l1);
+    }
+  };
+  fetch(r_beg);
+  for (long t0 = r_beg; t0 < r_end; t0 += TNK) {
+    put(ra, sa, Ah, Al);
+    put(rb, sb, Bh, Bl);
+    __syncthreads();
+    if (t0 + TNK < r_end) fetch(t0 + TNK);
+#pragma unroll
+    for (int s2 = 0; s2 < TNK / 16; ++s2) {
+      const int ko = 16 * s2 + 8 * lh;
+      th8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const th8*>(Ah + (wi + 32 * i + l31) * TNS + ko);
+        al[i] = *reinterpret_cast<const th8*>(Al + (wi + 32 * i + l31) * TNS + ko);
+        bh[i] = *reinterpret_cast<const th8*>(Bh + (wj + 32 * i + l31) * TNS + ko);
+        bl[i] = *reinterpret_cast<const th8*>(Bl + (wj + 32 * i + l31) * TNS + ko);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  // C layout: col = l31, row = (r & 3) + 8 (r >> 2) + 4 lh
+  float* P = parts + (size_t)blockIdx.y * nl * nr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = j0 + wj + 32 * j + l31;
+      if (col >= nr) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + wi + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < nl) P[(size_t)row * nr + col] = acc[i][j][r] * unscale;
+      }
+    }
+}
+}  // namespace
+}  // namespace spr
+
+extern "C" size_t spr_tn_product_split_workspace_bytes(void) { return 2 * align_up(kAmaxParts * sizeof(float), 256); }
+
+// parts [nbatch][nl][nr], nbatch = ceil(rows / chunk): the caller sums them (spr_reduce_parts).  l_range / r_range:
+// range partials of L / R (NULL: measured here).  nl, nr multiples of 4; chunk a multiple of 16.
+extern "C" int spr_tn_product_split(const float* Lm, const float* Rm, long rows, int nl, int nr, int chunk,
+                                    const float* l_range, int l_range_n, const float* r_range, int r_range_n,
+                                    float* parts, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(Lm && Rm && parts && rows >= 1 && nl >= 4 && nr >= 4 && nl % 4 == 0 && nr % 4 == 0 && chunk >= 16 &&
+                  chunk % 16 == 0, "tn_product_split: bad arguments (rows=%ld nl=%d nr=%d chunk=%d)", rows, nl, nr, chunk);
+  SPR_REQUIRE(ws != nullptr && ws_bytes >= spr_tn_product_split_workspace_bytes(), "tn_product_split: workspace too small");
+  Workspace w(ws, ws_bytes);
+  float* lp = w.take<float>(kAmaxParts);
+  float* rp = w.take<float>(kAmaxParts);
+  const float* lparts = l_range;
+  const float* rparts = r_range;
+  int nlp = l_range_n, nrp = r_range_n;
+  if (l_range == nullptr) {
+    if (int rc = launch_absmax(Lm, rows, nl, nl, lp, stream)) return rc;
+    lparts = lp;
+    nlp = kAmaxParts;
+  }
+  if (r_range == nullptr) {
+    if (int rc = launch_absmax(Rm, rows, nr, nr, rp, stream)) return rc;
+    rparts = rp;
+    nrp = kAmaxParts;
+  }
+  SPR_REQUIRE(nlp >= 1 && nrp >= 1, "tn_product_split: a range needs a count");
+  const long nbatch = (rows + chunk - 1) / chunk;
+  SPR_REQUIRE(nbatch <= 65535, "tn_product_split: too many batches (%ld)", nbatch);
+  const int tiles = cdiv(nl, spr::TNT) * cdiv(nr, spr::TNT);
+  hipLaunchKernelGGL(spr::k_gemm_tn_h3, dim3(tiles, (unsigned)nbatch), dim3(256), 0, stream, Lm, Rm, rows, nl, nr, chunk,
+                     lparts, nlp, rparts, nrp, parts);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int spr_bgemm(const float* A, const float* B, float* C, const void* desc_dev, int nbatch,
                          int max_m, int max_n, long sa_i, long sa_k, long sb_k, long sb_j, long sc_i,
                          long sc_j, float alpha, float beta, void* stream_) {
