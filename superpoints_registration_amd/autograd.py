@@ -140,6 +140,8 @@ class LinearFn(torch.autograd.Function):
         m, k = x.shape
         n = w.shape[0]
         dx = dw = db = None
+        if _ops._modes["gemm"] == 1 and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            _ops.ensure_range(g)              # dX and dW both scale g: one measuring pass
         if ctx.needs_input_grad[0]:
             if _ops._modes["gemm"] == 1 and n % 32 == 0 and k >= 16:
                 # dX = g W = g (W^T)^T: the forward's NT product (range-scaled split-fp16 MFMA, the arithmetic the

@@ -143,6 +143,20 @@ def weight_transposed(w: torch.Tensor) -> torch.Tensor:
     return wt
 
 
+def ensure_range(t: torch.Tensor) -> torch.Tensor:
+    """Measures max |t| once (spr_absmax) and publishes it on the tensor like a producer kernel would, unless a
+    valid range is already attached: a gradient that feeds two products (dX and dW of a projection) is then
+    scanned once instead of once per product."""
+    if not _HANDOVER or t.dim() != 2 or not t.is_contiguous() or _get_range(t)[0] is not None:
+        return t
+    L = _lib.lib()
+    n = L.spr_range_parts()
+    parts = torch.empty((n,), dtype=torch.float32, device=t.device)
+    _lib.check(L.spr_absmax(_ptr(t), t.shape[0], t.shape[1], t.shape[1], _ptr(parts), _stream(t)), "spr_absmax")
+    _set_range(t, parts, n)
+    return t
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
     """Grow-only scratch buffer per device+stream (stream-ordered reuse)."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
