@@ -181,8 +181,9 @@ def train_leg(cfg, args, dev):
                 stage_ms=dict(forward=round(stage[0] / steps, 2), loss=round(stage[1] / steps, 2),
                               backward=round(stage[2] / steps, 2), clip_adamw=round(stage[3] / steps, 2)),
                 loss_total=round(float(losses["total"].detach()), 5),
-                arithmetic="forward as the headline; backward: dX of the projections through the forward's split-fp16 GEMM, "
-                           "dW / KPConv / attention (flash-style, csrc/attention_bwd.hip) exact f32 MFMA")
+                arithmetic="forward as the headline; backward: dX and dW of the projections and the KPConv dW in the forward's "
+                           "split-fp16 arithmetic; KPConv d(weighted features) and attention (flash-style, "
+                           "csrc/attention_bwd.hip) exact f32 MFMA")
 
 
 def main():
