@@ -94,6 +94,45 @@ def test_cell_table_overflow_falls_back(device):
     assert mc == mc2 and np.array_equal(got.cpu().numpy(), orc)
 
 
+def test_radius_table_serves_several_searches_like_separate_calls(gold, device):
+    """ops.RadiusTable (spr_radius_table_build / _query): ONE cell table per (supports, radius) answers the self
+    search, a search from other queries and a second self search -- each row for row what spr_radius_neighbors
+    (and the CPU oracle) give for the same call; the pyramid builds three tables for its seven searches."""
+    pts, lens, r = gold["dense.pts"], gold["dense.lens"], float(gold["dense.radius"])
+    d, cu = torch.from_numpy(pts).to(device), _cu(lens, device)
+    rng = np.random.default_rng(5)
+    qlens = [max(1, int(l) // 3) for l in lens]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    qs = np.concatenate([pts[offs[c]:offs[c + 1]][rng.permutation(int(lens[c]))[:qlens[c]]] + np.float32(1e-3)
+                         for c in range(len(lens))]).astype(np.float32)
+    q, qcu = torch.from_numpy(qs).to(device), _cu(qlens, device)
+    table = ops.RadiusTable(d, cu, r)
+    assert table.matches(d, cu, r) and not table.matches(d, cu, 2 * r) and not table.matches(q, qcu, r)
+    a, ma = table.query(d, cu, 40)            # self search: cell-order walk
+    b, mb = table.query(q, qcu, 40)           # other queries, same supports
+    c, mc = table.query(d, cu, 25)            # another limit against the same build
+    for (got, m), (qq, ql, lim) in zip(((a, ma), (b, mb), (c, mc)), ((pts, lens, 40), (qs, qlens, 40), (pts, lens, 25))):
+        orc, mo = native.radius_neighbors(qq, pts, ql, lens, r, limit=lim)
+        assert m == mo and np.array_equal(got.cpu().numpy(), orc)
+        sep, ms = ops.radius_neighbors(torch.from_numpy(qq).to(device), d, _cu(ql, device), cu, r, lim)
+        assert ms == m and torch.equal(sep, got)
+
+
+def test_radius_table_overflow_and_empty_results(device):
+    """A geometry the table cannot hold is answered through the sorted-key path (same rows); a query set without
+    any neighbour raises like the reference (cpp_neighbors/wrapper.cpp:201-205)."""
+    rng = np.random.default_rng(0)
+    a = rng.uniform(0, 0.05, (300, 3)).astype(np.float32)
+    pts = np.concatenate([a, a + np.float32(60.0)])
+    d, cu = torch.from_numpy(pts).to(device), _cu([600], device)
+    got, m = ops.RadiusTable(d, cu, 0.01).query(d, cu, 32)
+    orc, mo = native.radius_neighbors(pts, pts, [600], [600], 0.01, limit=32)
+    assert m == mo and np.array_equal(got.cpu().numpy(), orc)
+    far = torch.full((2, 3), 100.0, device=device)
+    with pytest.raises(RuntimeError):
+        ops.RadiusTable(d, cu, 0.01).query(far, _cu([2], device), 8)
+
+
 def test_limit_below_max_count_keeps_k_nearest(gold, device):
     pts, lens, r = gold["dense.pts"], gold["dense.lens"], float(gold["dense.radius"])
     got, mc = ops.radius_neighbors(torch.from_numpy(pts).to(device), torch.from_numpy(pts).to(device),
