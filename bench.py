@@ -411,8 +411,20 @@ def main():
             dist.destroy_process_group()
         return
 
+    # labels follow the arguments actually used (the driver's default command is BASELINE configs[1])
+    headline = (args.points == 16384 and args.config == "3dmatch" and args.generator == "box")
+    if args.generator == "lidar":
+        cloud_desc = "LiDAR-shaped 120 k-return scans pre-voxelised at 0.3 m (synthetic.make_lidar_pair)"
+        metric = "point-cloud pairs/sec (KITTI-shaped scans, ~120 k returns/cloud)"
+    else:
+        cloud_desc = f"synthetic {args.points}-pt pairs"
+        metric = ("point-cloud pairs/sec (16 384 pts/cloud)" if args.points == 16384
+                  else f"point-cloud pairs/sec ({args.points} pts/cloud)")
+    baseline_cfg = ("BASELINE configs[1]" if headline else
+                    {"kitti": "BASELINE configs[3] shape", "modelnet": "BASELINE configs[4] shape"}.get(
+                        args.config, "BASELINE configs[2] shape" if args.config == "3dmatch" else "parity-case shape"))
     result = {
-        "metric": "point-cloud pairs/sec (16 384 pts/cloud)",
+        "metric": metric,
         "value": round(sharding.throughput(B, args.steps, world, elapsed), 3),
         "unit": "pairs/s",
         "n_gpus": world,
@@ -427,11 +439,12 @@ def main():
                                                       f"f32 storage/accumulate, gemm_mode={args.gemm_mode}, "
                                                       f"attn_mode={args.attn_mode}"),
         "data": "synthetic",
-        "config": {"workload": f"synthetic {args.points}-pt pairs, full KPConv backbone + superpoint attn "
+        "config": {"workload": f"{cloud_desc}, full KPConv backbone + superpoint attn "
                                f"+ {'Sinkhorn-' if cfg.use_sinkhorn else ''}SVD pose ({args.config} config, "
-                               f"BASELINE configs[1])",
+                               f"{baseline_cfg})",
                    "pairs_per_step_per_gpu": B, "streams_per_gpu": max(1, args.streams),
-                   "points_per_cloud": args.points,
+                   "points_per_cloud": (args.points if args.generator == "box" else "lidar scan (varies)"),
+                   "generator": args.generator,
                    "point_order": "canonical" if args.canonical_order else "reference",
                    "upsample_indices": not args.skip_upsamples,
                    "cross_step_overlap": not args.no_cross_step_overlap,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPR_VERSION 3
+#define SPR_VERSION 4
 
 /* activation codes for spr_linear / spr_instnorm */
 #define SPR_ACT_NONE 0
@@ -330,6 +330,37 @@ int spr_attn_inproj_varlen_fwd(const float* x_qk, const float* x_v, int t,
                                int max_len_host, int nhead, int head_dim,
                                float scale, float* out, int o_stride, void* ws,
                                size_t ws_bytes, void* stream);
+
+/* ---- a9, fused: the whole cross-encoder stack of an inference forward -----------------------
+ * Replaces TransformerCrossEncoder.forward (models/transformer/transformers.py:45-80) over
+ * TransformerCrossEncoderLayer.forward_pre (:184-245) for the configuration every shipped experiment
+ * uses (pre_norm, sa_val_has_pos_emb, ca_val_has_pos_emb, ReLU, dropout 0, d_model 256 = 8 x 32):
+ * per layer two attention cores and two fused row chains (csrc/xenc.hip) -- out-projection +
+ * residual, LayerNorm (+ positional embedding), feed-forward block, next in-projection -- that keep
+ * every intermediate on the chip and write the attention operand planes directly.
+ * spr_xenc_prepare: once per weight version.  layer_ptrs_host = SPR_XENC_PTRS_PER_LAYER device
+ *   pointers per layer in the order self_attn.{in_proj_weight, in_proj_bias, out_proj.weight,
+ *   out_proj.bias}, multihead_attn.{same four}, linear1.{weight, bias}, linear2.{weight, bias},
+ *   norm1.{weight, bias}, norm2.{..}, norm3.{..}; eps_host = 3 floats per layer (norm1..3);
+ *   final_g / final_b = the stack's final LayerNorm or NULL; pos_bound = max |pos| (1 for the sine
+ *   embedding).  Lays the weights out as split-fp16 MFMA fragments in `prepared`
+ *   (spr_xenc_prepared_bytes, device) and fills the host-side plan (spr_xenc_plan_bytes, opaque).
+ *   Synchronises the stream (one device->host read of the parameter statistics).  The plan refers to
+ *   `prepared` and to the bias / LayerNorm parameters themselves: keep all of them alive and unchanged.
+ * spr_xenc_forward: x, pos, out [t, 256]; cu [nseg + 1]; kv_self / kv_cross [nseg] = key segment of
+ *   every query segment.  Split-fp16 arithmetic only (gemm mode 1, attention mode 1 or 2).
+ */
+#define SPR_XENC_PTRS_PER_LAYER 18
+size_t spr_xenc_prepared_bytes(int n_layers, int d_ff);
+size_t spr_xenc_plan_bytes(void);
+int spr_xenc_prepare(const void* const* layer_ptrs_host, const float* eps_host, int n_layers,
+                     int d_model, int nhead, int d_ff, const float* final_g, const float* final_b,
+                     float final_eps, float pos_bound, void* prepared, size_t prepared_bytes,
+                     void* plan_host, size_t plan_bytes, void* stream);
+size_t spr_xenc_workspace_bytes(int t, int nseg);
+int spr_xenc_forward(const void* plan_host, const float* x, const float* pos, const int* cu,
+                     const int* kv_self, const int* kv_cross, int t, int nseg, int max_len_host,
+                     float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* Backward of spr_attn_varlen_fwd (the graph torch autograd builds for the attention core of
  * nn.MultiheadAttention, transformers.py:198-227), flash style: the Lq x Lk matrices are recomputed

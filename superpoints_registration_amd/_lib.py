@@ -79,6 +79,11 @@ SIGNATURES = {
     "spr_attn_inproj_varlen_fwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _vp,
                                         _sz, _vp]),
     "spr_set_attn_mode": (_i, [_i]),
+    "spr_xenc_prepared_bytes": (_sz, [_i, _i]),
+    "spr_xenc_plan_bytes": (_sz, []),
+    "spr_xenc_prepare": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _f, _vp, _sz, _vp, _sz, _vp]),
+    "spr_xenc_workspace_bytes": (_sz, [_i, _i]),
+    "spr_xenc_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "spr_match_workspace_bytes": (_sz, [_vp, _i]),
     "spr_match_dualsoftmax": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "spr_match_dualsoftmax2": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -747,14 +747,14 @@ __global__ __launch_bounds__(256) void k_plane_scales(const float* __restrict__ 
 
 using namespace spr;
 
-static size_t attn_tp(int t, int nseg) { return align_up((size_t)t + 8 * (size_t)nseg + KT2, PT); }
+static size_t attn_tp_(int t, int nseg) { return align_up((size_t)t + 8 * (size_t)nseg + KT2, PT); }
 // small scratch behind the planes: 3 absmax partial arrays, 3*256 row norms, 4 scales
 static constexpr size_t kAttnSmall = 3 * 2048 + 4096 + 256;
 
 extern "C" size_t spr_attn_workspace_bytes(int t, int nseg, int nhead, int head_dim) {
   if (t < 0 || nseg < 0 || nhead < 0 || head_dim < 0) return 0;
   const size_t d = (size_t)nhead * head_dim;
-  return 4 * align_up((size_t)(t > 0 ? t : 1) * d * 2, 256) + 2 * align_up(d * attn_tp(t, nseg) * 2, 256) +
+  return 4 * align_up((size_t)(t > 0 ? t : 1) * d * 2, 256) + 2 * align_up(d * attn_tp_(t, nseg) * 2, 256) +
          kAttnSmall;
 }
 
@@ -828,7 +828,7 @@ extern "C" int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k,
     return 0;
   }
   const int d_model = nhead * head_dim;
-  const size_t tp = attn_tp(t, nseg);
+  const size_t tp = attn_tp_(t, nseg);
   SPR_REQUIRE(tp < (1ul << 31), "attention: too many tokens");
   SPR_REQUIRE(ws != nullptr && ws_bytes >= spr_attn_workspace_bytes(t, nseg, nhead, head_dim),
               "attention: workspace too small (%zu bytes given)", ws_bytes);
@@ -889,7 +889,7 @@ extern "C" int spr_attn_inproj_varlen_fwd_r(const float* x_qk, const float* x_v,
   const int d = nhead * head_dim;
   const size_t planes_bytes = spr_attn_workspace_bytes(t, nseg, nhead, head_dim);
   const int mode = spr::g_attn_mode.load(std::memory_order_relaxed);
-  const size_t tp = attn_tp(t, nseg);
+  const size_t tp = attn_tp_(t, nseg);
   SPR_REQUIRE(tp < (1ul << 31), "attention: too many tokens");
   AttnPlanes pl{};
   AttnSmall sm{};
@@ -981,6 +981,26 @@ extern "C" int spr_attn_inproj_varlen_fwd_r(const float* x_qk, const float* x_v,
       return rc;
   }
   return launch_core(pl, t, tp, cu, kv_seg, nseg, max_len_host, nhead, out, o_stride, mode, stream);
+}
+
+// ---- entry points for the fused cross-encoder chains (xenc.hip) --------------------------------
+size_t spr::attn_tp(int t, int nseg) { return ::attn_tp_(t, nseg); }
+int spr::attn_mode() { return spr::g_attn_mode.load(std::memory_order_relaxed); }
+int spr::attn_carve_planes(void* ws, size_t ws_bytes, int t, int nseg, int d, AttnPlanes& pl) {
+  AttnSmall sm{};
+  return carve(ws, ws_bytes, t, nseg, d, ::attn_tp_(t, nseg), pl, sm);
+}
+int spr::attn_zero_gaps(const AttnPlanes& pl, int d, hipStream_t stream) {
+  hipLaunchKernelGGL(k_attn_zero_gaps, dim3(d), dim3(256), 0, stream, pl.cu, pl.nseg, pl.tp, pl.vth, pl.vtl);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+int spr::attn_core_on_planes(const AttnPlanes& pl, const int* kv_seg, int max_len_host, int nhead, float* out,
+                             int o_stride, int mode, hipStream_t stream) {
+  SPR_REQUIRE(mode == 1 || mode == 2, "attention core on planes: mode must be 1 or 2 (got %d)", mode);
+  SPR_REQUIRE((long)cdiv(max_len_host, QB2) * nhead * pl.nseg < (1l << 31), "attention: grid too large");
+  return launch_core(pl, pl.t_total, (size_t)pl.tp, pl.cu, kv_seg, pl.nseg, max_len_host, nhead, out, o_stride, mode,
+                     stream);
 }
 
 extern "C" int spr_set_attn_mode(int mode) {

@@ -20,6 +20,17 @@ struct AttnPlanes {
   const float* scales;
 };
 
+// Shared by attention.hip and xenc.hip (the fused cross-encoder chains write the planes themselves):
+// padded column count of the transposed V planes, carving of the planes out of a workspace of
+// spr_attn_workspace_bytes(t, nseg, nhead, 32) bytes, zeroing of the gap / tail columns, and the
+// attention core over planes that are already in place.  `mode`: 1 split-fp16, 2 single pass.
+size_t attn_tp(int t, int nseg);
+int attn_carve_planes(void* ws, size_t ws_bytes, int t, int nseg, int d, AttnPlanes& pl);
+int attn_zero_gaps(const AttnPlanes& pl, int d, hipStream_t stream);
+int attn_core_on_planes(const AttnPlanes& pl, const int* kv_seg, int max_len_host, int nhead, float* out,
+                        int o_stride, int mode, hipStream_t stream);
+int attn_mode();   // 1 split-fp16, 0 exact f32, 2 single-pass fp16
+
 // Split-fp16 GEMM  planes <- x [m, k] . w [n, k]^T + bias  for the n output
 // features [f0, f0 + n) of the packed in-projection (0..255 = Q, 256..511 = K,
 // 512..767 = V; d_model = 256, head_dim = 32).  n and f0 are multiples of 256.

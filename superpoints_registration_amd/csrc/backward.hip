@@ -118,9 +118,14 @@ __device__ __forceinline__ void fx_add(unsigned long long* acc, float v, int fx)
 __global__ void k_fx_to_float(const unsigned long long* __restrict__ acc, long n, const float* __restrict__ parts,
                               float factor, float* __restrict__ out) {
   __shared__ float sh[17];
-  const int fx = fx_exp(parts, sh, factor);
+  const float amax = block_absmax(parts, sh);
+  const int fx = pow2_exp_for(amax * factor) + 25;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (!(amax < 3.0e38f)) {   // the incoming gradient holds an inf or a NaN (k_absmax maps NaN to inf): a float
+    out[i] = __builtin_nanf("");   // atomicAdd would have propagated it; the fixed-point sums cannot, so the
+    return;                        // whole gradient is marked (a finite-gradient check downstream still fires)
+  }
   const double inv = (double)pow2f(-(fx / 2)) * (double)pow2f(-(fx - fx / 2));
   out[i] = (float)((double)(long long)acc[i] * inv);
 }

@@ -47,6 +47,11 @@ struct AbsmaxJob {
 };
 // blockIdx.y selects the tensor (a second, usually small one -- the weights -- rides along in
 // the same launch)
+// |a|, with NaN mapped to +inf: a range that "saw" a NaN must not read as finite (the consumers treat a
+// non-finite range as "this tensor is broken" -- e.g. the fixed-point scatter-adds of backward.hip turn
+// their whole output into NaN instead of silently dropping the NaN contribution).
+__device__ __forceinline__ float amag(float a) { return a != a ? INFINITY : fabsf(a); }
+
 __global__ __launch_bounds__(256) void k_absmax(AbsmaxJob j0, AbsmaxJob j1) {
   const AbsmaxJob j = blockIdx.y == 0 ? j0 : j1;
   const float* __restrict__ x = j.x;
@@ -63,28 +68,28 @@ __global__ __launch_bounds__(256) void k_absmax(AbsmaxJob j0, AbsmaxJob j1) {
       long i = t0;
       for (; i + 3 * nthr < total; i += 4 * nthr) {   // four 16-byte loads in flight
         const float4 a = p[i], b = p[i + nthr], c = p[i + 2 * nthr], d = p[i + 3 * nthr];
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))));
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w))));
+        m = fmaxf(m, fmaxf(fmaxf(amag(a.x), amag(a.y)), fmaxf(amag(a.z), amag(a.w))));
+        m = fmaxf(m, fmaxf(fmaxf(amag(b.x), amag(b.y)), fmaxf(amag(b.z), amag(b.w))));
+        m = fmaxf(m, fmaxf(fmaxf(amag(c.x), amag(c.y)), fmaxf(amag(c.z), amag(c.w))));
+        m = fmaxf(m, fmaxf(fmaxf(amag(d.x), amag(d.y)), fmaxf(amag(d.z), amag(d.w))));
       }
       for (; i < total; i += nthr) {
         const float4 a = p[i];
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        m = fmaxf(m, fmaxf(fmaxf(amag(a.x), amag(a.y)), fmaxf(amag(a.z), amag(a.w))));
       }
     } else {
       for (long i = t0; i < total; i += nthr) {
         const long r = i / cols4;
         const int c = (int)(i - r * cols4);
         const float4 a = *reinterpret_cast<const float4*>(x + r * stride + 4 * c);
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        m = fmaxf(m, fmaxf(fmaxf(amag(a.x), amag(a.y)), fmaxf(amag(a.z), amag(a.w))));
       }
     }
   } else {
     const long total = rows * cols;
     for (long i = t0; i < total; i += nthr) {
       const long r = i / cols;
-      m = fmaxf(m, fabsf(x[r * stride + (i - r * cols)]));
+      m = fmaxf(m, amag(x[r * stride + (i - r * cols)]));
     }
   }
   m = wave_max(m);

@@ -1,0 +1,964 @@
+// Fused row chains of the cross-encoder (inference): everything of a pre-norm layer that is not
+// the attention core runs in TWO kernels per layer, and no intermediate leaves the chip.
+//
+// Behaviour contract: TransformerCrossEncoderLayer.forward_pre + TransformerCrossEncoder.forward
+//   /root/reference/src/models/transformer/transformers.py:184-245 (layer), :45-80 (stack, final norm)
+// for the configuration every shipped experiment uses (pre_norm, sa/ca_val_has_pos_emb, sine
+// positional embedding, dropout 0, ReLU, d_model 256 = 8 heads x 32).
+//
+// Every operator between two attention cores is ROW LOCAL (projection, bias, residual add, LayerNorm,
+// positional-embedding add, ReLU), so a wave can own 32 tokens and push them through the whole chain:
+//   chain A (behind the self attention)   o -> out_proj + x -> x' (stored) -> norm2 + pos -> in_proj -> planes
+//   chain B (behind the cross attention)  o -> out_proj + x -> norm3 -> linear1 -> ReLU -> linear2 + x'
+//                                           -> x'' (stored) -> norm1 of the NEXT layer + pos -> in_proj -> planes
+//                                           (last layer: -> final norm -> out)
+//   prologue                               x -> norm1 + pos -> in_proj -> planes
+// "planes" = the split-fp16 Q / K / V^T operand planes the attention core consumes (attn_planes.h).
+//
+// Kernel shape (k_xenc_chain): 4 waves per workgroup, ONE wave per SIMD with the whole 512-entry
+// register file; a wave owns 32 tokens, a workgroup 128, persistent workgroups walk the token tiles.
+// All products are computed TRANSPOSED, C^T[feature][token] = W X^T with v_mfma_f32_32x32x16_f16:
+// the token is the LANE (l & 31), so every row reduction (LayerNorm) is in-lane plus one exchange with
+// lane ^ 32, and the 32 x 32 accumulator tile of one product is -- after scaling and splitting, with
+// no lane movement and no LDS -- the B operand of the next product (registers 8s..8s+7 = k-step s;
+// the k order inside a step is the fixed permutation kperm() below, applied to the weights when they are
+// laid out).  Activations therefore live in registers from the first load to the last store:
+//   operand planes 2 x 64 VGPRs (hi, lo; K = 256), accumulators 128 (out_proj / linear2 tile) or 16.
+// Weights are the only stream: pre-split ONCE per weight version into fp16 hi / lo MFMA fragments in
+// exactly the order the chain consumes them (spr_xenc_prepare: 32 KiB chunks = 32 fragments of
+// 1 KiB), brought to LDS by global_load_lds_dwordx4 (no VGPRs, no VALU) into a ring of four chunks
+// shared by the four waves, three chunks ahead, retired with counted s_waitcnt vmcnt + one raw
+// s_barrier per chunk.  A fragment is one conflict-free ds_read_b128 per lane and feeds three MFMAs
+// (al.bh + ah.bl + ah.bh, the split-fp16 product of spr_common.h).
+//
+// Operand scales are STATIC: every tensor inside a chain has a data-independent bound
+//   |LayerNorm(x)| <= sqrt(d - 1) max|gamma| + max|beta|,   |x W^T + b| <= bound(x) max_row ||W||_1 + max|b|,
+//   |attention output| <= bound(V),   |pos| <= pos_bound
+// evaluated on the host when the weights are prepared.  The bounds are loose by 2^4..2^8; the split
+// keeps an absolute error of 2^-40 of the SCALED maximum, so the results stay at fp32 rounding level
+// (spr_common.h, split_pk_s) and nothing can overflow.  No range is measured or handed over at run time.
+#include <vector>
+
+#include "attn_planes.h"
+#include "spr_common.h"
+
+namespace spr {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int XD = 256;            // d_model
+constexpr int XCHUNK = 32768;      // bytes per weight chunk (32 fragments of 1 KiB)
+constexpr int XSLOTS = 4;          // ring depth (chunks)
+constexpr int XAHEAD = 2;          // an acquire of chunk g (at step 8 of chunk g - 1) issues chunk g + XAHEAD
+constexpr int XDMA = 8;            // LDS-DMA instructions per wave and chunk (32 KiB / 4 waves / 1 KiB)
+constexpr int XTOK = 128;          // tokens per workgroup tile
+
+// k order of a 16-deep k-step whose B operand is an accumulator tile (or is loaded in that shape):
+// element j of lane half h <-> feature 16 S + 8 (j >> 2) + 4 h + (j & 3).
+__host__ __device__ inline int kperm(int S, int h, int j) { return 16 * S + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+// One fused chain: device tables + host-evaluated constants.  Passed to the kernel by value.
+struct ChainConsts {
+  const unsigned char* w;               // weight stream: chunks of XCHUNK bytes in consumption order
+  const float *bo, *b1, *b2, *bin;      // biases (the parameters themselves)
+  const float *g_mid, *b_mid;           // LayerNorm in front of the feed-forward block (norm3)
+  const float *g_tail, *b_tail;         // LayerNorm in front of the in-projection / final norm
+  float eps_mid, eps_tail;
+  float o_scale, res_o, un_o;           // out_proj: 2^ko, 2^(ko + kwo), 2^-(ko + kwo)
+  float x2_scale, bs1, h_mul, res_f, un_f;   // FFN: 2^kx2, 2^(kx2 + kw1), 2^(kh - kx2 - kw1), 2^(kh + kw2), 2^-(kh + kw2)
+  float xt_scale, bs_in, un_in;         // in_proj: 2^kxt, 2^(kxt + kwin), 2^-(kxt + kwin)
+  float pmul[3];                        // plane multipliers (Q incl. log2(e)/sqrt(d), K, V)
+  int nf;                               // d_ff / 32
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_vm_any(int n) {   // n wave uniform, a multiple of 4 in 0..60
+#define SPR_W(k) case k: wait_vm<k>(); break;
+  switch (n) {
+    SPR_W(4) SPR_W(8) SPR_W(12) SPR_W(16) SPR_W(20) SPR_W(24) SPR_W(28) SPR_W(32) SPR_W(36) SPR_W(40) SPR_W(44)
+    SPR_W(48) SPR_W(52) SPR_W(56) SPR_W(60)
+    default: wait_vm<0>(); break;
+  }
+#undef SPR_W
+}
+
+// LDS-DMA: 16 bytes per lane from base + off (per-lane byte offset) to LDS at dst_s + 16 * lane.
+__device__ __forceinline__ void dma16(const void* base, unsigned off, unsigned dst_s) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               : : "v"(off), "s"(base), "s"(dst_s) : "memory", "m0");
+}
+// (the trailing s_nop keeps the compiler's next instruction from overwriting the data registers of a
+// wide store before it has read them)
+__device__ __forceinline__ void store16(void* p, const u32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store2(void* p, unsigned int v) {   // low 16 bits
+  asm volatile("global_store_short %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store2hi(void* p, unsigned int v) {   // high 16 bits
+  asm volatile("global_store_short_d16_hi %0, %1, off" ::"v"(p), "v"(v) : "memory");
+}
+
+// [32 tokens x 256 features] tile in the accumulator ("C") layout: v[b][e] = feature
+// 32 b + (e & 3) + 8 (e >> 2) + 4 h of the lane's token.  The loads are VOLATILE: they are issued where
+// they stand (a whole tile in one batch, long before its first use) and the compiler waits for them once,
+// with one s_waitcnt -- which, blind to the LDS-DMAs queued behind them, also drains the weight ring: once
+// per batch instead of once per table or row access (every other operand of the kernel comes from LDS).
+__device__ __forceinline__ void load_c(const float* src, int tok, int h, f32x16 (&v)[8]) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(src + (size_t)tok * XD + 4 * h);
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 t = p[8 * b + 2 * g];
+      v[b][4 * g + 0] = t[0];
+      v[b][4 * g + 1] = t[1];
+      v[b][4 * g + 2] = t[2];
+      v[b][4 * g + 3] = t[3];
+    }
+}
+__device__ __forceinline__ void store_c(float* __restrict__ dst, int tok, int h, bool valid, const f32x16 (&v)[8]) {
+  if (!valid) return;
+  float* p = dst + (size_t)tok * XD + 4 * h;
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 t = {v[b][4 * g + 0], v[b][4 * g + 1], v[b][4 * g + 2], v[b][4 * g + 3]};
+      *reinterpret_cast<f32x4*>(p + 32 * b + 8 * g) = t;
+    }
+}
+// per-feature table (in LDS) in the same shape: t[g] = table[32 b + 8 g + 4 h .. + 3]
+__device__ __forceinline__ void load_tab(const float* tab, int b, int h, f32x4 (&t)[4]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) t[g] = *reinterpret_cast<const f32x4*>(tab + 32 * b + 8 * g + 4 * h);
+}
+
+// scaled split of one 32-feature block into the B fragments of its two k-steps
+__device__ __forceinline__ void split_block(const f32x16& v, float scale, f16x8& h0, f16x8& l0, f16x8& h1,
+                                            f16x8& l1) {
+  unsigned int hu[8], lu[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) split_pk_s(v[2 * i], v[2 * i + 1], scale, hu[i], lu[i]);
+  h0 = __builtin_bit_cast(f16x8, (u32x4){hu[0], hu[1], hu[2], hu[3]});
+  l0 = __builtin_bit_cast(f16x8, (u32x4){lu[0], lu[1], lu[2], lu[3]});
+  h1 = __builtin_bit_cast(f16x8, (u32x4){hu[4], hu[5], hu[6], hu[7]});
+  l1 = __builtin_bit_cast(f16x8, (u32x4){lu[4], lu[5], lu[6], lu[7]});
+}
+
+// LayerNorm over the 256 features of the lane's token (two half rows: lanes l and l ^ 32).  Same
+// operations as k_layernorm256 (two-pass mean / variance, (d rstd) gamma + beta); only the order of the
+// two sums differs.  v is left untouched (it is also the residual).
+__device__ __forceinline__ void ln_stats(const f32x16 (&v)[8], float eps, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += v[b][e];
+  s += __shfl_xor(s, 32, 64);
+  mean = s / 256.0f;
+  float ss = 0.f;
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float d = v[b][e] - mean;
+      ss += d * d;
+    }
+  ss += __shfl_xor(ss, 32, 64);
+  rstd = 1.0f / sqrtf(ss / 256.0f + eps);
+}
+__device__ __forceinline__ f32x16 ln_block(const f32x16& v, int b, int h, float mean, float rstd, const float* gamma,
+                                           const float* beta) {
+  f32x4 g[4], be[4];
+  load_tab(gamma, b, h, g);
+  load_tab(beta, b, h, be);
+  f32x16 y;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) y[e] = (v[e] - mean) * rstd * g[e >> 2][e & 3] + be[e >> 2][e & 3];
+  return y;
+}
+
+// ---- chunk engine ----------------------------------------------------------------------------------
+// A chunk is 16 steps; step i uses fragments 2 i (hi) and 2 i + 1 (lo) of the chunk's slot and issues three
+// MFMAs.  Fragment reads run THREE steps ahead of the MFMAs through a ring of four register pairs that is
+// carried from chunk to chunk: the last three steps of a chunk read the first three fragments pairs of the
+// NEXT chunk, which is acquired (DMA wait + barrier + refill of the slot every wave has left) at step 8.
+struct Carry {
+  f16x8 h[4], l[4];
+};
+__device__ __forceinline__ void frag_ld(const unsigned char* slot, int lane, int i, f16x8& h, f16x8& l) {
+  const f16x8* fr = reinterpret_cast<const f16x8*>(slot) + lane;
+  h = fr[(2 * i) * 64];
+  l = fr[(2 * i + 1) * 64];
+}
+template <class MF, class ACQ>
+__device__ __forceinline__ const unsigned char* run_chunk(const unsigned char* cur, int lane, Carry& c, MF&& mf,
+                                                          ACQ&& acq) {
+  const unsigned char* nxt = cur;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (i == 8) nxt = acq();
+    if (i + 3 < 16) frag_ld(cur, lane, i + 3, c.h[(i + 3) & 3], c.l[(i + 3) & 3]);
+    else frag_ld(nxt, lane, i + 3 - 16, c.h[(i + 3) & 3], c.l[(i + 3) & 3]);
+    __builtin_amdgcn_sched_barrier(0);
+    mf(i, c.h[i & 3], c.l[i & 3]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return nxt;
+}
+__device__ __forceinline__ f32x16 mfma3(const f16x8& wh, const f16x8& wl, const f16x8& xh, const f16x8& xl, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
+  return acc;
+}
+
+// Diagnostic build only (-DSPR_XENC_STAMP, scripts/xenc_timeline.py): shader-clock stamps of wave 0 of
+// workgroup 0 at the stage boundaries of every tile, into a buffer nothing else reads.
+#ifdef SPR_XENC_STAMP
+__device__ unsigned long long g_xenc_stamps[64 * 64];
+#define XSTAMP(k)                                                                                   \
+  do {                                                                                              \
+    if (blockIdx.x == 0 && tid == 0 && it < 64 && T < 0x7fffffff && c.nf > 0 && (stamp_on & 1))          \
+      g_xenc_stamps[it * 64 + (k)] = __builtin_amdgcn_s_memtime();                                  \
+  } while (0)
+#define XSTAMP_REAL(k)                                                                              \
+  do {                                                                                              \
+    if (blockIdx.x == 0 && tid == 0 && it < 64 && (stamp_on & 1))                                      \
+      g_xenc_stamps[it * 64 + (k)] = __builtin_amdgcn_s_memrealtime();                              \
+  } while (0)
+#else
+#define XSTAMP(k) do { } while (0)
+#define XSTAMP_REAL(k) do { } while (0)
+#endif
+
+// LDS: [ring XSLOTS x XCHUNK] [tables] [cu]
+constexpr int T_BO = 0, T_B2 = 256, T_GM = 512, T_BM = 768, T_GT = 1024, T_BT = 1280, T_BIN = 1536, T_B1 = 2304;
+__host__ __device__ inline size_t xenc_lds_bytes(int d_ff, int nseg) {
+  return (size_t)XSLOTS * XCHUNK + (size_t)(T_B1 + d_ff + nseg + 1) * 4;
+}
+
+// TAIL: 0 = x_out only, 1 = LayerNorm -> ln_out (final norm), 2 = LayerNorm + pos -> in-projection -> planes
+template <bool HEAD, bool FFN, int TAIL>
+__global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const float* __restrict__ o_g,
+                                                       const float* __restrict__ x_g, float* __restrict__ xo_g,
+                                                       const float* __restrict__ pos_g, float* __restrict__ ln_g,
+                                                       AttnPlanes pl, int T, int ntiles, int stamp_on) {
+  extern __shared__ __align__(16) unsigned char ring[];
+  float* tab = reinterpret_cast<float*>(ring + XSLOTS * XCHUNK);
+  const int d_ff = 32 * c.nf;
+  int* cu_s = reinterpret_cast<int*>(tab + T_B1 + d_ff);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const unsigned ring_s = (unsigned)(uintptr_t)ring;
+  const int nch = (HEAD ? 8 : 0) + (FFN ? 2 * c.nf : 0) + (TAIL == 2 ? 24 : 0);   // chunks per tile
+  const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int total = my_tiles * nch;   // chunks this workgroup consumes
+
+  // ---- parameter tables and cu_seqlens into LDS (the steady state issues no register loads) ----
+  for (int i = tid; i < 256; i += 256) {
+    tab[T_BO + i] = HEAD ? c.bo[i] : 0.f;
+    tab[T_B2 + i] = FFN ? c.b2[i] : 0.f;
+    tab[T_GM + i] = FFN ? c.g_mid[i] : 0.f;
+    tab[T_BM + i] = FFN ? c.b_mid[i] : 0.f;
+    tab[T_GT + i] = TAIL >= 1 ? c.g_tail[i] : 0.f;
+    tab[T_BT + i] = TAIL >= 1 ? c.b_tail[i] : 0.f;
+  }
+  if (TAIL == 2)
+    for (int i = tid; i < 768; i += 256) tab[T_BIN + i] = c.bin[i];
+  if (FFN)
+    for (int i = tid; i < d_ff; i += 256) tab[T_B1 + i] = c.b1[i];
+  if (TAIL == 2)
+    for (int i = tid; i <= pl.nseg; i += 256) cu_s[i] = pl.cu[i];
+  __syncthreads();
+
+  // ---- weight ring ---------------------------------------------------------------------------------
+  int g_acq = 0;                          // next chunk to acquire
+  int i_pos = 0, i_slot = 0, g_iss = 0;   // issue side: stream position, slot, chunk number
+  int a_slot = 0;                         // acquire side slot
+  // counted (asm) stores since the DMAs of the chunk about to be acquired were issued (two acquire calls back)
+  int hist = 0, cur = 0;
+  auto issue = [&]() {
+#ifdef SPR_XENC_STAMP
+    if (g_iss < total && !(stamp_on & 2)) {      // ablation: no weight DMA (garbage results)
+#else
+    if (g_iss < total) {
+#endif
+      const unsigned dst = __builtin_amdgcn_readfirstlane(ring_s + (unsigned)i_slot * XCHUNK + (unsigned)wave * (XDMA * 1024));
+      const unsigned off = (unsigned)i_pos * XCHUNK + (unsigned)wave * (XDMA * 1024) + (unsigned)lane * 16;
+#pragma unroll
+      for (int i = 0; i < XDMA; ++i) dma16(c.w, off + i * 1024, dst + i * 1024);
+    }
+    ++g_iss;
+    if (++i_pos == nch) i_pos = 0;
+    if (++i_slot == XSLOTS) i_slot = 0;
+  };
+  // Makes chunk g_acq readable and returns its slot.  Called at step 8 of chunk g_acq - 1: every wave has
+  // then left chunk g_acq - 2, whose slot is refilled with chunk g_acq + XAHEAD.  Beyond the end of the
+  // stream: returns `fallback` (its fragments are read and never used).
+  auto acquire = [&](const unsigned char* fallback) -> const unsigned char* {
+    if (g_acq >= total) return fallback;
+    // vector-memory operations younger than the DMAs of chunk g_acq (issued two acquire calls ago): the DMAs
+    // of chunk g_acq + 1 and the counted stores since.  An under-count only waits longer; an over-count would
+    // read a chunk that has not landed -- stores are counted only when they are certain to issue.
+    int n = (g_acq + 1 < total ? XDMA : 0) + hist + cur;
+    n = n < 60 ? (n & ~3) : 60;
+    wait_vm_any(n);
+#ifdef SPR_XENC_STAMP
+    if (!(stamp_on & 4))                          // ablation: no barrier (garbage results)
+#endif
+    __builtin_amdgcn_s_barrier();
+    issue();
+    hist = cur;
+    cur = 0;
+    const unsigned char* p = ring + a_slot * XCHUNK;
+    ++g_acq;
+    if (++a_slot == XSLOTS) a_slot = 0;
+    return p;
+  };
+#pragma unroll 1
+  for (int i = 0; i < XAHEAD; ++i) issue();
+  Carry cy;
+  const unsigned char* slot = acquire(ring);
+  if (total > 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) frag_ld(slot, lane, i, cy.h[i], cy.l[i]);
+  }
+  auto acq = [&]() __attribute__((always_inline)) { return acquire(slot); };
+
+  // tile operands, prefetched one tile ahead (volatile batches, see load_c)
+  f32x16 t_o[8], t_x[8], t_p[8];
+  auto tok_of = [&](int it) {
+    const int tok = ((int)blockIdx.x + it * (int)gridDim.x) * XTOK + wave * 32 + r;
+    return tok < T ? tok : T - 1;
+  };
+  // Register budget (512 per lane): planes 128 + accumulator tile 128 + ONE prefetched tile 128 + fragment
+  // ring 32 + epilogue temporaries; so o is fetched under the previous tile's in-projection, x under the
+  // out-projection, pos (and, behind the feed-forward block, x' again: it is parked in x_out) when the
+  // planes die.
+  if (my_tiles > 0) {
+    if constexpr (HEAD) load_c(o_g, tok_of(0), h, t_o);
+    else load_c(x_g, tok_of(0), h, t_x);
+  }
+
+#pragma unroll 1
+  for (int it = 0; it < my_tiles; ++it) {
+    const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+    const int tok = tile * XTOK + wave * 32 + r;
+    const bool valid = tok < T;
+    const bool wave_valid = tile * XTOK + wave * 32 < T;   // lane 0 of the wave is valid: its stores do issue
+    const int tokc = valid ? tok : T - 1;
+    const bool more = it + 1 < my_tiles;
+    f32x16 v[8];
+    f16x8 ph[16], pw[16];
+    XSTAMP(0);
+    XSTAMP_REAL(31);
+
+    if constexpr (HEAD) {
+      // ---- x' = o Wo^T + bo + x ------------------------------------------------------------------
+#pragma unroll
+      for (int b = 0; b < 8; ++b) split_block(t_o[b], c.o_scale, ph[2 * b], pw[2 * b], ph[2 * b + 1], pw[2 * b + 1]);
+      load_c(x_g, tokc, h, t_x);                                          // residual: needed behind the 8 chunks
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        f32x4 t[4];
+        load_tab(tab + T_BO, b, h, t);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[b][e] = t[e >> 2][e & 3] * c.res_o;
+      }
+      XSTAMP(1);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        slot = run_chunk(slot, lane, cy, [&](int i, const f16x8& wh, const f16x8& wl) __attribute__((always_inline)) {
+          v[b] = mfma3(wh, wl, ph[i], pw[i], v[b]);
+        }, acq);
+        if (b == 0) XSTAMP(2);
+      }
+      XSTAMP(3);
+      if constexpr (TAIL == 2 && !FFN) load_c(pos_g, tokc, h, t_p);      // planes are dead: their registers take pos
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[b][e] = v[b][e] * c.un_o + t_x[b][e];
+      store_c(xo_g, tok, h, valid, v);      // the new residual stream (FFN: parked there, re-read behind the loop)
+      XSTAMP(4);
+    } else {
+      if constexpr (TAIL == 2) load_c(pos_g, tokc, h, t_p);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) v[b] = t_x[b];
+    }
+
+    if constexpr (FFN) {
+      // ---- x'' = x' + linear2(relu(linear1(norm3(x')))) -------------------------------------------
+      f32x16 y[8];
+      {
+        float mean, rstd;
+        ln_stats(v, c.eps_mid, mean, rstd);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const f32x16 t = ln_block(v[b], b, h, mean, rstd, tab + T_GM, tab + T_BM);
+          split_block(t, c.x2_scale, ph[2 * b], pw[2 * b], ph[2 * b + 1], pw[2 * b + 1]);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        f32x4 t[4];
+        load_tab(tab + T_B2, b, h, t);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) y[b][e] = t[e >> 2][e & 3] * c.res_f;
+      }
+      XSTAMP(5);
+#pragma unroll 1
+      for (int ch = 0; ch < c.nf; ++ch) {
+        if (ch == 1) XSTAMP(6);
+        if (ch == 2) XSTAMP(7);
+        f32x16 a;
+        {
+          f32x4 t[4];
+          load_tab(tab + T_B1 + 32 * ch, 0, h, t);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) a[e] = t[e >> 2][e & 3] * c.bs1;
+        }
+        slot = run_chunk(slot, lane, cy, [&](int i, const f16x8& wh, const f16x8& wl) __attribute__((always_inline)) {
+          a = mfma3(wh, wl, ph[i], pw[i], a);
+        }, acq);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] = fmaxf(a[e], 0.f);
+        f16x8 hh[2], hl[2];
+        split_block(a, c.h_mul, hh[0], hl[0], hh[1], hl[1]);
+        slot = run_chunk(slot, lane, cy, [&](int i, const f16x8& wh, const f16x8& wl) __attribute__((always_inline)) {
+          y[i >> 1] = mfma3(wh, wl, hh[i & 1], hl[i & 1], y[i >> 1]);
+        }, acq);
+      }
+      XSTAMP(8);
+      load_c(xo_g, tokc, h, t_x);                                         // x' again (this lane stored it)
+      if constexpr (TAIL == 2) load_c(pos_g, tokc, h, t_p);              // planes are dead: their registers take pos
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[b][e] = y[b][e] * c.un_f + t_x[b][e];
+      if constexpr (TAIL != 1) store_c(xo_g, tok, h, valid, v);
+      XSTAMP(9);
+    }
+
+    if constexpr (TAIL == 1) {
+      float mean, rstd;
+      ln_stats(v, c.eps_tail, mean, rstd);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) v[b] = ln_block(v[b], b, h, mean, rstd, tab + T_GT, tab + T_BT);
+      store_c(ln_g, tok, h, valid, v);
+    }
+    if constexpr (TAIL == 2) {
+      // ---- Q / K / V planes of norm(x) + pos ------------------------------------------------------
+      {
+        float mean, rstd;
+        ln_stats(v, c.eps_tail, mean, rstd);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          f32x16 t = ln_block(v[b], b, h, mean, rstd, tab + T_GT, tab + T_BT);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) t[e] += t_p[b][e];
+          split_block(t, c.xt_scale, ph[2 * b], pw[2 * b], ph[2 * b + 1], pw[2 * b + 1]);
+        }
+      }
+    }
+    XSTAMP(10);
+    // ---- the next tile's operands: in flight under the in-projection ------------------------------
+    if (more) {
+      const int tn = tok_of(it + 1);
+      if constexpr (HEAD) load_c(o_g, tn, h, t_o);
+      else load_c(x_g, tn, h, t_x);
+    }
+    if constexpr (TAIL == 2) {
+      int vcol = 0;
+      {
+        int lo = 0, hi = pl.nseg;                      // largest s with cu[s] <= tokc
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (cu_s[mid] <= tokc) lo = mid; else hi = mid;
+        }
+        vcol = attn_vstart_of(cu_s[lo], lo) + tokc - cu_s[lo];
+      }
+#pragma unroll 1
+      for (int fb = 0; fb < 24; ++fb) {
+        if (fb == 1) XSTAMP(11);
+        if (fb == 8) XSTAMP(12);
+        if (fb == 16) XSTAMP(13);
+        const int which = fb >> 3, head = fb & 7;     // 0 Q, 1 K, 2 V
+        f32x16 a;
+        {
+          f32x4 t[4];
+          load_tab(tab + T_BIN + 32 * fb, 0, h, t);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) a[e] = t[e >> 2][e & 3] * c.bs_in;
+        }
+        slot = run_chunk(slot, lane, cy, [&](int i, const f16x8& wh, const f16x8& wl) __attribute__((always_inline)) {
+          a = mfma3(wh, wl, ph[i], pw[i], a);
+        }, acq);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] *= c.un_in;
+        const float pmul = which == 0 ? c.pmul[0] : (which == 1 ? c.pmul[1] : c.pmul[2]);
+        unsigned int hu[8], lu[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) split_pk_s(a[2 * i], a[2 * i + 1], pmul, hu[i], lu[i]);
+        if (which < 2) {
+          // head-major [head][token][32]: the lane's 16 features of the head as 32 contiguous bytes at
+          // d' = 16 h + e.  The order of d inside a head is free as long as Q and K agree (both
+          // are written here) -- the scores sum over it.
+          _Float16* ph_ = which == 0 ? pl.qh : pl.kh;
+          _Float16* pl_ = which == 0 ? pl.ql : pl.kl;
+          const size_t row = ((size_t)head * pl.t_total + tokc) * 32 + 16 * h;
+          if (valid) {
+            store16(ph_ + row, (u32x4){hu[0], hu[1], hu[2], hu[3]});
+            store16(ph_ + row + 8, (u32x4){hu[4], hu[5], hu[6], hu[7]});
+            store16(pl_ + row, (u32x4){lu[0], lu[1], lu[2], lu[3]});
+            store16(pl_ + row + 8, (u32x4){lu[4], lu[5], lu[6], lu[7]});
+          }
+          if (wave_valid) cur += 4;
+        } else {
+          // transposed planes [feature][token column]: one 2-byte store per feature
+          if (valid) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int e = 2 * i;
+              const int f = head * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;     // feature of register e (e + 1: f + 1)
+              const size_t o0 = (size_t)f * pl.tp + vcol;
+              store2(pl.vth + o0, hu[i]);
+              store2hi(pl.vth + o0 + pl.tp, hu[i]);
+              store2(pl.vtl + o0, lu[i]);
+              store2hi(pl.vtl + o0 + pl.tp, lu[i]);
+            }
+          }
+          if (wave_valid) cur += 32;
+        }
+      }
+      XSTAMP(14);
+    }
+  }
+}
+
+// ---- weight preparation ------------------------------------------------------------------------------
+// F kind: W [n, 256] (row stride ld): feature block fb -> chunk c0 + fb * cstride; fragment (S, plane)
+// at 2 S + plane; lane l holds W[32 fb + (l & 31)][kperm(S, l >> 5, j)] * wscale, j = 0..7.
+__global__ __launch_bounds__(256) void k_xenc_wprep_f(const float* __restrict__ W, int ld, int nblocks, float wscale,
+                                                      unsigned char* __restrict__ out, int c0, int cstride) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;     // (fb, S, lane)
+  if (gid >= nblocks * 16 * 64) return;
+  const int l = gid & 63, S = (gid >> 6) & 15, fb = gid >> 10;
+  const float* row = W + (size_t)(32 * fb + (l & 31)) * ld;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = row[kperm(S, l >> 5, j)];
+  unsigned int hu[4], lu[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) split_pk_s(v[2 * i], v[2 * i + 1], wscale, hu[i], lu[i]);
+  unsigned char* chunk = out + (size_t)(c0 + fb * cstride) * XCHUNK;
+  *reinterpret_cast<u32x4*>(chunk + (size_t)(2 * S) * 1024 + l * 16) = (u32x4){hu[0], hu[1], hu[2], hu[3]};
+  *reinterpret_cast<u32x4*>(chunk + (size_t)(2 * S + 1) * 1024 + l * 16) = (u32x4){lu[0], lu[1], lu[2], lu[3]};
+}
+// G kind: W2 [256, ff]: hidden chunk ch -> chunk c0 + ch * cstride; fragment (fb, s, plane) at (fb 2 + s) 2 + plane;
+// lane l holds W2[32 fb + (l & 31)][32 ch + kperm(s, l >> 5, j)] * wscale.
+__global__ __launch_bounds__(256) void k_xenc_wprep_g(const float* __restrict__ W, int ld, int nchunks, float wscale,
+                                                      unsigned char* __restrict__ out, int c0, int cstride) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;     // (ch, fb, s, lane)
+  if (gid >= nchunks * 16 * 64) return;
+  const int l = gid & 63, s = (gid >> 6) & 1, fb = (gid >> 7) & 7, ch = gid >> 10;
+  const float* row = W + (size_t)(32 * fb + (l & 31)) * ld + 32 * ch;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = row[kperm(s, l >> 5, j)];
+  unsigned int hu[4], lu[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) split_pk_s(v[2 * i], v[2 * i + 1], wscale, hu[i], lu[i]);
+  unsigned char* chunk = out + (size_t)(c0 + ch * cstride) * XCHUNK;
+  const int fi = (fb * 2 + s) * 2;
+  *reinterpret_cast<u32x4*>(chunk + (size_t)fi * 1024 + l * 16) = (u32x4){hu[0], hu[1], hu[2], hu[3]};
+  *reinterpret_cast<u32x4*>(chunk + (size_t)(fi + 1) * 1024 + l * 16) = (u32x4){lu[0], lu[1], lu[2], lu[3]};
+}
+
+// max |w| and the largest row L1 norm of a [rows, cols] tensor: one workgroup per job.
+struct StatJob {
+  const float* w;
+  int rows, cols;
+};
+__global__ __launch_bounds__(256) void k_xenc_stats(const StatJob* __restrict__ jobs, float* __restrict__ out) {
+  __shared__ float sh[8];
+  const StatJob j = jobs[blockIdx.x];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float amax = 0.f, l1max = 0.f;
+  for (int row = wave; row < j.rows; row += 4) {
+    float s = 0.f;
+    for (int cidx = lane; cidx < j.cols; cidx += 64) {
+      const float a = fabsf(j.w[(size_t)row * j.cols + cidx]);
+      s += a;
+      amax = fmaxf(amax, a);
+    }
+    l1max = fmaxf(l1max, wave_sum(s));
+  }
+  amax = wave_max(amax);
+  if (lane == 0) {
+    sh[wave] = amax;
+    sh[4 + wave] = l1max;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    out[2 * blockIdx.x + 1] = fmaxf(fmaxf(sh[4], sh[5]), fmaxf(sh[6], sh[7]));
+  }
+}
+
+// ---- host plan -----------------------------------------------------------------------------------------
+constexpr int kMaxLayers = 16;
+constexpr uint32_t kPlanMagic = 0x58454e43u;   // "XENC"
+struct Plan {
+  uint32_t magic;
+  int n_layers, d_ff, nhead;
+  int has_final;
+  ChainConsts prologue;              // norm1 of layer 0 + pos -> in_proj (self)
+  ChainConsts a[kMaxLayers];         // behind the self attention
+  ChainConsts b[kMaxLayers];         // behind the cross attention
+  const float* scales_self[kMaxLayers];    // device [4] plane multipliers of the attention cores
+  const float* scales_cross[kMaxLayers];
+};
+
+int chunks_prologue() { return 24; }
+int chunks_a() { return 8 + 24; }
+int chunks_b(int nf, bool tail_inproj) { return 8 + 2 * nf + (tail_inproj ? 24 : 0); }
+size_t stream_chunks(int n_layers, int nf) {
+  size_t n = chunks_prologue();
+  for (int l = 0; l < n_layers; ++l) n += chunks_a() + chunks_b(nf, l + 1 < n_layers);
+  return n;
+}
+constexpr size_t kStatsBytes = 64 * 1024;     // stat jobs + results + plane multipliers
+
+template <bool HEAD, bool FFN, int TAIL>
+int launch_chain(const ChainConsts& c, const float* o, const float* x, float* xo, const float* pos, float* ln,
+                 const AttnPlanes& pl, int T, hipStream_t stream) {
+  auto kern = k_xenc_chain<HEAD, FFN, TAIL>;
+  const size_t lds = xenc_lds_bytes(32 * c.nf, pl.nseg);
+  SPR_REQUIRE(lds <= 160 * 1024, "xenc: d_ff %d with %d segments does not fit the LDS tables", 32 * c.nf, pl.nseg);
+  if (int rc = ensure_dyn_lds((const void*)kern, 160 * 1024)) return rc;
+  const int ntiles = cdiv(T, XTOK);
+  int grid = device_cu_count();
+  grid = grid < ntiles ? grid : ntiles;
+  int stamp_on = 0;
+#ifdef SPR_XENC_STAMP
+  {   // SPR_XENC_STAMP_WHICH = "A", "B" or "P": only launches of that chain kind stamp (default: every launch)
+    const char* e = getenv("SPR_XENC_STAMP_WHICH");
+    const char kind = !HEAD ? 'P' : (FFN ? 'B' : 'A');
+    const char* et = getenv("SPR_XENC_STAMP_TAIL");      // "0", "1" or "2": additionally only that tail
+    stamp_on = (e == nullptr || e[0] == kind) && (et == nullptr || et[0] - '0' == TAIL) ? 1 : 0;
+    const char* ea = getenv("SPR_XENC_ABL");             // ablation bits: 2 = no weight DMA, 4 = no barrier
+    if (ea != nullptr) stamp_on |= atoi(ea) & 6;
+  }
+#endif
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, c, o, x, xo, pos, ln, pl, T, ntiles, stamp_on);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+}  // namespace spr
+
+using namespace spr;
+
+extern "C" size_t spr_xenc_prepared_bytes(int n_layers, int d_ff) {
+  if (n_layers < 1 || n_layers > kMaxLayers || d_ff < 32 || d_ff % 32 != 0) return 0;
+  return kStatsBytes + stream_chunks(n_layers, d_ff / 32) * (size_t)XCHUNK;
+}
+
+extern "C" size_t spr_xenc_plan_bytes(void) { return sizeof(Plan); }
+
+// layer_ptrs_host: SPR_XENC_PTRS_PER_LAYER device pointers per layer, in the order
+//   self_attn.in_proj_weight, .in_proj_bias, .out_proj.weight, .out_proj.bias,
+//   multihead_attn.in_proj_weight, .in_proj_bias, .out_proj.weight, .out_proj.bias,
+//   linear1.weight, .bias, linear2.weight, .bias, norm1.weight, .bias, norm2.weight, .bias, norm3.weight, .bias
+extern "C" int spr_xenc_prepare(const void* const* layer_ptrs_host, const float* eps_host, int n_layers, int d_model,
+                                int nhead, int d_ff, const float* final_g, const float* final_b, float final_eps,
+                                float pos_bound, void* prepared, size_t prepared_bytes, void* plan_host,
+                                size_t plan_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(d_model == XD && nhead == 8, "xenc: d_model must be 256 with 8 heads (got %d, %d)", d_model, nhead);
+  SPR_REQUIRE(n_layers >= 1 && n_layers <= kMaxLayers && d_ff >= 32 && d_ff % 32 == 0,
+              "xenc: bad n_layers / d_ff (%d, %d)", n_layers, d_ff);
+  SPR_REQUIRE(layer_ptrs_host && eps_host && prepared && plan_host, "xenc_prepare: null argument");
+  SPR_REQUIRE(prepared_bytes >= spr_xenc_prepared_bytes(n_layers, d_ff) && plan_bytes >= sizeof(Plan),
+              "xenc_prepare: buffers too small");
+  SPR_REQUIRE((final_g == nullptr) == (final_b == nullptr), "xenc_prepare: final norm needs weight and bias");
+  SPR_REQUIRE(pos_bound >= 0.f, "xenc_prepare: pos_bound must be >= 0");
+  const int nf = d_ff / 32;
+  enum { SA_W, SA_B, SA_OW, SA_OB, CA_W, CA_B, CA_OW, CA_OB, W1, B1, W2, B2, N1G, N1B, N2G, N2B, N3G, N3B, NPTR };
+  static_assert(NPTR == SPR_XENC_PTRS_PER_LAYER, "pointer table layout");
+  auto P = [&](int l, int which) { return (const float*)layer_ptrs_host[l * NPTR + which]; };
+  for (int l = 0; l < n_layers; ++l)
+    for (int w = 0; w < NPTR; ++w) SPR_REQUIRE(P(l, w) != nullptr, "xenc_prepare: layer %d parameter %d is null", l, w);
+
+  // ---- statistics: max |.| and max row L1 of every tensor (in-projections per Q / K / V block) ------
+  // per layer: 0-2 sa_w blocks, 3-5 sa_b blocks, 6 sa_ow, 7 ca_w x3 .. 9, 10-12 ca_b blocks, 13 ca_ow,
+  //            14 w1, 15 b1, 16 w2, 17 n1g, 18 n1b, 19 n2g, 20 n2b, 21 n3g, 22 n3b ; then final g, b
+  constexpr int JPL = 23;
+  std::vector<StatJob> jobs;
+  for (int l = 0; l < n_layers; ++l) {
+    for (int q = 0; q < 3; ++q) jobs.push_back({P(l, SA_W) + (size_t)q * XD * XD, XD, XD});
+    for (int q = 0; q < 3; ++q) jobs.push_back({P(l, SA_B) + (size_t)q * XD, 1, XD});
+    jobs.push_back({P(l, SA_OW), XD, XD});
+    for (int q = 0; q < 3; ++q) jobs.push_back({P(l, CA_W) + (size_t)q * XD * XD, XD, XD});
+    for (int q = 0; q < 3; ++q) jobs.push_back({P(l, CA_B) + (size_t)q * XD, 1, XD});
+    jobs.push_back({P(l, CA_OW), XD, XD});
+    jobs.push_back({P(l, W1), d_ff, XD});
+    jobs.push_back({P(l, B1), 1, d_ff});
+    jobs.push_back({P(l, W2), XD, d_ff});
+    jobs.push_back({P(l, N1G), 1, XD});
+    jobs.push_back({P(l, N1B), 1, XD});
+    jobs.push_back({P(l, N2G), 1, XD});
+    jobs.push_back({P(l, N2B), 1, XD});
+    jobs.push_back({P(l, N3G), 1, XD});
+    jobs.push_back({P(l, N3B), 1, XD});
+  }
+  if (final_g) {
+    jobs.push_back({final_g, 1, XD});
+    jobs.push_back({final_b, 1, XD});
+  }
+  const size_t njobs = jobs.size();
+  // head of the prepared buffer: jobs | results | plane multipliers
+  unsigned char* base = (unsigned char*)prepared;
+  StatJob* jobs_dev = (StatJob*)base;
+  float* res_dev = (float*)(base + 16 * 1024);
+  float* scales_dev = (float*)(base + 32 * 1024);            // [2 n_layers][4]
+  SPR_REQUIRE(njobs * sizeof(StatJob) <= 16 * 1024 && njobs * 2 * sizeof(float) <= 16 * 1024, "xenc_prepare: too many tensors");
+  SPR_HIP_CHECK(hipMemcpyAsync(jobs_dev, jobs.data(), njobs * sizeof(StatJob), hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(k_xenc_stats, dim3((unsigned)njobs), dim3(256), 0, stream, jobs_dev, res_dev);
+  SPR_LAUNCH_CHECK();
+  std::vector<float> res(njobs * 2);
+  SPR_HIP_CHECK(hipMemcpyAsync(res.data(), res_dev, njobs * 2 * sizeof(float), hipMemcpyDeviceToHost, stream));
+  SPR_HIP_CHECK(hipStreamSynchronize(stream));
+  auto amax = [&](int l, int j) { return res[2 * (l * JPL + j)]; };
+  auto l1 = [&](int l, int j) { return res[2 * (l * JPL + j) + 1]; };
+  for (float f : res) SPR_REQUIRE(f == f && f < 3.0e38f, "xenc_prepare: non-finite parameter");
+
+  // 2^k on the host; the single exponents are clamped to +-60 (pow2_exp_for), their sums must stay normal floats
+  bool exp_ok = true;
+  auto pow2f = [&](int k) {
+    if (k < -120 || k > 120) exp_ok = false;
+    return ldexpf(1.0f, k);
+  };
+  Plan* plan = (Plan*)plan_host;
+  memset(plan, 0, sizeof(Plan));
+  plan->n_layers = n_layers;
+  plan->d_ff = d_ff;
+  plan->nhead = nhead;
+  plan->has_final = final_g != nullptr;
+  unsigned char* wbase = base + kStatsBytes;
+  size_t chunk_at = 0;
+  std::vector<float> scales_host((size_t)2 * n_layers * 4);
+  const float lnk = sqrtf((float)(XD - 1)) * 1.0001f;
+  auto ln_bound = [&](float gmax, float bmax) { return lnk * gmax + bmax; };
+
+  auto prep_f = [&](const float* W, int ld, int nblocks, int kw, int c0, int cstride) -> int {
+    hipLaunchKernelGGL(k_xenc_wprep_f, dim3(cdiv((long)nblocks * 1024, 256)), dim3(256), 0, stream, W, ld, nblocks,
+                       pow2f(kw), wbase, c0, cstride);
+    SPR_LAUNCH_CHECK();
+    return 0;
+  };
+  auto prep_g = [&](const float* W, int ld, int nchunks, int kw, int c0, int cstride) -> int {
+    hipLaunchKernelGGL(k_xenc_wprep_g, dim3(cdiv((long)nchunks * 1024, 256)), dim3(256), 0, stream, W, ld, nchunks,
+                       pow2f(kw), wbase, c0, cstride);
+    SPR_LAUNCH_CHECK();
+    return 0;
+  };
+  // in-projection tail: input bound xb (norm + pos); jw = first stat job of the weight blocks, jb of the bias blocks
+  auto setup_inproj = [&](ChainConsts& c, int l, int jw, int jb, const float* W, const float* B, const float* g,
+                          const float* be, float eps, float gmax, float bmax, float* sc, float* o_bound,
+                          int c0) -> int {
+    const float xb = ln_bound(gmax, bmax) + pos_bound;
+    const int kx = pow2_exp_for(xb);
+    const float wmax = fmaxf(fmaxf(amax(l, jw), amax(l, jw + 1)), amax(l, jw + 2));
+    const int kw = pow2_exp_for(wmax);
+    c.g_tail = g;
+    c.b_tail = be;
+    c.eps_tail = eps;
+    c.bin = B;
+    c.xt_scale = pow2f(kx);
+    c.bs_in = pow2f(kx + kw);
+    c.un_in = pow2f(-kx - kw);
+    // plane multipliers (k_plane_scales, attention.hip) from the bounds of the three blocks
+    const float qb = xb * l1(l, jw) + amax(l, jb), kb = xb * l1(l, jw + 1) + amax(l, jb + 1),
+                vb = xb * l1(l, jw + 2) + amax(l, jb + 2);
+    const float qscale = 1.4426950408889634f / sqrtf(32.0f);
+    const float qs = qb * qscale;
+    int ek = 0;
+    if (qs > 0.f && kb > 0.f && qs < 3.0e38f && kb < 3.0e38f) {
+      int eq, ekk;
+      frexpf(qs, &eq);
+      frexpf(kb, &ekk);
+      ek = ((eq - 1) - (ekk - 1)) >> 1;
+      ek = ek < -60 ? -60 : (ek > 60 ? 60 : ek);
+    }
+    const int ev = pow2_exp_for(vb);
+    sc[0] = qscale * pow2f(-ek);
+    sc[1] = pow2f(ek);
+    sc[2] = pow2f(ev);
+    sc[3] = pow2f(-ev);
+    c.pmul[0] = sc[0];
+    c.pmul[1] = sc[1];
+    c.pmul[2] = sc[2];
+    *o_bound = pow2f(15 - ev);
+    return prep_f(W, XD, 24, kw, c0, 1);
+  };
+  auto setup_head = [&](ChainConsts& c, int l, int jw, const float* W, const float* B, float o_bound, int c0) -> int {
+    const int ko = pow2_exp_for(o_bound), kw = pow2_exp_for(amax(l, jw));
+    c.bo = B;
+    c.o_scale = pow2f(ko);
+    c.res_o = pow2f(ko + kw);
+    c.un_o = pow2f(-ko - kw);
+    return prep_f(W, XD, 8, kw, c0, 1);
+  };
+
+  float o_bound = 0.f;
+  // prologue: norm1 of layer 0 + pos -> self in-projection
+  {
+    ChainConsts& c = plan->prologue;
+    c.w = wbase + chunk_at * XCHUNK;
+    c.nf = nf;
+    if (int rc = setup_inproj(c, 0, 0, 3, P(0, SA_W), P(0, SA_B), P(0, N1G), P(0, N1B), eps_host[0], amax(0, 17),
+                              amax(0, 18), &scales_host[0], &o_bound, (int)chunk_at))
+      return rc;
+    chunk_at += chunks_prologue();
+  }
+  for (int l = 0; l < n_layers; ++l) {
+    // chain A: self out_proj + residual, norm2 + pos, cross in-projection
+    {
+      ChainConsts& c = plan->a[l];
+      c.w = wbase + chunk_at * XCHUNK;
+      c.nf = nf;
+      if (int rc = setup_head(c, l, 6, P(l, SA_OW), P(l, SA_OB), o_bound, (int)chunk_at)) return rc;
+      if (int rc = setup_inproj(c, l, 7, 10, P(l, CA_W), P(l, CA_B), P(l, N2G), P(l, N2B), eps_host[3 * l + 1],
+                                amax(l, 19), amax(l, 20), &scales_host[(size_t)(2 * l + 1) * 4], &o_bound,
+                                (int)chunk_at + 8))
+        return rc;
+      chunk_at += chunks_a();
+    }
+    // chain B: cross out_proj + residual, norm3, feed forward + residual, then norm1 of layer l + 1 + pos and
+    // its self in-projection (or the final norm)
+    {
+      ChainConsts& c = plan->b[l];
+      c.w = wbase + chunk_at * XCHUNK;
+      c.nf = nf;
+      if (int rc = setup_head(c, l, 13, P(l, CA_OW), P(l, CA_OB), o_bound, (int)chunk_at)) return rc;
+      const float x2b = ln_bound(amax(l, 21), amax(l, 22));
+      const int kx2 = pow2_exp_for(x2b), kw1 = pow2_exp_for(amax(l, 14));
+      const float hb = x2b * l1(l, 14) + amax(l, 15);
+      const int kh = pow2_exp_for(hb), kw2 = pow2_exp_for(amax(l, 16));
+      c.g_mid = P(l, N3G);
+      c.b_mid = P(l, N3B);
+      c.eps_mid = eps_host[3 * l + 2];
+      c.b1 = P(l, B1);
+      c.b2 = P(l, B2);
+      c.x2_scale = pow2f(kx2);
+      c.bs1 = pow2f(kx2 + kw1);
+      c.h_mul = pow2f(kh - kx2 - kw1);
+      c.res_f = pow2f(kh + kw2);
+      c.un_f = pow2f(-kh - kw2);
+      if (int rc = prep_f(P(l, W1), XD, nf, kw1, (int)chunk_at + 8, 2)) return rc;
+      if (int rc = prep_g(P(l, W2), d_ff, nf, kw2, (int)chunk_at + 9, 2)) return rc;
+      if (l + 1 < n_layers) {
+        if (int rc = setup_inproj(c, l + 1, 0, 3, P(l + 1, SA_W), P(l + 1, SA_B), P(l + 1, N1G), P(l + 1, N1B),
+                                  eps_host[3 * (l + 1)], amax(l + 1, 17), amax(l + 1, 18),
+                                  &scales_host[(size_t)(2 * (l + 1)) * 4], &o_bound, (int)chunk_at + 8 + 2 * nf))
+          return rc;
+      } else if (final_g) {
+        c.g_tail = final_g;
+        c.b_tail = final_b;
+        c.eps_tail = final_eps;
+      }
+      chunk_at += chunks_b(nf, l + 1 < n_layers);
+    }
+  }
+  SPR_REQUIRE(chunk_at == stream_chunks(n_layers, nf), "xenc_prepare: internal chunk count mismatch");
+  SPR_REQUIRE(exp_ok, "xenc_prepare: parameter magnitudes out of the range the split arithmetic can scale");
+  SPR_HIP_CHECK(hipMemcpyAsync(scales_dev, scales_host.data(), scales_host.size() * sizeof(float), hipMemcpyHostToDevice,
+                               stream));
+  SPR_HIP_CHECK(hipStreamSynchronize(stream));   // scales_host goes out of scope
+  for (int l = 0; l < n_layers; ++l) {
+    plan->scales_self[l] = scales_dev + (size_t)(2 * l) * 4;
+    plan->scales_cross[l] = scales_dev + (size_t)(2 * l + 1) * 4;
+  }
+  plan->magic = kPlanMagic;
+  return 0;
+}
+
+#ifdef SPR_XENC_STAMP
+// diagnostic build: zero / read the stamp buffer (not part of include/spr.h)
+extern "C" int spr_xenc_debug_stamps(unsigned long long* out_host, int clear) {
+  if (clear) {
+    static unsigned long long zeros[64 * 64];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_xenc_stamps), zeros, sizeof(zeros)) != hipSuccess;
+  }
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_xenc_stamps), sizeof(unsigned long long) * 64 * 64) != hipSuccess;
+}
+#endif
+
+extern "C" size_t spr_xenc_workspace_bytes(int t, int nseg) {
+  if (t < 1 || nseg < 1) return 0;
+  return spr_attn_workspace_bytes(t, nseg, 8, 32) + 3 * align_up((size_t)t * XD * sizeof(float), 256);
+}
+
+// x [t, 256] tokens of all clouds (packed), pos [t, 256] positional embedding, cu [nseg + 1],
+// kv_self / kv_cross [nseg] key segment of every query segment; out [t, 256].
+extern "C" int spr_xenc_forward(const void* plan_host, const float* x, const float* pos, const int* cu,
+                                const int* kv_self, const int* kv_cross, int t, int nseg, int max_len_host,
+                                float* out, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const Plan* plan = (const Plan*)plan_host;
+  SPR_REQUIRE(plan != nullptr && plan->magic == kPlanMagic, "xenc_forward: plan is not prepared");
+  SPR_REQUIRE(x && pos && cu && kv_self && kv_cross && out, "xenc_forward: null argument");
+  SPR_REQUIRE(t >= 1 && nseg >= 1 && max_len_host >= 1, "xenc_forward: bad sizes");
+  SPR_REQUIRE((size_t)t * XD * 4 < (1ull << 32), "xenc_forward: too many tokens");
+  SPR_REQUIRE(ws != nullptr && ws_bytes >= spr_xenc_workspace_bytes(t, nseg), "xenc_forward: workspace too small");
+  const int mode = attn_mode();
+  SPR_REQUIRE(gemm_mode() == 1 && (mode == 1 || mode == 2),
+              "xenc_forward: needs the split-fp16 arithmetic (gemm mode 1, attention mode 1 or 2)");
+  const size_t planes_bytes = spr_attn_workspace_bytes(t, nseg, 8, 32);
+  AttnPlanes pl{};
+  if (int rc = attn_carve_planes(ws, planes_bytes, t, nseg, XD, pl)) return rc;
+  pl.cu = cu;
+  pl.nseg = nseg;
+  pl.t_total = t;
+  pl.tp = (int)attn_tp(t, nseg);
+  const size_t act = align_up((size_t)t * XD * sizeof(float), 256);
+  float* obuf = (float*)((char*)ws + planes_bytes);
+  float* xa = (float*)((char*)ws + planes_bytes + act);
+  float* xb = (float*)((char*)ws + planes_bytes + 2 * act);
+  if (int rc = attn_zero_gaps(pl, XD, stream)) return rc;
+  const int L = plan->n_layers;
+  if (int rc = launch_chain<false, false, 2>(plan->prologue, nullptr, x, nullptr, pos, nullptr, pl, t, stream)) return rc;
+  const float* cur = x;
+  float* nxt = xa;
+  for (int l = 0; l < L; ++l) {
+    pl.scales = plan->scales_self[l];
+    if (int rc = attn_core_on_planes(pl, kv_self, max_len_host, 8, obuf, XD, mode, stream)) return rc;
+    if (int rc = launch_chain<true, false, 2>(plan->a[l], obuf, cur, nxt, pos, nullptr, pl, t, stream)) return rc;
+    cur = nxt;
+    nxt = (nxt == xa) ? xb : xa;
+    pl.scales = plan->scales_cross[l];
+    if (int rc = attn_core_on_planes(pl, kv_cross, max_len_host, 8, obuf, XD, mode, stream)) return rc;
+    if (l + 1 < L) {
+      if (int rc = launch_chain<true, true, 2>(plan->b[l], obuf, cur, nxt, pos, nullptr, pl, t, stream)) return rc;
+      cur = nxt;
+      nxt = (nxt == xa) ? xb : xa;
+    } else if (plan->has_final) {
+      if (int rc = launch_chain<true, true, 1>(plan->b[l], obuf, cur, nxt, pos, out, pl, t, stream)) return rc;
+    } else {
+      if (int rc = launch_chain<true, true, 0>(plan->b[l], obuf, cur, out, pos, nullptr, pl, t, stream)) return rc;
+    }
+  }
+  return 0;
+}

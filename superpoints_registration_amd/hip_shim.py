@@ -40,6 +40,12 @@ def _cu(lens, dev):
     return torch.from_numpy(cu).to(dev)
 
 
+def _stream(dev):
+    """The caller's current HIP stream: the tensors above are allocated and copied on it, and the results are
+    read back on it (torch streams do not synchronise with the NULL stream)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
 def _raise(L):
     msg = L.spr_last_error()
     raise RuntimeError(msg.decode() if msg else "Error")
@@ -63,7 +69,7 @@ class cpp_subsampling:
         tot = torch.empty(1, dtype=torch.int32, device=dev)
         cu = _cu(batches, dev)       # (held in a variable: a temporary would be freed before the kernels run)
         rc = L.spr_grid_subsample(_p(x), _p(cu), n, nb, ctypes.c_float(sampleDl), int(max_p), 0,
-                                  _p(out), _p(lens), _p(tot), _p(ws), ctypes.c_size_t(ws.numel()), None)
+                                  _p(out), _p(lens), _p(tot), _p(ws), ctypes.c_size_t(ws.numel()), _stream(dev))
         if rc:
             _raise(L)
         m = int(tot.item())
@@ -95,7 +101,7 @@ class cpp_neighbors:
         for algo in (0, 1):                  # 0 = cell table, 1 = sorted keys (no geometry limit)
             rc = L.spr_radius_neighbors(_p(q), _p(q_cu), nq, _p(s), _p(s_cu), ns, nb,
                                         ctypes.c_float(radius), int(limit), algo, _p(out), _p(mc), _p(ws),
-                                        ctypes.c_size_t(ws.numel()), None)
+                                        ctypes.c_size_t(ws.numel()), _stream(dev))
             if rc:
                 _raise(L)
             m = int(mc.item())

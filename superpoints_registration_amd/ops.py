@@ -7,6 +7,7 @@ tensors -- a CPU tensor raises, there is no fallback.
 import ctypes
 import math
 import os
+import threading
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -273,10 +274,15 @@ class RadiusTable:
                                             _stream(self.supports)), "spr_radius_table_build")
         self._slot = 0
         self._slots = L.spr_radius_table_slots()
+        self._versions = (self.supports._version, self.s_cu._version)   # the table is stale after an in-place edit
 
     def matches(self, supports: torch.Tensor, s_cu: torch.Tensor, radius: float) -> bool:
+        """True when this table was built from exactly these tensors (same storage, shape AND content: an
+        in-place update of the supports bumps their version counter) at this radius and has a result slot left."""
         return (supports.data_ptr() == self.supports.data_ptr() and supports.shape[0] == self.ns
                 and s_cu.data_ptr() == self.s_cu.data_ptr() and float(radius) == self.radius
+                and (self.supports._version, self.s_cu._version) == self._versions
+                and supports._version == self.supports._version and s_cu._version == self.s_cu._version
                 and self._slot < self._slots)
 
     def query(self, queries: torch.Tensor, q_cu: torch.Tensor, limit: int) -> Tuple[torch.Tensor, int]:
@@ -766,6 +772,74 @@ def attention_inproj(x_qk, x_v, w_in, b_in, cu, kv_seg, max_len: int, nhead: int
                "spr_attn_inproj_varlen_fwd_r")
     if orng is not None:
         _set_range(out, orng, 1)
+    return out
+
+
+# ---- fused cross-encoder stack (csrc/xenc.hip) ---------------------------------------------------
+_XENC_ON = os.environ.get("SPR_NO_XENC", "0") != "1"   # experiment switch (A/B against the per-operator route)
+_xenc_lock = threading.Lock()
+XENC_PTRS_PER_LAYER = 18                                # SPR_XENC_PTRS_PER_LAYER of include/spr.h
+
+
+class XencPlan:
+    """Prepared weights of a cross-encoder stack: split-fp16 fragment streams on the device + the
+    host-side plan (spr_xenc_prepare).  Valid while the parameters it was built from are untouched
+    (storage pointers and version counters are part of `key`)."""
+
+    def __init__(self, key, prepared, plan, keep):
+        self.key, self.prepared, self.plan, self.keep = key, prepared, plan, keep
+
+
+def xenc_available() -> bool:
+    return _XENC_ON and _modes["gemm"] == 1 and _modes["attn"] in (1, 2)
+
+
+def xenc_prepare(layer_params, layer_eps, final, nhead: int, d_ff: int, pos_bound: float, cached=None) -> XencPlan:
+    """layer_params: per layer the 18 parameter tensors in the order of include/spr.h
+    (SPR_XENC_PTRS_PER_LAYER); layer_eps: per layer (eps1, eps2, eps3); final: (weight, bias, eps) of
+    the stack's last LayerNorm or None.  `cached`: a previous XencPlan, returned as is when nothing changed."""
+    flat = [t for lp in layer_params for t in lp] + ([final[0], final[1]] if final is not None else [])
+    key = (tuple((t.data_ptr(), t._version) for t in flat), tuple(float(e) for le in layer_eps for e in le),
+           None if final is None else float(final[2]), int(nhead), int(d_ff), float(pos_bound), _range_epoch[0])
+    if cached is not None and cached.key == key:
+        return cached
+    with _xenc_lock:
+        L = _lib.lib()
+        n_layers = len(layer_params)
+        keep = [_dev(t.detach(), "parameter", torch.float32) for t in flat]
+        per = XENC_PTRS_PER_LAYER
+        assert all(len(lp) == per for lp in layer_params)
+        ptrs = (ctypes.c_void_p * (n_layers * per))(*[t.data_ptr() for t in keep[:n_layers * per]])
+        eps = (ctypes.c_float * (3 * n_layers))(*[float(e) for le in layer_eps for e in le])
+        dev = keep[0].device
+        nbytes = L.spr_xenc_prepared_bytes(n_layers, int(d_ff))
+        if nbytes == 0:
+            raise RuntimeError("xenc_prepare: unsupported stack shape")
+        prepared = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        plan = ctypes.create_string_buffer(L.spr_xenc_plan_bytes())
+        fg = keep[-2] if final is not None else None
+        fb = keep[-1] if final is not None else None
+        _lib.check(L.spr_xenc_prepare(ptrs, eps, n_layers, 256, int(nhead), int(d_ff), _ptr(fg), _ptr(fb),
+                                      float(final[2]) if final is not None else 0.0, float(pos_bound),
+                                      _ptr(prepared), nbytes, plan, len(plan), _stream(prepared)), "spr_xenc_prepare")
+        return XencPlan(key, prepared, plan, keep)
+
+
+def xenc_forward(plan: XencPlan, x, pos, cu, seg_self, seg_cross, max_len: int) -> torch.Tensor:
+    x = _dev(x, "x", torch.float32)
+    pos = _dev(pos, "pos", torch.float32)
+    cu = _dev(cu, "cu", torch.int32)
+    seg_self = _dev(seg_self, "seg_self", torch.int32)
+    seg_cross = _dev(seg_cross, "seg_cross", torch.int32)
+    T, d = x.shape
+    assert d == 256 and pos.shape == (T, d)
+    nseg = cu.numel() - 1
+    out = torch.empty_like(x)
+    L = _lib.lib()
+    ws = _workspace(L.spr_xenc_workspace_bytes(T, nseg), x.device)
+    plan.prepared.record_stream(torch.cuda.current_stream(x.device))
+    _lib.check(L.spr_xenc_forward(plan.plan, _ptr(x), _ptr(pos), _ptr(cu), _ptr(seg_self), _ptr(seg_cross), T, nseg,
+                                  int(max_len), _ptr(out), _ptr(ws), ws.numel(), _stream(x)), "spr_xenc_forward")
     return out
 
 

@@ -155,7 +155,7 @@ class RegTR(nn.Module):
         seg_host = ([int(n) for n in list(src_lens) + list(tgt_lens)], list(range(2 * B)),
                     list(range(B, 2 * B)) + list(range(B)))
         cond = self.transformer_encoder.forward_packed(tokens, cu, seg_self, seg_cross, max_len, pos=pe,
-                                                       seg_host=seg_host)
+                                                       seg_host=seg_host, pos_bound=1.0)   # |sin|, |cos| <= 1
 
         # overlap head (qk_regtr_full.py:248-249)
         overlap = ops.linear(cond, self.overlap_predictor.weight, self.overlap_predictor.bias,

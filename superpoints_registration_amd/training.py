@@ -127,6 +127,17 @@ class GradientSync:
         self._handles[bi] = self.dist.all_reduce(self.buckets[bi], op=self.dist.ReduceOp.SUM, group=self.group,
                                                  async_op=True)
 
+    def _launch_ready(self):
+        """Collectives must be issued in the same order on every rank, whatever the order in which a rank's
+        hooks fire (or whether its backward ran at all): buckets leave in ASCENDING index order only -- a
+        complete bucket waits for its predecessors (finish() sends the rest, in the same order)."""
+        if self._expected is None:
+            return
+        nxt = len(self._handles)
+        while nxt < len(self.buckets) and self._expected[nxt] and self._fired[nxt] >= self._expected[nxt]:
+            self._launch(nxt)
+            nxt += 1
+
     def _on_grad(self, p):
         bi, _ = self._slot[p]
         want = self._view(p)
@@ -142,41 +153,70 @@ class GradientSync:
             raise RuntimeError("GradientSync: a gradient was accumulated into a bucket whose all-reduce had "
                                "already been launched (call sync.zero_grad() before every backward)")
         self._fired[bi].add(p)
-        if self._expected is not None and self._fired[bi] >= self._expected[bi]:
-            self._launch(bi)
+        self._launch_ready()
 
-    def finish(self):
-        """Call after backward() on EVERY rank (also when the loss carried no gradient: the
-        collectives must match across ranks): launches what the hooks could not, waits, turns sums
-        into means, and drops the zero gradients of parameters that did not take part."""
-        if self._expected is None:
-            self._expected = [set(f) for f in self._fired]
-        for bi in range(len(self.buckets)):
+    def finish(self) -> bool:
+        """Call after backward() on EVERY rank, also when this rank's loss carried no gradient: launches
+        what the hooks could not, waits, turns sums into means.  Returns whether ANY rank had a gradient
+        this step -- every rank then clips and steps (or none does), so replicas and schedules stay in
+        lock step.  What took part is agreed ACROSS ranks (one small all-reduce of two masks behind the
+        buckets): a rank without a local gradient keeps the averaged gradient of its peers, learns the
+        same set of participating parameters, and joins the same per-parameter reductions of late
+        parameters."""
+        for bi in range(len(self.buckets)):           # ascending, like _launch_ready
             self._launch(bi)
+        n = len(self.params)
+        index = {p: i for i, p in enumerate(self.params)}
+        mask = torch.zeros(2 * n, dtype=torch.int32)
+        for f in self._fired:
+            for p in f:
+                mask[index[p]] = 1
+        for p in self._late:
+            mask[index[p]] = 1
+            mask[n + index[p]] = 1
+        if self.active and self.world > 1:
+            dev = self.buckets[0].device if self.buckets else torch.device('cpu')
+            m = mask.to(dev)
+            self.dist.all_reduce(m, op=self.dist.ReduceOp.MAX, group=self.group)
+            mask = m.cpu()
+        fired_any = [self.params[i] for i in range(n) if mask[i]]
+        late_any = [self.params[i] for i in range(n) if mask[n + i]]
+        any_grad = bool(fired_any)
         for bi, h in self._handles.items():
             h.wait()
-        for p in self._late:                 # same set on every rank (decided by the config, not the data)
-            if self.active:
-                self.dist.all_reduce(p.grad, op=self.dist.ReduceOp.SUM, group=self.group)
+        if self._expected is None and any_grad:       # learned from a step in which some rank's backward ran
+            self._expected = [set() for _ in self.buckets]
+            for p in fired_any:
+                self._expected[self._slot[p][0]].add(p)
+        local_late = set(self._late)
+        for p in late_any:                            # same list, same order, on every rank
             want = self._view(p)
-            want.copy_(p.grad)
+            t = p.grad if p in local_late else torch.zeros_like(want)
+            if self.active:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            want.copy_(t)
             p.grad = want
             bi, _ = self._slot[p]
-            self._expected[bi].add(p)
-            self._fired[bi].add(p)
+            if self._expected is not None:
+                self._expected[bi].add(p)
         if self.world > 1:
             for b in self.buckets:
                 b.div_(self.world)
+        taking_part = set(fired_any)
         for p in self.params:
-            bi, _ = self._slot[p]
-            if p not in self._fired[bi] and p.grad is not None and p.grad.data_ptr() == self._view(p).data_ptr():
+            want = self._view(p)
+            if p in taking_part:
+                if p.grad is None or p.grad.data_ptr() != want.data_ptr():
+                    p.grad = want                     # no local gradient: the peers' average
+            elif p.grad is not None and p.grad.data_ptr() == want.data_ptr():
                 p.grad = None
         # ready for the next backward even if the caller resets gradients with optimizer.zero_grad()
         # instead of sync.zero_grad()
-        self.n_reduced = len(self._handles) + len(self._late)
+        self.n_reduced = len(self._handles) + len(late_any)
         self._fired = [set() for _ in self.buckets]
         self._handles = {}
         self._late = []
+        return any_grad
 
     def close(self):
         for h in self._hooks:
@@ -346,7 +386,10 @@ class Trainer:
             if has_grad:
                 losses['total'].backward()
             if self.sync is not None:
-                self.sync.finish()        # explicit RCCL gradient all-reduce (mean); on every rank, always
+                # explicit RCCL gradient all-reduce (mean); on every rank, always.  With several ranks the
+                # step is taken when ANY rank had a gradient (the reference clips and steps unconditionally
+                # on every rank, trainer.py:121-127): a rank-local decision would let replicas diverge
+                has_grad = self.sync.finish()
             if has_grad:
                 if self.grad_clip > 0:
                     torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=self.grad_clip)

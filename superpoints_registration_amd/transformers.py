@@ -193,7 +193,36 @@ class TransformerCrossEncoder(nn.Module):
         self.norm = norm
         self.return_intermediate = return_intermediate
 
-    def forward_packed(self, x, cu, seg_self, seg_cross, max_len, pos=None, seg_host=None):
+    # -- fused stack (csrc/xenc.hip): two attention cores + two row-chain kernels per layer ---------
+    def _xenc_eligible(self, x, pos, pos_bound) -> bool:
+        if pos is None or pos_bound is None or not ops.xenc_available() or x.shape[1] != 256:
+            return False
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False                                  # training: the differentiable per-operator route
+        return all(l.normalize_before and l.sa_val_has_pos_emb and l.ca_val_has_pos_emb and l.nhead == 8
+                   and l.linear1.out_features % 32 == 0 for l in self.layers)
+
+    def _xenc_plan(self, pos_bound: float):
+        lp, le = [], []
+        for l in self.layers:
+            lp.append([l.self_attn.in_proj_weight, l.self_attn.in_proj_bias, l.self_attn.out_proj.weight,
+                       l.self_attn.out_proj.bias, l.multihead_attn.in_proj_weight, l.multihead_attn.in_proj_bias,
+                       l.multihead_attn.out_proj.weight, l.multihead_attn.out_proj.bias, l.linear1.weight,
+                       l.linear1.bias, l.linear2.weight, l.linear2.bias, l.norm1.weight, l.norm1.bias,
+                       l.norm2.weight, l.norm2.bias, l.norm3.weight, l.norm3.bias])
+            le.append((l.norm1.eps, l.norm2.eps, l.norm3.eps))
+        final = (self.norm.weight, self.norm.bias, self.norm.eps) if self.norm is not None else None
+        plan = ops.xenc_prepare(lp, le, final, 8, self.layers[0].linear1.out_features, pos_bound,
+                                cached=getattr(self, '_spr_xenc', None))
+        self._spr_xenc = plan
+        return plan
+
+    def forward_packed(self, x, cu, seg_self, seg_cross, max_len, pos=None, seg_host=None, pos_bound=None):
+        """pos_bound: an upper bound of max |pos| the caller guarantees (1.0 for the sine embedding).  With it
+        (and the shipped layer configuration, inference) the stack runs as the fused chains of csrc/xenc.hip;
+        without it operator by operator."""
+        if self._xenc_eligible(x, pos, pos_bound):
+            return ops.xenc_forward(self._xenc_plan(float(pos_bound)), x, pos, cu, seg_self, seg_cross, max_len)
         for layer in self.layers:
             x = layer.forward_packed(x, cu, seg_self, seg_cross, max_len, pos=pos, seg_host=seg_host)
         if self.norm is not None:

@@ -93,6 +93,17 @@ def test_maxpool_and_gather_backward(device):
     cx2 = x.double().requires_grad_(True)
     cx2[sel.long()].backward(go[:5].double())
     assert _rel(dx2.grad, cx2.grad) <= 1e-6
+    # a NaN / inf in the incoming gradient must not come out finite (the fixed-point sums cannot
+    # carry it per element, so the whole gradient is marked: a finite-gradient check downstream still fires)
+    for bad in (float('nan'), float('inf')):
+        gb = go.clone()
+        gb[3, 7] = bad
+        dx3 = _leaf(x, device)
+        ops.maxpool(dx3, idx.to(torch.int32).to(device)).backward(gb.to(device))
+        assert not bool(torch.isfinite(dx3.grad).all())
+        dx4 = _leaf(x, device)
+        ops.gather_rows(dx4, sel.to(device)).backward(gb[:5].to(device))
+        assert not bool(torch.isfinite(dx4.grad).all())
 
 
 @pytest.mark.parametrize("tag", ["c32", "c64", "c128", "c48"])

@@ -41,3 +41,17 @@ def test_batch_query_like_the_reference_extension(device):
     assert_rows_equal_up_to_ties(ref, nb, sub, s_ext, truncated=False)
     with pytest.raises(RuntimeError):
         cpp_neighbors.batch_query(np.zeros((0, 3), np.float32), pts, np.array([0, 0], np.int32), lens, radius=0.09)
+
+
+def test_shim_inside_a_non_default_stream_context(device):
+    """the kernels run on the caller's current stream (uploads, kernels and read-back ordered on it)."""
+    import torch
+    pts, lens = _clouds()
+    ref, ref_lens = native.ref_grid_subsample(pts, lens, 0.05, 0)
+    side = torch.cuda.Stream(device)
+    with torch.cuda.stream(side):
+        for _ in range(3):                                                   # repeated: a race would show as a mismatch
+            sub, sub_lens = cpp_subsampling.subsample_batch(pts, lens, sampleDl=0.05)
+            assert np.array_equal(sub_lens, ref_lens) and np.array_equal(sub.view(np.uint32), ref.view(np.uint32))
+            nb = cpp_neighbors.batch_query(sub, pts, sub_lens, lens, radius=0.09)
+            assert nb.shape == native.ref_radius_neighbors(sub, pts, sub_lens, lens, 0.09).shape

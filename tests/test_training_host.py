@@ -104,6 +104,81 @@ def test_two_rank_gradient_allreduce_equals_single_process_mean():
         assert torch.allclose(torch.from_numpy(res[0][1][n]), p.detach(), rtol=1e-5, atol=1e-7), n  # == single process
 
 
+class ToyMaybeDetached(Toy):
+    """compute_loss carries no gradient when the batch says so (a rank-local, data-dependent event)."""
+
+    def compute_loss(self, pred, batch):
+        loss = ((pred['y'] - batch['t']) ** 2).mean()
+        return {'total': loss.detach() if batch.get('detach', False) else loss}
+
+
+def _worker_detached(rank, world, port, q, first_step_detached):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = get_config("3dmatch")
+    model = ToyMaybeDetached()
+    tr = Trainer(cfg, rank=rank, world=world, bucket_bytes=256).setup(model)
+    lrs = []
+    for step in range(4):
+        b = _batch(100 * step + rank)
+        # rank 1 has no gradient in step 0 (before anything was learnt) or in step 2 (hooks active on rank 0)
+        b['detach'] = rank == 1 and step == (0 if first_step_detached else 2)
+        tr.train_step(model, b)
+        lrs.append(tr.optimizer.param_groups[0]['lr'])
+    q.put((rank, {n: p.detach().numpy().copy() for n, p in model.named_parameters()}, lrs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_detached(first_step_detached):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_detached, args=(r, 2, port, q, first_step_detached)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict((r, (w, lrs)) for r, w, lrs in (q.get(timeout=180) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process replay: the rank without a gradient contributes zeros to the mean
+    cfg = get_config("3dmatch")
+    model = ToyMaybeDetached()
+    opt, sched = configure_optimizers(model, cfg)
+    for step in range(4):
+        per_rank = []
+        for rank in range(2):
+            model.zero_grad(set_to_none=True)
+            if not (rank == 1 and step == (0 if first_step_detached else 2)):
+                b = _batch(100 * step + rank)
+                model.compute_loss(model(b), b)['total'].backward()
+            per_rank.append({n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+        for n, p in model.named_parameters():
+            if n in per_rank[0]:
+                p.grad = 0.5 * (per_rank[0][n] + per_rank[1].get(n, torch.zeros_like(per_rank[0][n])))
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=cfg.grad_clip)
+        opt.step()
+        sched.step()
+    assert res[0][1] == res[1][1], "learning-rate schedules diverged"
+    for n, p in model.named_parameters():
+        assert np.array_equal(res[0][0][n], res[1][0][n]), f"replicas diverged in {n}"
+        assert torch.allclose(torch.from_numpy(res[0][0][n]), p.detach(), rtol=1e-5, atol=1e-7), n
+
+
+def test_rank_without_gradient_steps_with_its_peers():
+    """a rank whose loss carries no gradient in some step keeps the averaged gradient of its
+    peers and takes the same optimizer / scheduler step (the reference steps unconditionally on every rank,
+    trainer.py:121-127)."""
+    _run_detached(first_step_detached=False)
+
+
+def test_first_step_without_gradient_on_one_rank_learns_the_same_buckets():
+    """the set of participating parameters is agreed across ranks, so a rank whose FIRST step had
+    no backward neither launches half-empty buckets later nor issues collectives its peers do not."""
+    _run_detached(first_step_detached=True)
+
+
 def test_step_order_clip_before_step_and_scheduler_after():
     cfg = get_config("3dmatch")
     cfg.scheduler_param = [2, 0.5]
