@@ -37,6 +37,7 @@
 // evaluated on the host when the weights are prepared.  The bounds are loose by 2^4..2^8; the split
 // keeps an absolute error of 2^-40 of the SCALED maximum, so the results stay at fp32 rounding level
 // (spr_common.h, split_pk_s) and nothing can overflow.  No range is measured or handed over at run time.
+#include <type_traits>
 #include <vector>
 
 #include "attn_planes.h"
@@ -185,10 +186,16 @@ __device__ __forceinline__ f32x16 ln_block(const f32x16& v, int b, int h, float 
 }
 
 // ---- chunk engine ----------------------------------------------------------------------------------
-// A chunk is 16 steps; step i uses fragments 2 i (hi) and 2 i + 1 (lo) of the chunk's slot and issues three
-// MFMAs.  Fragment reads run THREE steps ahead of the MFMAs through a ring of four register pairs that is
-// carried from chunk to chunk: the last three steps of a chunk read the first three fragments pairs of the
-// NEXT chunk, which is acquired (DMA wait + barrier + refill of the slot every wave has left) at step 8.
+// One wave per SIMD: nothing else issues while this wave waits, and every instruction of the wave costs
+// ~4 cycles of issue; what is not placed INSIDE the 32-cycle shadow of an MFMA is paid in full.  So the
+// stream is laid out by hand and pinned with sched_barrier: a chunk is 16 steps; step i issues
+//   MFMA (lo x hi) | side slice 2i | MFMA (hi x lo) | side slice 2i+1 | MFMA (hi x hi) | two fragment reads
+//   for step i + 3 | (steps 8..15) one 1-KiB piece of the weight DMA
+// where the "side" slices are the epilogue of the PREVIOUS chunk cut into 32 pieces (ReLU + split of the
+// hidden chunk, plane stores, bias initialisation of the next accumulator, ...).  Fragment reads run three
+// steps ahead through a ring of four register pairs carried from chunk to chunk: the last three steps of a
+// chunk read the first fragments of the NEXT chunk, which is acquired (counted DMA wait + barrier) at step 8.
+#define XSB() __builtin_amdgcn_sched_barrier(0)
 struct Carry {
   f16x8 h[4], l[4];
 };
@@ -197,26 +204,15 @@ __device__ __forceinline__ void frag_ld(const unsigned char* slot, int lane, int
   h = fr[(2 * i) * 64];
   l = fr[(2 * i + 1) * 64];
 }
-template <class MF, class ACQ>
-__device__ __forceinline__ const unsigned char* run_chunk(const unsigned char* cur, int lane, Carry& c, MF&& mf,
-                                                          ACQ&& acq) {
-  const unsigned char* nxt = cur;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    if (i == 8) nxt = acq();
-    if (i + 3 < 16) frag_ld(cur, lane, i + 3, c.h[(i + 3) & 3], c.l[(i + 3) & 3]);
-    else frag_ld(nxt, lane, i + 3 - 16, c.h[(i + 3) & 3], c.l[(i + 3) & 3]);
-    __builtin_amdgcn_sched_barrier(0);
-    mf(i, c.h[i & 3], c.l[i & 3]);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  return nxt;
+__device__ __forceinline__ f32x16 mfma1(const f16x8& a, const f16x8& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ f32x16 mfma3(const f16x8& wh, const f16x8& wl, const f16x8& xh, const f16x8& xl, f32x16 acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, acc, 0, 0, 0);
-  return acc;
+
+// LDS: [ring XSLOTS x XCHUNK] [tables] [cu]
+constexpr int T_BO = 0, T_B2 = 256, T_GM = 512, T_BM = 768, T_GT = 1024, T_BT = 1280, T_BIN = 1536, T_B1 = 2304;
+constexpr int T_PAD = 64;   // the bias tables are read one block past their end by the pipelined initialisations
+__host__ __device__ inline size_t xenc_lds_bytes(int d_ff, int nseg) {
+  return (size_t)XSLOTS * XCHUNK + (size_t)(T_B1 + d_ff + T_PAD + nseg + 1) * 4;
 }
 
 // Diagnostic build only (-DSPR_XENC_STAMP, scripts/xenc_timeline.py): shader-clock stamps of wave 0 of
@@ -225,12 +221,12 @@ __device__ __forceinline__ f32x16 mfma3(const f16x8& wh, const f16x8& wl, const 
 __device__ unsigned long long g_xenc_stamps[64 * 64];
 #define XSTAMP(k)                                                                                   \
   do {                                                                                              \
-    if (blockIdx.x == 0 && tid == 0 && it < 64 && T < 0x7fffffff && c.nf > 0 && (stamp_on & 1))          \
+    if (blockIdx.x == 0 && tid == 0 && it < 64 && (stamp_on & 1))                                   \
       g_xenc_stamps[it * 64 + (k)] = __builtin_amdgcn_s_memtime();                                  \
   } while (0)
 #define XSTAMP_REAL(k)                                                                              \
   do {                                                                                              \
-    if (blockIdx.x == 0 && tid == 0 && it < 64 && (stamp_on & 1))                                      \
+    if (blockIdx.x == 0 && tid == 0 && it < 64 && (stamp_on & 1))                                   \
       g_xenc_stamps[it * 64 + (k)] = __builtin_amdgcn_s_memrealtime();                              \
   } while (0)
 #else
@@ -238,31 +234,26 @@ __device__ unsigned long long g_xenc_stamps[64 * 64];
 #define XSTAMP_REAL(k) do { } while (0)
 #endif
 
-// LDS: [ring XSLOTS x XCHUNK] [tables] [cu]
-constexpr int T_BO = 0, T_B2 = 256, T_GM = 512, T_BM = 768, T_GT = 1024, T_BT = 1280, T_BIN = 1536, T_B1 = 2304;
-__host__ __device__ inline size_t xenc_lds_bytes(int d_ff, int nseg) {
-  return (size_t)XSLOTS * XCHUNK + (size_t)(T_B1 + d_ff + nseg + 1) * 4;
-}
-
 // TAIL: 0 = x_out only, 1 = LayerNorm -> ln_out (final norm), 2 = LayerNorm + pos -> in-projection -> planes
 template <bool HEAD, bool FFN, int TAIL>
-__global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const float* __restrict__ o_g,
-                                                       const float* __restrict__ x_g, float* __restrict__ xo_g,
-                                                       const float* __restrict__ pos_g, float* __restrict__ ln_g,
-                                                       AttnPlanes pl, int T, int ntiles, int stamp_on) {
+__global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const float* o_g, const float* x_g, float* xo_g,
+                                                       const float* pos_g, float* ln_g, AttnPlanes pl, int T,
+                                                       int ntiles, int* tile_ctr, int stamp_on) {
   extern __shared__ __align__(16) unsigned char ring[];
   float* tab = reinterpret_cast<float*>(ring + XSLOTS * XCHUNK);
   const int d_ff = 32 * c.nf;
-  int* cu_s = reinterpret_cast<int*>(tab + T_B1 + d_ff);
+  int* cu_s = reinterpret_cast<int*>(tab + T_B1 + d_ff + T_PAD);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const unsigned ring_s = (unsigned)(uintptr_t)ring;
   const int nch = (HEAD ? 8 : 0) + (FFN ? 2 * c.nf : 0) + (TAIL == 2 ? 24 : 0);   // chunks per tile
-  const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-  const int total = my_tiles * nch;   // chunks this workgroup consumes
-
-  // ---- parameter tables and cu_seqlens into LDS (the steady state issues no register loads) ----
+  // Tiles are dealt by a device counter (tile_ctr, zeroed by the host before the launch): workgroups that run
+  // slower (or start later) take fewer tiles.  (A staggered start -- four phase groups per XCD, so that the
+  // chip does not load its tile operands in one burst -- was measured and changed nothing: the operand phases
+  // are bound by what ONE CU's vector-memory path moves, 128 KB per tile tensor at ~25 GB/s, not by HBM.)
+  __shared__ int s_tile[2];
+  // ---- parameter tables and cu_seqlens into LDS (the steady state reads its operands from LDS only) ----
   for (int i = tid; i < 256; i += 256) {
     tab[T_BO + i] = HEAD ? c.bo[i] : 0.f;
     tab[T_B2 + i] = FFN ? c.b2[i] : 0.f;
@@ -271,91 +262,137 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
     tab[T_GT + i] = TAIL >= 1 ? c.g_tail[i] : 0.f;
     tab[T_BT + i] = TAIL >= 1 ? c.b_tail[i] : 0.f;
   }
-  if (TAIL == 2)
-    for (int i = tid; i < 768; i += 256) tab[T_BIN + i] = c.bin[i];
-  if (FFN)
-    for (int i = tid; i < d_ff; i += 256) tab[T_B1 + i] = c.b1[i];
+  for (int i = tid; i < 768; i += 256) tab[T_BIN + i] = TAIL == 2 ? c.bin[i] : 0.f;
+  for (int i = tid; i < d_ff + T_PAD; i += 256) tab[T_B1 + i] = (FFN && i < d_ff) ? c.b1[i] : 0.f;
   if (TAIL == 2)
     for (int i = tid; i <= pl.nseg; i += 256) cu_s[i] = pl.cu[i];
   __syncthreads();
 
-  // ---- weight ring ---------------------------------------------------------------------------------
-  int g_acq = 0;                          // next chunk to acquire
-  int i_pos = 0, i_slot = 0, g_iss = 0;   // issue side: stream position, slot, chunk number
-  int a_slot = 0;                         // acquire side slot
-  // counted (asm) stores since the DMAs of the chunk about to be acquired were issued (two acquire calls back)
-  int hist = 0, cur = 0;
-  auto issue = [&]() {
+  // ---- weight ring -----------------------------------------------------------------------------------
+  // Chunk g lives in slot g % 4.  acquire() -- at step 8 of chunk g - 1 -- makes chunk g readable (every wave
+  // waits for its own eight DMA pieces of it, then the barrier) and arms the pieces of chunk g + 2 for the
+  // slot every wave has left (that of chunk g - 2); they are issued one per step in steps 8..15.  The stream
+  // simply runs on past the last tile (positions wrap: valid memory, never read; drained before the exit),
+  // so the counts are constants.
+  int i_pos = 0, i_slot = 0;              // issue side: stream position, slot
+  int a_slot = 0;
+  int s_cnt = 0;                          // counted (asm) stores since the last acquire
+  unsigned dma_dst = 0, dma_off = 0;      // armed pieces
+  bool dma_on = false;
+  auto arm = [&]() {
+    dma_on = true;
 #ifdef SPR_XENC_STAMP
-    if (g_iss < total && !(stamp_on & 2)) {      // ablation: no weight DMA (garbage results)
-#else
-    if (g_iss < total) {
+    if (stamp_on & 2) dma_on = false;     // ablation: no weight DMA (garbage results)
 #endif
-      const unsigned dst = __builtin_amdgcn_readfirstlane(ring_s + (unsigned)i_slot * XCHUNK + (unsigned)wave * (XDMA * 1024));
-      const unsigned off = (unsigned)i_pos * XCHUNK + (unsigned)wave * (XDMA * 1024) + (unsigned)lane * 16;
-#pragma unroll
-      for (int i = 0; i < XDMA; ++i) dma16(c.w, off + i * 1024, dst + i * 1024);
-    }
-    ++g_iss;
+    dma_dst = __builtin_amdgcn_readfirstlane(ring_s + (unsigned)i_slot * XCHUNK + (unsigned)wave * (XDMA * 1024));
+    dma_off = (unsigned)i_pos * XCHUNK + (unsigned)wave * (XDMA * 1024) + (unsigned)lane * 16;
     if (++i_pos == nch) i_pos = 0;
     if (++i_slot == XSLOTS) i_slot = 0;
   };
-  // Makes chunk g_acq readable and returns its slot.  Called at step 8 of chunk g_acq - 1: every wave has
-  // then left chunk g_acq - 2, whose slot is refilled with chunk g_acq + XAHEAD.  Beyond the end of the
-  // stream: returns `fallback` (its fragments are read and never used).
-  auto acquire = [&](const unsigned char* fallback) -> const unsigned char* {
-    if (g_acq >= total) return fallback;
-    // vector-memory operations younger than the DMAs of chunk g_acq (issued two acquire calls ago): the DMAs
-    // of chunk g_acq + 1 and the counted stores since.  An under-count only waits longer; an over-count would
-    // read a chunk that has not landed -- stores are counted only when they are certain to issue.
-    int n = (g_acq + 1 < total ? XDMA : 0) + hist + cur;
-    n = n < 60 ? (n & ~3) : 60;
-    wait_vm_any(n);
+  auto piece = [&](int j) __attribute__((always_inline)) {
+    if (dma_on) dma16(c.w, dma_off + j * 1024, dma_dst + j * 1024);
+  };
+  auto acquire = [&]() __attribute__((always_inline)) -> const unsigned char* {
+    // younger than the last piece of chunk g_acq: the eight pieces of chunk g_acq + 1 and the counted stores
+    // since the previous acquire (rounded DOWN: an under-count only waits longer)
+    if (s_cnt >= 32) wait_vm<40>();
+    else if (s_cnt >= 4) wait_vm<12>();
+    else wait_vm<8>();
 #ifdef SPR_XENC_STAMP
-    if (!(stamp_on & 4))                          // ablation: no barrier (garbage results)
+    if (!(stamp_on & 4))                  // ablation: no barrier (garbage results)
 #endif
     __builtin_amdgcn_s_barrier();
-    issue();
-    hist = cur;
-    cur = 0;
+    arm();
+    s_cnt = 0;
     const unsigned char* p = ring + a_slot * XCHUNK;
-    ++g_acq;
     if (++a_slot == XSLOTS) a_slot = 0;
     return p;
   };
+  // first tile; staggered start
+  if (tid == 0) s_tile[0] = atomicAdd(tile_ctr, 1);
+  __syncthreads();
+  int tile = s_tile[0];
+  if (tile >= ntiles) return;
+  // prologue: chunks 0, 1, 2 in flight, chunk 0 acquired, its first fragments read
 #pragma unroll 1
-  for (int i = 0; i < XAHEAD; ++i) issue();
-  Carry cy;
-  const unsigned char* slot = acquire(ring);
-  if (total > 0) {
+  for (int q = 0; q < 3; ++q) {
+    arm();
 #pragma unroll
-    for (int i = 0; i < 3; ++i) frag_ld(slot, lane, i, cy.h[i], cy.l[i]);
+    for (int j = 0; j < XDMA; ++j) piece(j);
   }
-  auto acq = [&]() __attribute__((always_inline)) { return acquire(slot); };
-
-  // tile operands, prefetched one tile ahead (volatile batches, see load_c)
-  f32x16 t_o[8], t_x[8], t_p[8];
-  auto tok_of = [&](int it) {
-    const int tok = ((int)blockIdx.x + it * (int)gridDim.x) * XTOK + wave * 32 + r;
-    return tok < T ? tok : T - 1;
+  dma_on = false;
+  Carry cy;
+  const unsigned char* slot = ring;
+  wait_vm<16>();
+  __builtin_amdgcn_s_barrier();
+  a_slot = 1;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) frag_ld(slot, lane, i, cy.h[i], cy.l[i]);
+  // chunk with accumulator `acc`, B operand planes xh / xl (one fragment per step), side slices side(0..31)
+  auto chunk_f = [&](f32x16& acc, const f16x8 (&xh)[16], const f16x8 (&xl)[16], auto&& side)
+      __attribute__((always_inline)) {
+    const unsigned char* nxt = slot;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i == 8) nxt = acquire();
+      acc = mfma1(cy.l[i & 3], xh[i], acc);
+      XSB();
+      side(2 * i);
+      XSB();
+      acc = mfma1(cy.h[i & 3], xl[i], acc);
+      XSB();
+      side(2 * i + 1);
+      XSB();
+      acc = mfma1(cy.h[i & 3], xh[i], acc);
+      XSB();
+      if (i + 3 < 16) frag_ld(slot, lane, i + 3, cy.h[(i + 3) & 3], cy.l[(i + 3) & 3]);
+      else frag_ld(nxt, lane, i + 3 - 16, cy.h[(i + 3) & 3], cy.l[(i + 3) & 3]);
+      if (i >= 8) piece(i - 8);
+      XSB();
+    }
+    slot = nxt;
   };
-  // Register budget (512 per lane): planes 128 + accumulator tile 128 + ONE prefetched tile 128 + fragment
-  // ring 32 + epilogue temporaries; so o is fetched under the previous tile's in-projection, x under the
-  // out-projection, pos (and, behind the feed-forward block, x' again: it is parked in x_out) when the
-  // planes die.
-  if (my_tiles > 0) {
-    if constexpr (HEAD) load_c(o_g, tok_of(0), h, t_o);
-    else load_c(x_g, tok_of(0), h, t_x);
-  }
+  // linear2 chunk: y[i >> 1] += W2 fragment(i) . hidden k-step (i & 1)
+  auto chunk_g = [&](f32x16 (&y)[8], const f16x8 (&hh)[2], const f16x8 (&hl)[2], auto&& side)
+      __attribute__((always_inline)) {
+    const unsigned char* nxt = slot;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i == 8) nxt = acquire();
+      y[i >> 1] = mfma1(cy.l[i & 3], hh[i & 1], y[i >> 1]);
+      XSB();
+      side(2 * i);
+      XSB();
+      y[i >> 1] = mfma1(cy.h[i & 3], hl[i & 1], y[i >> 1]);
+      XSB();
+      side(2 * i + 1);
+      XSB();
+      y[i >> 1] = mfma1(cy.h[i & 3], hh[i & 1], y[i >> 1]);
+      XSB();
+      if (i + 3 < 16) frag_ld(slot, lane, i + 3, cy.h[(i + 3) & 3], cy.l[(i + 3) & 3]);
+      else frag_ld(nxt, lane, i + 3 - 16, cy.h[(i + 3) & 3], cy.l[(i + 3) & 3]);
+      if (i >= 8) piece(i - 8);
+      XSB();
+    }
+    slot = nxt;
+  };
+  auto no_side = [](int) __attribute__((always_inline)) {};
+  // accumulator <- bias table block (scaled), one group of four per call (g = 0..3)
+  auto bias_group = [&](f32x16& a, const float* tb, float sc, int g) __attribute__((always_inline)) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(tb + 8 * g + 4 * h);
+    a[4 * g + 0] = t[0] * sc;
+    a[4 * g + 1] = t[1] * sc;
+    a[4 * g + 2] = t[2] * sc;
+    a[4 * g + 3] = t[3] * sc;
+  };
 
 #pragma unroll 1
-  for (int it = 0; it < my_tiles; ++it) {
-    const int tile = (int)blockIdx.x + it * (int)gridDim.x;
+  for (int it = 0; tile < ntiles; ++it) {
+    if (tid == 0) s_tile[(it + 1) & 1] = atomicAdd(tile_ctr, 1);       // the next tile (read at the end of this one)
     const int tok = tile * XTOK + wave * 32 + r;
     const bool valid = tok < T;
     const bool wave_valid = tile * XTOK + wave * 32 < T;   // lane 0 of the wave is valid: its stores do issue
     const int tokc = valid ? tok : T - 1;
-    const bool more = it + 1 < my_tiles;
     f32x16 v[8];
     f16x8 ph[16], pw[16];
     XSTAMP(0);
@@ -363,40 +400,38 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
 
     if constexpr (HEAD) {
       // ---- x' = o Wo^T + bo + x ------------------------------------------------------------------
+      load_c(o_g, tokc, h, v);
 #pragma unroll
-      for (int b = 0; b < 8; ++b) split_block(t_o[b], c.o_scale, ph[2 * b], pw[2 * b], ph[2 * b + 1], pw[2 * b + 1]);
-      load_c(x_g, tokc, h, t_x);                                          // residual: needed behind the 8 chunks
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        f32x4 t[4];
-        load_tab(tab + T_BO, b, h, t);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[b][e] = t[e >> 2][e & 3] * c.res_o;
-      }
-      XSTAMP(1);
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        slot = run_chunk(slot, lane, cy, [&](int i, const f16x8& wh, const f16x8& wl) __attribute__((always_inline)) {
-          v[b] = mfma3(wh, wl, ph[i], pw[i], v[b]);
-        }, acq);
-        if (b == 0) XSTAMP(2);
-      }
-      XSTAMP(3);
-      if constexpr (TAIL == 2 && !FFN) load_c(pos_g, tokc, h, t_p);      // planes are dead: their registers take pos
+      for (int b = 0; b < 8; ++b) split_block(v[b], c.o_scale, ph[2 * b], pw[2 * b], ph[2 * b + 1], pw[2 * b + 1]);
 #pragma unroll
       for (int b = 0; b < 8; ++b)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[b][e] = v[b][e] * c.un_o + t_x[b][e];
+        for (int g = 0; g < 4; ++g) bias_group(v[b], tab + T_BO + 32 * b, c.res_o, g);
+      XSTAMP(1);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        chunk_f(v[b], ph, pw, no_side);
+        if (b == 0) XSTAMP(2);
+      }
+      XSTAMP(3);
+      {
+        f32x16 t_x[8];
+        load_c(x_g, tokc, h, t_x);
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[b][e] = v[b][e] * c.un_o + t_x[b][e];
+      }
       store_c(xo_g, tok, h, valid, v);      // the new residual stream (FFN: parked there, re-read behind the loop)
       XSTAMP(4);
     } else {
-      if constexpr (TAIL == 2) load_c(pos_g, tokc, h, t_p);
-#pragma unroll
-      for (int b = 0; b < 8; ++b) v[b] = t_x[b];
+      load_c(x_g, tokc, h, v);
     }
 
     if constexpr (FFN) {
       // ---- x'' = x' + linear2(relu(linear1(norm3(x')))) -------------------------------------------
+      // stream order F0, F1, G0, F2, G1, ..., F(nf-1), G(nf-2), G(nf-1): the ReLU + split of hidden chunk c
+      // runs as side slices of F(c+1); two linear1 accumulators A / B alternate (nf is even)
       f32x16 y[8];
       {
         float mean, rstd;
@@ -408,42 +443,67 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
         }
       }
 #pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        f32x4 t[4];
-        load_tab(tab + T_B2, b, h, t);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) y[b][e] = t[e >> 2][e & 3] * c.res_f;
-      }
-      XSTAMP(5);
-#pragma unroll 1
-      for (int ch = 0; ch < c.nf; ++ch) {
-        if (ch == 1) XSTAMP(6);
-        if (ch == 2) XSTAMP(7);
-        f32x16 a;
-        {
-          f32x4 t[4];
-          load_tab(tab + T_B1 + 32 * ch, 0, h, t);
-#pragma unroll
-          for (int e = 0; e < 16; ++e) a[e] = t[e >> 2][e & 3] * c.bs1;
-        }
-        slot = run_chunk(slot, lane, cy, [&](int i, const f16x8& wh, const f16x8& wl) __attribute__((always_inline)) {
-          a = mfma3(wh, wl, ph[i], pw[i], a);
-        }, acq);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) a[e] = fmaxf(a[e], 0.f);
-        f16x8 hh[2], hl[2];
-        split_block(a, c.h_mul, hh[0], hl[0], hh[1], hl[1]);
-        slot = run_chunk(slot, lane, cy, [&](int i, const f16x8& wh, const f16x8& wl) __attribute__((always_inline)) {
-          y[i >> 1] = mfma3(wh, wl, hh[i & 1], hl[i & 1], y[i >> 1]);
-        }, acq);
-      }
-      XSTAMP(8);
-      load_c(xo_g, tokc, h, t_x);                                         // x' again (this lane stored it)
-      if constexpr (TAIL == 2) load_c(pos_g, tokc, h, t_p);              // planes are dead: their registers take pos
-#pragma unroll
       for (int b = 0; b < 8; ++b)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[b][e] = y[b][e] * c.un_f + t_x[b][e];
+        for (int g = 0; g < 4; ++g) bias_group(y[b], tab + T_B2 + 32 * b, c.res_f, g);
+      f32x16 A, B;
+      unsigned int hu[8], lu[8];
+      f16x8 hh[2], hl[2];
+      const float* b1t = tab + T_B1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bias_group(A, b1t, c.bs1, g);
+      XSTAMP(5);
+      // side of F(c): slices 0..7 ReLU + split of the previous accumulator P (hidden chunk c - 1), slices
+      // 8..11 re-initialise P with the bias of hidden chunk c + 1 (the table is padded past d_ff)
+      auto relu_split = [&](f32x16& P, int cnext, int s) __attribute__((always_inline)) {
+        if (s < 8) {
+          split_pk_s(fmaxf(P[2 * s], 0.f), fmaxf(P[2 * s + 1], 0.f), c.h_mul, hu[s], lu[s]);
+        } else if (s < 12) {
+          bias_group(P, b1t + 32 * cnext, c.bs1, s - 8);
+        }
+      };
+      auto pack_h = [&]() __attribute__((always_inline)) {
+        hh[0] = __builtin_bit_cast(f16x8, (u32x4){hu[0], hu[1], hu[2], hu[3]});
+        hl[0] = __builtin_bit_cast(f16x8, (u32x4){lu[0], lu[1], lu[2], lu[3]});
+        hh[1] = __builtin_bit_cast(f16x8, (u32x4){hu[4], hu[5], hu[6], hu[7]});
+        hl[1] = __builtin_bit_cast(f16x8, (u32x4){lu[4], lu[5], lu[6], lu[7]});
+      };
+      // F0 (side: bias of hidden chunk 1 into B)
+      chunk_f(A, ph, pw, [&](int s) __attribute__((always_inline)) {
+        if (s < 4) bias_group(B, b1t + 32, c.bs1, s);
+      });
+      XSTAMP(6);
+      const int npair = c.nf / 2 - 1;
+#pragma unroll 1
+      for (int j = 0; j < npair; ++j) {
+        const int c1 = 2 * j + 1;
+        chunk_f(B, ph, pw, [&](int s) __attribute__((always_inline)) { relu_split(A, c1 + 1, s); });   // F(c1), A = hidden c1-1
+        pack_h();
+        chunk_g(y, hh, hl, no_side);                                                                    // G(c1 - 1)
+        chunk_f(A, ph, pw, [&](int s) __attribute__((always_inline)) { relu_split(B, c1 + 2, s); });   // F(c1 + 1)
+        pack_h();
+        chunk_g(y, hh, hl, no_side);                                                                    // G(c1)
+        if (j == 0) XSTAMP(7);
+      }
+      {
+        const int c1 = c.nf - 1;                                                                        // last pair
+        chunk_f(B, ph, pw, [&](int s) __attribute__((always_inline)) { relu_split(A, c1 + 1, s); });
+        pack_h();
+        chunk_g(y, hh, hl, no_side);                                                                    // G(nf - 2)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) split_pk_s(fmaxf(B[2 * s], 0.f), fmaxf(B[2 * s + 1], 0.f), c.h_mul, hu[s], lu[s]);
+        pack_h();
+        chunk_g(y, hh, hl, no_side);                                                                    // G(nf - 1)
+      }
+      XSTAMP(8);
+      {
+        f32x16 t_x[8];
+        load_c(xo_g, tokc, h, t_x);                                       // x' again (this lane stored it)
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[b][e] = y[b][e] * c.un_f + t_x[b][e];
+      }
       if constexpr (TAIL != 1) store_c(xo_g, tok, h, valid, v);
       XSTAMP(9);
     }
@@ -460,6 +520,8 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
       {
         float mean, rstd;
         ln_stats(v, c.eps_tail, mean, rstd);
+        f32x16 t_p[8];
+        load_c(pos_g, tokc, h, t_p);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
           f32x16 t = ln_block(v[b], b, h, mean, rstd, tab + T_GT, tab + T_BT);
@@ -468,15 +530,7 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
           split_block(t, c.xt_scale, ph[2 * b], pw[2 * b], ph[2 * b + 1], pw[2 * b + 1]);
         }
       }
-    }
-    XSTAMP(10);
-    // ---- the next tile's operands: in flight under the in-projection ------------------------------
-    if (more) {
-      const int tn = tok_of(it + 1);
-      if constexpr (HEAD) load_c(o_g, tn, h, t_o);
-      else load_c(x_g, tn, h, t_x);
-    }
-    if constexpr (TAIL == 2) {
+      XSTAMP(10);
       int vcol = 0;
       {
         int lo = 0, hi = pl.nseg;                      // largest s with cu[s] <= tokc
@@ -486,49 +540,40 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
         }
         vcol = attn_vstart_of(cu_s[lo], lo) + tokc - cu_s[lo];
       }
-#pragma unroll 1
-      for (int fb = 0; fb < 24; ++fb) {
-        if (fb == 1) XSTAMP(11);
-        if (fb == 8) XSTAMP(12);
-        if (fb == 16) XSTAMP(13);
-        const int which = fb >> 3, head = fb & 7;     // 0 Q, 1 K, 2 V
-        f32x16 a;
-        {
-          f32x4 t[4];
-          load_tab(tab + T_BIN + 32 * fb, 0, h, t);
+      // 24 feature blocks (8 heads of Q, K, V); the epilogue of block fb - 1 (scale, split, plane stores) and
+      // the bias of block fb + 1 run as side slices of block fb; accumulators A / B alternate
+      const float* bint = tab + T_BIN;
+      f32x16 A, B;
+      unsigned int hu[8], lu[8];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) a[e] = t[e >> 2][e & 3] * c.bs_in;
-        }
-        slot = run_chunk(slot, lane, cy, [&](int i, const f16x8& wh, const f16x8& wl) __attribute__((always_inline)) {
-          a = mfma3(wh, wl, ph[i], pw[i], a);
-        }, acq);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) a[e] *= c.un_in;
-        const float pmul = which == 0 ? c.pmul[0] : (which == 1 ? c.pmul[1] : c.pmul[2]);
-        unsigned int hu[8], lu[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) split_pk_s(a[2 * i], a[2 * i + 1], pmul, hu[i], lu[i]);
-        if (which < 2) {
-          // head-major [head][token][32]: the lane's 16 features of the head as 32 contiguous bytes at
-          // d' = 16 h + e.  The order of d inside a head is free as long as Q and K agree (both
-          // are written here) -- the scores sum over it.
-          _Float16* ph_ = which == 0 ? pl.qh : pl.kh;
-          _Float16* pl_ = which == 0 ? pl.ql : pl.kl;
-          const size_t row = ((size_t)head * pl.t_total + tokc) * 32 + 16 * h;
-          if (valid) {
-            store16(ph_ + row, (u32x4){hu[0], hu[1], hu[2], hu[3]});
-            store16(ph_ + row + 8, (u32x4){hu[4], hu[5], hu[6], hu[7]});
-            store16(pl_ + row, (u32x4){lu[0], lu[1], lu[2], lu[3]});
-            store16(pl_ + row + 8, (u32x4){lu[4], lu[5], lu[6], lu[7]});
-          }
-          if (wave_valid) cur += 4;
-        } else {
-          // transposed planes [feature][token column]: one 2-byte store per feature
-          if (valid) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
+      for (int g = 0; g < 4; ++g) bias_group(A, bint, c.bs_in, g);
+      // epilogue slices of accumulator P = feature block fbp (kind WHICH: 0 Q, 1 K, 2 V), then bias of block fbn
+      auto epi = [&](auto which_tag, f32x16& P, int fbp, int fbn, int s) __attribute__((always_inline)) {
+        constexpr int WHICH = decltype(which_tag)::value;
+        const int head = fbp & 7;
+        if (s < 8) {
+          split_pk_s(P[2 * s] * c.un_in, P[2 * s + 1] * c.un_in, c.pmul[WHICH], hu[s], lu[s]);
+        } else if (s < 12) {
+          bias_group(P, bint + 32 * fbn, c.bs_in, s - 8);
+        } else if (s >= 18) {                      // stores behind the acquire of step 8 (slice 16): counted there
+          if constexpr (WHICH < 2) {
+            // head-major [head][token][32]: the lane's 16 features of the head as 32 contiguous bytes at
+            // d' = 16 h + e.  The order of d inside a head is free as long as Q and K agree (both are
+            // written here) -- the scores sum over it.
+            if (s < 22 && valid) {
+              _Float16* pb = WHICH == 0 ? (s < 20 ? pl.qh : pl.ql) : (s < 20 ? pl.kh : pl.kl);
+              const size_t row = ((size_t)head * pl.t_total + tokc) * 32 + 16 * h + 8 * (s & 1);
+              const unsigned int* src = s < 20 ? hu : lu;
+              const int o4 = 4 * (s & 1);
+              store16(pb + row, (u32x4){src[o4], src[o4 + 1], src[o4 + 2], src[o4 + 3]});
+            }
+          } else {
+            // transposed planes [feature][token column]: one 2-byte store per feature; slices 18..25 take
+            // one register pair each (features f, f + 1 of both planes)
+            if (s < 26 && valid) {
+              const int i = s - 18;
               const int e = 2 * i;
-              const int f = head * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;     // feature of register e (e + 1: f + 1)
+              const int f = head * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
               const size_t o0 = (size_t)f * pl.tp + vcol;
               store2(pl.vth + o0, hu[i]);
               store2hi(pl.vth + o0 + pl.tp, hu[i]);
@@ -536,12 +581,40 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
               store2hi(pl.vtl + o0 + pl.tp, lu[i]);
             }
           }
-          if (wave_valid) cur += 32;
         }
-      }
+      };
+      auto count = [&](int which) __attribute__((always_inline)) {
+        if (wave_valid) s_cnt += which < 2 ? 4 : 32;
+      };
+      // block 0 (side: bias of block 1 into B)
+      chunk_f(A, ph, pw, [&](int s) __attribute__((always_inline)) {
+        if (s < 4) bias_group(B, bint + 32, c.bs_in, s);
+      });
+      XSTAMP(11);
+      auto pair = [&](auto which_tag, int fb) __attribute__((always_inline)) {   // blocks fb (odd, into B) and fb + 1 (into A)
+        chunk_f(B, ph, pw, [&](int s) __attribute__((always_inline)) { epi(which_tag, A, fb - 1, fb + 1, s); });
+        count(decltype(which_tag)::value);
+        chunk_f(A, ph, pw, [&](int s) __attribute__((always_inline)) { epi(which_tag, B, fb, fb + 2, s); });
+        count(decltype(which_tag)::value);
+      };
+#pragma unroll 1
+      for (int fb = 1; fb < 8; fb += 2) pair(std::integral_constant<int, 0>{}, fb);     // epilogues of blocks 0..7 (Q)
+      XSTAMP(12);
+#pragma unroll 1
+      for (int fb = 9; fb < 16; fb += 2) pair(std::integral_constant<int, 1>{}, fb);    // blocks 8..15 (K)
+      XSTAMP(13);
+#pragma unroll 1
+      for (int fb = 17; fb < 22; fb += 2) pair(std::integral_constant<int, 2>{}, fb);   // blocks 16..21 (V)
+      chunk_f(B, ph, pw, [&](int s) __attribute__((always_inline)) { epi(std::integral_constant<int, 2>{}, A, 22, 23, s); });
+      count(2);
+#pragma unroll
+      for (int s = 0; s < 32; ++s) epi(std::integral_constant<int, 2>{}, B, 23, 23, s);   // last block: nothing to hide behind
+      count(2);
       XSTAMP(14);
     }
+    tile = s_tile[(it + 1) & 1];   // written before this tile's first barrier: ordered by the barriers since
   }
+  wait_vm<0>();   // the chunks issued past the end of the stream must have landed before the LDS is released
 }
 
 // ---- weight preparation ------------------------------------------------------------------------------
@@ -640,11 +713,11 @@ constexpr size_t kStatsBytes = 64 * 1024;     // stat jobs + results + plane mul
 
 template <bool HEAD, bool FFN, int TAIL>
 int launch_chain(const ChainConsts& c, const float* o, const float* x, float* xo, const float* pos, float* ln,
-                 const AttnPlanes& pl, int T, hipStream_t stream) {
+                 const AttnPlanes& pl, int T, int* tile_ctr, hipStream_t stream) {
   auto kern = k_xenc_chain<HEAD, FFN, TAIL>;
   const size_t lds = xenc_lds_bytes(32 * c.nf, pl.nseg);
-  SPR_REQUIRE(lds <= 160 * 1024, "xenc: d_ff %d with %d segments does not fit the LDS tables", 32 * c.nf, pl.nseg);
-  if (int rc = ensure_dyn_lds((const void*)kern, 160 * 1024)) return rc;
+  SPR_REQUIRE(lds + 64 <= 160 * 1024, "xenc: d_ff %d with %d segments does not fit the LDS tables", 32 * c.nf, pl.nseg);
+  if (int rc = ensure_dyn_lds((const void*)kern, 160 * 1024 - 64)) return rc;
   const int ntiles = cdiv(T, XTOK);
   int grid = device_cu_count();
   grid = grid < ntiles ? grid : ntiles;
@@ -659,7 +732,7 @@ int launch_chain(const ChainConsts& c, const float* o, const float* x, float* xo
     if (ea != nullptr) stamp_on |= atoi(ea) & 6;
   }
 #endif
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, c, o, x, xo, pos, ln, pl, T, ntiles, stamp_on);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, c, o, x, xo, pos, ln, pl, T, ntiles, tile_ctr, stamp_on);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -670,7 +743,7 @@ int launch_chain(const ChainConsts& c, const float* o, const float* x, float* xo
 using namespace spr;
 
 extern "C" size_t spr_xenc_prepared_bytes(int n_layers, int d_ff) {
-  if (n_layers < 1 || n_layers > kMaxLayers || d_ff < 32 || d_ff % 32 != 0) return 0;
+  if (n_layers < 1 || n_layers > kMaxLayers || d_ff < 64 || d_ff % 64 != 0) return 0;
   return kStatsBytes + stream_chunks(n_layers, d_ff / 32) * (size_t)XCHUNK;
 }
 
@@ -686,8 +759,8 @@ extern "C" int spr_xenc_prepare(const void* const* layer_ptrs_host, const float*
                                 size_t plan_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(d_model == XD && nhead == 8, "xenc: d_model must be 256 with 8 heads (got %d, %d)", d_model, nhead);
-  SPR_REQUIRE(n_layers >= 1 && n_layers <= kMaxLayers && d_ff >= 32 && d_ff % 32 == 0,
-              "xenc: bad n_layers / d_ff (%d, %d)", n_layers, d_ff);
+  SPR_REQUIRE(n_layers >= 1 && n_layers <= kMaxLayers && d_ff >= 64 && d_ff % 64 == 0,
+              "xenc: bad n_layers / d_ff (%d, %d): d_ff must be a multiple of 64", n_layers, d_ff);
   SPR_REQUIRE(layer_ptrs_host && eps_host && prepared && plan_host, "xenc_prepare: null argument");
   SPR_REQUIRE(prepared_bytes >= spr_xenc_prepared_bytes(n_layers, d_ff) && plan_bytes >= sizeof(Plan),
               "xenc_prepare: buffers too small");
@@ -866,8 +939,13 @@ extern "C" int spr_xenc_prepare(const void* const* layer_ptrs_host, const float*
       c.h_mul = pow2f(kh - kx2 - kw1);
       c.res_f = pow2f(kh + kw2);
       c.un_f = pow2f(-kh - kw2);
-      if (int rc = prep_f(P(l, W1), XD, nf, kw1, (int)chunk_at + 8, 2)) return rc;
-      if (int rc = prep_g(P(l, W2), d_ff, nf, kw2, (int)chunk_at + 9, 2)) return rc;
+      // stream order F0, F1, G0, F2, G1, ..., F(nf-1), G(nf-2), G(nf-1)  (k_xenc_chain, feed-forward block)
+      const int fbase = (int)chunk_at + 8;
+      if (int rc = prep_f(P(l, W1), XD, 1, kw1, fbase, 1)) return rc;                                    // F0
+      if (int rc = prep_f(P(l, W1) + (size_t)32 * XD, XD, nf - 1, kw1, fbase + 1, 2)) return rc;          // F(c) at 2c - 1
+      if (nf > 1)
+        if (int rc = prep_g(P(l, W2), d_ff, nf - 1, kw2, fbase + 2, 2)) return rc;                        // G(c) at 2c + 2
+      if (int rc = prep_g(P(l, W2) + (size_t)32 * (nf - 1), d_ff, 1, kw2, fbase + 2 * nf - 1, 1)) return rc;   // G(nf-1)
       if (l + 1 < n_layers) {
         if (int rc = setup_inproj(c, l + 1, 0, 3, P(l + 1, SA_W), P(l + 1, SA_B), P(l + 1, N1G), P(l + 1, N1B),
                                   eps_host[3 * (l + 1)], amax(l + 1, 17), amax(l + 1, 18),
@@ -908,7 +986,7 @@ extern "C" int spr_xenc_debug_stamps(unsigned long long* out_host, int clear) {
 
 extern "C" size_t spr_xenc_workspace_bytes(int t, int nseg) {
   if (t < 1 || nseg < 1) return 0;
-  return spr_attn_workspace_bytes(t, nseg, 8, 32) + 3 * align_up((size_t)t * XD * sizeof(float), 256);
+  return spr_attn_workspace_bytes(t, nseg, 8, 32) + 3 * align_up((size_t)t * XD * sizeof(float), 256) + 1024;
 }
 
 // x [t, 256] tokens of all clouds (packed), pos [t, 256] positional embedding, cu [nseg + 1],
@@ -937,27 +1015,29 @@ extern "C" int spr_xenc_forward(const void* plan_host, const float* x, const flo
   float* obuf = (float*)((char*)ws + planes_bytes);
   float* xa = (float*)((char*)ws + planes_bytes + act);
   float* xb = (float*)((char*)ws + planes_bytes + 2 * act);
+  int* ctr = (int*)((char*)ws + planes_bytes + 3 * act);      // one tile counter per chain launch
+  SPR_HIP_CHECK(hipMemsetAsync(ctr, 0, 1024, stream));
   if (int rc = attn_zero_gaps(pl, XD, stream)) return rc;
   const int L = plan->n_layers;
-  if (int rc = launch_chain<false, false, 2>(plan->prologue, nullptr, x, nullptr, pos, nullptr, pl, t, stream)) return rc;
+  if (int rc = launch_chain<false, false, 2>(plan->prologue, nullptr, x, nullptr, pos, nullptr, pl, t, ctr++, stream)) return rc;
   const float* cur = x;
   float* nxt = xa;
   for (int l = 0; l < L; ++l) {
     pl.scales = plan->scales_self[l];
     if (int rc = attn_core_on_planes(pl, kv_self, max_len_host, 8, obuf, XD, mode, stream)) return rc;
-    if (int rc = launch_chain<true, false, 2>(plan->a[l], obuf, cur, nxt, pos, nullptr, pl, t, stream)) return rc;
+    if (int rc = launch_chain<true, false, 2>(plan->a[l], obuf, cur, nxt, pos, nullptr, pl, t, ctr++, stream)) return rc;
     cur = nxt;
     nxt = (nxt == xa) ? xb : xa;
     pl.scales = plan->scales_cross[l];
     if (int rc = attn_core_on_planes(pl, kv_cross, max_len_host, 8, obuf, XD, mode, stream)) return rc;
     if (l + 1 < L) {
-      if (int rc = launch_chain<true, true, 2>(plan->b[l], obuf, cur, nxt, pos, nullptr, pl, t, stream)) return rc;
+      if (int rc = launch_chain<true, true, 2>(plan->b[l], obuf, cur, nxt, pos, nullptr, pl, t, ctr++, stream)) return rc;
       cur = nxt;
       nxt = (nxt == xa) ? xb : xa;
     } else if (plan->has_final) {
-      if (int rc = launch_chain<true, true, 1>(plan->b[l], obuf, cur, nxt, pos, out, pl, t, stream)) return rc;
+      if (int rc = launch_chain<true, true, 1>(plan->b[l], obuf, cur, nxt, pos, out, pl, t, ctr++, stream)) return rc;
     } else {
-      if (int rc = launch_chain<true, true, 0>(plan->b[l], obuf, cur, out, pos, nullptr, pl, t, stream)) return rc;
+      if (int rc = launch_chain<true, true, 0>(plan->b[l], obuf, cur, out, pos, nullptr, pl, t, ctr++, stream)) return rc;
     }
   }
   return 0;

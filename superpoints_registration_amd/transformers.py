@@ -200,7 +200,7 @@ class TransformerCrossEncoder(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False                                  # training: the differentiable per-operator route
         return all(l.normalize_before and l.sa_val_has_pos_emb and l.ca_val_has_pos_emb and l.nhead == 8
-                   and l.linear1.out_features % 32 == 0 for l in self.layers)
+                   and l.linear1.out_features % 64 == 0 for l in self.layers)
 
     def _xenc_plan(self, pos_bound: float):
         lp, le = [], []
