@@ -808,12 +808,15 @@ extern "C" size_t spr_sinkhorn_workspace_bytes(const int* cu_host, int npairs) {
 namespace {
 // Fills the scratch with raw correlations F_s F_t^T (unscaled), one MFMA GEMM
 // per pair; uploads the pair descriptors.
+// per_group: the running tile count restarts every per_group pairs (the correlation GEMM is launched once per
+// group of pairs, see correlate)
 __global__ void k_build_pairs(const int* __restrict__ cu, int npairs, PairDesc* pd, GemmGroup* gg, int d,
-                              int bm, int bn) {
+                              int bm, int bn, int per_group) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   long long off = 0;
   int tiles = 0;
   for (int b = 0; b < npairs; ++b) {
+    if (b % per_group == 0) tiles = 0;
     PairDesc p;
     p.src_beg = cu[b];
     p.n = cu[b + 1] - cu[b];
@@ -838,39 +841,69 @@ __global__ void k_build_pairs(const int* __restrict__ cu, int npairs, PairDesc* 
   }
 }
 
-// epi_mode / epi: optional elementwise epilogue of the grouped GEMM (kEpiScale, kEpiAffinity;
-// parameters on the device); *epi_applied tells the caller whether it ran (split-fp16 mode) or
-// the separate pass over the matrix is still needed (exact-f32 mode: one GEMM per pair).
-int correlate(const float* feat, int d, const int* cu_dev, const int* cu_host, int npairs, Workspace& w,
-              float** mat_out, PairDesc** pd_out, std::vector<PairDesc>& h, long long* total,
-              int* max_n, int* max_m, hipStream_t stream, int epi_mode = 0, const float* epi = nullptr,
-              bool* epi_applied = nullptr) {
-  if (epi_applied) *epi_applied = false;
-  h.resize(npairs);
-  build_pairs(cu_host, npairs, h.data(), total);
-  float* mat = w.take<float>((size_t)*total);
-  PairDesc* pd = w.take<PairDesc>(npairs);
-  SPR_REQUIRE(mat && pd, "match: workspace carve failed");
-  // descriptors are rebuilt on the device from cu (no pageable host copy)
-  *max_n = 0;
-  *max_m = 0;
+// Correlation matrices of all pairs, produced and consumed GROUP BY GROUP: the score matrices of the bench's 32
+// pairs are 477 MB and every softmax / Sinkhorn pass swept all of them from HBM (nine to thirteen sweeps per
+// forward); the matrices of a group are written by their GEMM and read by all their passes while (mostly) still in
+// the 256 MB Infinity Cache.  Group budget 250 MB = 16 of the bench's pairs (measured: 96 MB groups leave the chip
+// under-filled -- 3.9 ms of matching kernels per forward; 250 MB: 2.6 ms; one group of 477 MB: 3.0 ms).  corr_setup builds the descriptors of all pairs, corr_gemm launches the
+// product of one group.
+// epi_mode / epi: optional elementwise epilogue of the grouped GEMM (kEpiScale, kEpiAffinity; parameters on the
+// device); applied = whether it ran (split-fp16 mode) or the separate pass over the matrix is still needed
+// (exact-f32 mode: one GEMM per pair).
+struct Corr {
+  const float* feat;
+  int d, npairs;
+  float* mat;
+  PairDesc* pd;
+  GemmGroup* gg;
+  std::vector<PairDesc> h;
+  long long total;
+  int max_n, max_m, per_group, ngroups;
+  bool grouped;
+  const float *sparts, *tparts;
+  int first(int g) const { return g * per_group; }
+  int count(int g) const { return (g + 1) * per_group <= npairs ? per_group : npairs - g * per_group; }
+  // element range of group g inside mat
+  long long beg(int g) const { return h[first(g)].off; }
+  long long end(int g) const {
+    const int l = first(g) + count(g) - 1;
+    return l + 1 < npairs ? h[l + 1].off : total;
+  }
+};
+int corr_setup(Corr& c, const float* feat, int d, const int* cu_dev, const int* cu_host, int npairs, Workspace& w,
+               hipStream_t stream, bool one_group) {
+  c.feat = feat;
+  c.d = d;
+  c.npairs = npairs;
+  c.h.resize(npairs);
+  build_pairs(cu_host, npairs, c.h.data(), &c.total);
+  c.mat = w.take<float>((size_t)c.total);
+  c.pd = w.take<PairDesc>(npairs);
+  SPR_REQUIRE(c.mat && c.pd, "match: workspace carve failed");
+  c.max_n = 0;
+  c.max_m = 0;
   for (int b = 0; b < npairs; ++b) {
-    SPR_REQUIRE(h[b].n > 0 && h[b].m > 0, "match: empty cloud in pair %d", b);
-    *max_n = h[b].n > *max_n ? h[b].n : *max_n;
-    *max_m = h[b].m > *max_m ? h[b].m : *max_m;
+    SPR_REQUIRE(c.h[b].n > 0 && c.h[b].m > 0, "match: empty cloud in pair %d", b);
+    c.max_n = c.h[b].n > c.max_n ? c.h[b].n : c.max_n;
+    c.max_m = c.h[b].m > c.max_m ? c.h[b].m : c.max_m;
   }
-  const bool grouped = gemm_mode() == 1 && d % 32 == 0;
-  GemmGroup* gg = nullptr;
-  int bm = 1, bn = 1, total_tiles = 0;
-  if (grouped) {
-    gg = w.take<GemmGroup>(npairs);
-    SPR_REQUIRE(gg != nullptr, "match: workspace carve failed");
-    gemm_group_tile(*max_m, &bm, &bn);
-    for (int b = 0; b < npairs; ++b) total_tiles += cdiv(h[b].n, bm) * cdiv(h[b].m, bn);
+  static const long long budget = [] { const char* e = getenv("SPR_MATCH_GROUP_MB"); return (long long)(e ? atoi(e) : 250) << 20; }();
+  const long long pair_bytes = (long long)c.max_n * c.max_m * 4;
+  long long g = pair_bytes > 0 ? budget / pair_bytes : npairs;
+  c.per_group = one_group ? npairs : (int)(g < 1 ? 1 : (g > npairs ? npairs : g));
+  c.ngroups = cdiv(npairs, c.per_group);
+  c.grouped = gemm_mode() == 1 && d % 32 == 0;
+  c.gg = nullptr;
+  int bm = 1, bn = 1;
+  if (c.grouped) {
+    c.gg = w.take<GemmGroup>(npairs);
+    SPR_REQUIRE(c.gg != nullptr, "match: workspace carve failed");
+    gemm_group_tile(c.max_m, &bm, &bn);
   }
-  hipLaunchKernelGGL(k_build_pairs, dim3(1), dim3(64), 0, stream, cu_dev, npairs, pd, gg, d, bm, bn);
+  // descriptors are rebuilt on the device from cu (no pageable host copy)
+  hipLaunchKernelGGL(k_build_pairs, dim3(1), dim3(64), 0, stream, cu_dev, npairs, c.pd, c.gg, d, bm, bn, c.per_group);
   // two range measurements serve every pair: all src tokens (A operands), all tgt tokens (B)
-  const float *sparts = nullptr, *tparts = nullptr;
+  c.sparts = c.tparts = nullptr;
   if (gemm_mode() == 1) {
     float* ps = w.take<float>(kAmaxParts);
     float* pt = w.take<float>(kAmaxParts);
@@ -878,23 +911,30 @@ int correlate(const float* feat, int d, const int* cu_dev, const int* cu_host, i
     const int nsrc = cu_host[npairs], ntot = cu_host[2 * npairs];
     if (int rc = launch_absmax2(feat, nsrc, d, d, ps, feat + (size_t)nsrc * d, ntot - nsrc, d, d, pt, stream))
       return rc;
-    sparts = ps;
-    tparts = pt;
+    c.sparts = ps;
+    c.tparts = pt;
   }
-  if (grouped) {
-    // one launch for all pairs: a 1 930 x 1 930 x 256 product alone is 64 tiles of 256 x 256,
-    // a quarter of the chip, and pays the full pipeline latency of a tile
-    if (launch_gemm_grouped(feat, d, feat, mat, gg, total_tiles, *max_m, sparts, tparts, epi_mode, epi, stream))
+  return 0;
+}
+int corr_gemm(const Corr& c, int g, int epi_mode, const float* epi, hipStream_t stream, bool* applied) {
+  if (applied) *applied = false;
+  const int p0 = c.first(g), np = c.count(g);
+  if (c.grouped) {
+    int bm, bn, tiles = 0;
+    gemm_group_tile(c.max_m, &bm, &bn);
+    for (int b = p0; b < p0 + np; ++b) tiles += cdiv(c.h[b].n, bm) * cdiv(c.h[b].m, bn);
+    // one launch for the group: a 1 930 x 1 930 x 256 product alone is 64 tiles of 256 x 256, a quarter of the chip
+    if (launch_gemm_grouped(c.feat, c.d, c.feat, c.mat, c.gg + p0, tiles, c.max_m, c.sparts, c.tparts, epi_mode, epi,
+                            stream))
       return 1;
-    if (epi_applied) *epi_applied = epi_mode != 0;
+    if (applied) *applied = epi_mode != 0;
   } else {
-    for (int b = 0; b < npairs; ++b)
-      if (launch_linear_ranged(feat + (size_t)h[b].src_beg * d, h[b].n, d, feat + (size_t)h[b].tgt_beg * d,
-                               h[b].m, nullptr, mat + h[b].off, sparts, tparts, stream))
+    for (int b = p0; b < p0 + np; ++b)
+      if (launch_linear_ranged(c.feat + (size_t)c.h[b].src_beg * c.d, c.h[b].n, c.d,
+                               c.feat + (size_t)c.h[b].tgt_beg * c.d, c.h[b].m, nullptr, c.mat + c.h[b].off, c.sparts,
+                               c.tparts, stream))
         return 1;
   }
-  *mat_out = mat;
-  *pd_out = pd;
   return 0;
 }
 }  // namespace
@@ -906,33 +946,35 @@ extern "C" int spr_match_dualsoftmax2(const float* feat, int d, const int* cu, c
   SPR_REQUIRE(npairs >= 1 && d % 32 == 0, "match: need npairs >= 1 and d %% 32 == 0");
   SPR_REQUIRE(ws_bytes >= match_ws_bytes(cu_host, npairs), "match: workspace too small");
   Workspace w(ws, ws_bytes);
-  float* mat;
-  PairDesc* pd;
-  std::vector<PairDesc> h;
-  long long total;
-  int max_n, max_m;
   const float scale = 1.0f / sqrtf((float)d);
   float* epi = w.take<float>(4);
   SPR_REQUIRE(epi != nullptr, "match: workspace carve failed");
   hipLaunchKernelGGL(k_epi_params, dim3(1), dim3(64), 0, stream, scale, (const float*)nullptr,
                      (const float*)nullptr, epi);
-  bool scaled = false;
-  if (correlate(feat, d, cu, cu_host, npairs, w, &mat, &pd, h, &total, &max_n, &max_m, stream, kEpiScale, epi,
-                &scaled))
-    return 1;
+  Corr c;
+  if (corr_setup(c, feat, d, cu, cu_host, npairs, w, stream, false)) return 1;
   const int T = cu_host[2 * npairs];
   float* row_lse = w.take<float>(T);
   float* col_lse = w.take<float>(T);
   SPR_REQUIRE(col_lse != nullptr, "match: workspace carve failed");
-  if (!scaled) hipLaunchKernelGGL(k_scale, dim3(cdiv(total, 256)), dim3(256), 0, stream, mat, total, scale);
-  hipLaunchKernelGGL(k_row_lse, dim3(cdiv((long)max_n * 64, 256), npairs), dim3(256), 0, stream, mat,
-                     pd, row_lse, (const float*)nullptr, 0);
-  hipLaunchKernelGGL(k_col_lse, dim3(cdiv(max_m, 64), npairs), dim3(1024), 0, stream, mat, pd, col_lse,
-                     (const float*)nullptr, 0);
-  hipLaunchKernelGGL(k_match_cols, dim3(cdiv(max_m, 64), npairs), dim3(1024), 0, stream, mat, pd,
-                     row_lse, col_lse, match_val, match_ind, match_val2);
-  hipLaunchKernelGGL(k_match_rows, dim3(cdiv((long)max_n * 64, 256), npairs), dim3(256), 0, stream,
-                     mat, pd, row_lse, col_lse, match_val, match_ind, match_val2);
+  for (int g = 0; g < c.ngroups; ++g) {
+    bool scaled = false;
+    if (corr_gemm(c, g, kEpiScale, epi, stream, &scaled)) return 1;
+    const int np = c.count(g);
+    PairDesc* pg = c.pd + c.first(g);
+    if (!scaled) {
+      const long long cnt = c.end(g) - c.beg(g);
+      hipLaunchKernelGGL(k_scale, dim3(cdiv(cnt, 256)), dim3(256), 0, stream, c.mat + c.beg(g), cnt, scale);
+    }
+    hipLaunchKernelGGL(k_row_lse, dim3(cdiv((long)c.max_n * 64, 256), np), dim3(256), 0, stream, c.mat, pg, row_lse,
+                       (const float*)nullptr, 0);
+    hipLaunchKernelGGL(k_col_lse, dim3(cdiv(c.max_m, 64), np), dim3(1024), 0, stream, c.mat, pg, col_lse,
+                       (const float*)nullptr, 0);
+    hipLaunchKernelGGL(k_match_cols, dim3(cdiv(c.max_m, 64), np), dim3(1024), 0, stream, c.mat, pg, row_lse, col_lse,
+                       match_val, match_ind, match_val2);
+    hipLaunchKernelGGL(k_match_rows, dim3(cdiv((long)c.max_n * 64, 256), np), dim3(256), 0, stream, c.mat, pg, row_lse,
+                       col_lse, match_val, match_ind, match_val2);
+  }
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -972,36 +1014,37 @@ extern "C" int spr_sinkhorn_correspondences(const float* feat, int d, const floa
   SPR_REQUIRE(npairs >= 1 && d % 32 == 0 && n_iters >= 0, "sinkhorn: bad arguments");
   SPR_REQUIRE(ws_bytes >= match_ws_bytes(cu_host, npairs), "sinkhorn: workspace too small");
   Workspace w(ws, ws_bytes);
-  float* mat;
-  PairDesc* pd;
-  std::vector<PairDesc> h;
-  long long total;
-  int max_n, max_m;
   const float scale = 1.0f / sqrtf((float)d);
   SPR_REQUIRE(alpha != nullptr && beta != nullptr, "sinkhorn: alpha / beta must be device pointers");
   float* epi = w.take<float>(4);
   SPR_REQUIRE(epi != nullptr, "sinkhorn: workspace carve failed");
   hipLaunchKernelGGL(k_epi_params, dim3(1), dim3(64), 0, stream, scale, alpha, beta, epi);
-  bool fused = false;
-  if (correlate(feat, d, cu, cu_host, npairs, w, &mat, &pd, h, &total, &max_n, &max_m, stream, kEpiAffinity, epi,
-                &fused))
-    return 1;
+  Corr c;
+  if (corr_setup(c, feat, d, cu, cu_host, npairs, w, stream, false)) return 1;
   const int T = cu_host[2 * npairs];
   float* u = w.take<float>(T);
   float* v = w.take<float>(T);
   SPR_REQUIRE(v != nullptr, "sinkhorn: workspace carve failed");
-  if (!fused)
-    hipLaunchKernelGGL(k_affinity, dim3(cdiv(total, 256)), dim3(256), 0, stream, mat, total, scale, alpha, beta);
   SPR_HIP_CHECK(hipMemsetAsync(u, 0, sizeof(float) * T, stream));
   SPR_HIP_CHECK(hipMemsetAsync(v, 0, sizeof(float) * T, stream));
-  for (int it = 0; it < n_iters; ++it) {
-    hipLaunchKernelGGL(k_row_lse, dim3(cdiv((long)max_n * 64, 256), npairs), dim3(256), 0, stream,
-                       mat, pd, u, (const float*)v, 1);
-    hipLaunchKernelGGL(k_col_lse, dim3(cdiv(max_m, 64), npairs), dim3(1024), 0, stream, mat, pd, v,
-                       (const float*)u, 1);
+  for (int g = 0; g < c.ngroups; ++g) {
+    bool fused = false;
+    if (corr_gemm(c, g, kEpiAffinity, epi, stream, &fused)) return 1;
+    const int np = c.count(g);
+    PairDesc* pg = c.pd + c.first(g);
+    if (!fused) {
+      const long long cnt = c.end(g) - c.beg(g);
+      hipLaunchKernelGGL(k_affinity, dim3(cdiv(cnt, 256)), dim3(256), 0, stream, c.mat + c.beg(g), cnt, scale, alpha,
+                         beta);
+    }
+    for (int it = 0; it < n_iters; ++it) {
+      hipLaunchKernelGGL(k_row_lse, dim3(cdiv((long)c.max_n * 64, 256), np), dim3(256), 0, stream, c.mat, pg, u,
+                         (const float*)v, 1);
+      hipLaunchKernelGGL(k_col_lse, dim3(cdiv(c.max_m, 64), np), dim3(1024), 0, stream, c.mat, pg, v, (const float*)u, 1);
+    }
+    hipLaunchKernelGGL(k_sinkhorn_final, dim3(cdiv((long)c.max_n * 64, 256), np), dim3(256), 0, stream, c.mat, pg, u, v,
+                       xyz, out_w, out_that);
   }
-  hipLaunchKernelGGL(k_sinkhorn_final, dim3(cdiv((long)max_n * 64, 256), npairs), dim3(256), 0,
-                     stream, mat, pd, u, v, xyz, out_w, out_that);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -1058,7 +1101,15 @@ extern "C" int spr_sinkhorn_bwd(const float* feat, int d, const float* xyz, cons
   std::vector<PairDesc> h;
   long long total;
   int max_n, max_m;
-  if (correlate(feat, d, cu, cu_host, npairs, w, &mat, &pd, h, &total, &max_n, &max_m, stream)) return 1;
+  Corr cc;
+  if (corr_setup(cc, feat, d, cu, cu_host, npairs, w, stream, true)) return 1;     // the backward keeps every matrix
+  if (corr_gemm(cc, 0, 0, nullptr, stream, nullptr)) return 1;
+  mat = cc.mat;
+  pd = cc.pd;
+  h = cc.h;
+  total = cc.total;
+  max_n = cc.max_n;
+  max_m = cc.max_m;
   const int T = cu_host[2 * npairs];
   float* corr = w.take<float>((size_t)total);
   float* dmat = w.take<float>((size_t)total);
