@@ -338,8 +338,8 @@ __global__ __launch_bounds__(256) void k_attn_pack(
   }
 }
 
-constexpr int QW2 = 64;    // queries per wave (two 32-query MFMA column blocks)
-constexpr int QB2 = 256;   // queries per workgroup
+constexpr int QW2 = 64;    // queries per wave (two 32-query MFMA column blocks) of the default form
+constexpr int QB2 = 256;   // queries per workgroup of the default form
 
 // max over the two half-waves (lanes l and l^32) without touching LDS
 __device__ __forceinline__ float half_swap_max(float x) {
@@ -349,8 +349,11 @@ __device__ __forceinline__ float half_swap_max(float x) {
 }
 
 // H3 = true: split-fp16 (hi + lo planes, 3 MFMAs per product); false: hi planes only.
-template <bool H3, bool LAZY = false>
-__global__ __launch_bounds__(256) void k_attn_h3(
+// NQ = 32-query blocks per wave: 2 (default: 64 queries per wave, 256 per workgroup, ~250 VGPRs, two waves per
+// SIMD) or 1 (32 queries per wave, 128 per workgroup, <= 128 VGPRs: four waves per SIMD -- the same instruction
+// stream at twice the occupancy; K / V^T fragments are then read from LDS twice as often per query).
+template <bool H3, bool LAZY = false, int NQ = 2, int WPS = (NQ == 1 ? 3 : 2)>
+__global__ __launch_bounds__(256, WPS) void k_attn_h3(
     const _Float16* __restrict__ qh_g, const _Float16* __restrict__ ql_g,
     const _Float16* __restrict__ kh_g, const _Float16* __restrict__ kl_g,
     const _Float16* __restrict__ vth_g, const _Float16* __restrict__ vtl_g, int t_total, int tp,
@@ -378,7 +381,8 @@ __global__ __launch_bounds__(256) void k_attn_h3(
     }
   }
   const int qbeg = cu[seg], qlen = cu[seg + 1] - qbeg;
-  const int q0 = qt * QB2;
+  constexpr int QWN = 32 * NQ, QBN = 4 * QWN;   // queries per wave / workgroup
+  const int q0 = qt * QBN;
   if (q0 >= qlen) return;
   const int ks = kv_seg[seg];
   const int kbeg = cu[ks], klen = cu[ks + 1] - kbeg;
@@ -390,10 +394,10 @@ __global__ __launch_bounds__(256) void k_attn_h3(
 
   // Q^T B-fragments of the wave's two 32-query blocks: lane (query l31, half
   // lh), k-step s: d = 16 s + 8 lh + j
-  h16x8 qh[2][2], ql[2][2];
+  h16x8 qh[NQ][2], ql[NQ][2];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int qi = min(q0 + wave * QW2 + 32 * h + l31, qlen - 1);
+  for (int h = 0; h < NQ; ++h) {
+    const int qi = min(q0 + wave * QWN + 32 * h + l31, qlen - 1);
     const size_t row = ((size_t)head * t_total + qbeg + qi) * HD + 8 * lh;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -402,16 +406,17 @@ __global__ __launch_bounds__(256) void k_attn_h3(
     }
   }
 
-  f32x16 o[2];
-  float m_run[2] = {-INFINITY, -INFINITY};
-  f32x2 psum2[2];   // per-lane partial row sums; the two half-waves are joined at the end
+  f32x16 o[NQ];
+  float m_run[NQ];
+  f32x2 psum2[NQ];   // per-lane partial row sums; the two half-waves are joined at the end
   // LAZY: the softmax reference m_ref of the lane's two queries rides into the score MFMAs as
   // their C operand (all 16 registers = 4 - m_ref: scores come out as s - m_ref + 4, ready for
   // exp2), and is moved -- with the accumulator rescale -- only on the first tile and when a score
   // would push a scaled probability out of fp16's range; see tile().
-  f32x16 negm[2];
+  f32x16 negm[NQ];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < NQ; ++h) {
+    m_run[h] = -INFINITY;
     psum2[h] = (f32x2){0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -448,22 +453,31 @@ __global__ __launch_bounds__(256) void k_attn_h3(
   // the shadow of the other block's MFMAs.
   auto tile = [&](int kt, int buf, auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
-    // K A-fragments (shared by both query blocks)
+    // K A-fragments (shared by both query blocks; NQ = 1: read per key sub-tile, right before its MFMAs -- the
+    // register budget of four waves per SIMD has no room for all eight at once)
     h16x8 kfh[2][2], kfl[2][2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    auto load_kf = [&](int kk) __attribute__((always_inline)) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         kfh[kk][s] = *reinterpret_cast<const h16x8*>(Kh[buf] + (32 * kk + l31) * KH + 16 * s + 8 * lh);
         if constexpr (H3)
           kfl[kk][s] = *reinterpret_cast<const h16x8*>(Kl[buf] + (32 * kk + l31) * KH + 16 * s + 8 * lh);
       }
+    };
+    if constexpr (NQ == 2) {
+      load_kf(0);
+      load_kf(1);
+    }
     // ---- S^T = K Q^T (rows = keys, cols = queries) ----
-    f32x16 sacc[2][2];
+    f32x16 sacc[NQ][2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < NQ; ++h)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
+        if constexpr (NQ == 1) {
+          if (kk == 1) __builtin_amdgcn_sched_barrier(0);
+          load_kf(kk);
+        }
         if constexpr (LAZY) {
           sacc[h][kk] = negm[h];
         } else {
@@ -479,10 +493,9 @@ __global__ __launch_bounds__(256) void k_attn_h3(
           sacc[h][kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[kk][s], qh[h][s], sacc[h][kk], 0, 0, 0);
         }
       }
-    // V^T A-fragments (shared by both query blocks)
+    // V^T A-fragments (shared by both query blocks; NQ = 1: read per key sub-tile in front of its MFMAs)
     h16x8 vfh[2][2], vfl[2][2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    auto load_vf = [&](int kk) __attribute__((always_inline)) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const _Float16* ph_ = Vth[buf] + l31 * VH + 32 * kk + 16 * s + 4 * lh;
@@ -496,8 +509,13 @@ __global__ __launch_bounds__(256) void k_attn_h3(
           vfl[kk][s] = (h16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
         }
       }
+    };
+    if constexpr (NQ == 2) {
+      load_vf(0);
+      load_vf(1);
+    }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NQ; ++h) {
       // ---- online softmax (lane = query; reg r of sub-tile kk <-> key
       //      32 kk + (r&3) + 8 (r>>2) + 4 lh) ----
       if (TAIL) {
@@ -556,7 +574,11 @@ __global__ __launch_bounds__(256) void k_attn_h3(
             }
           }
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk) {
+          if constexpr (NQ == 1) {
+            if (kk == 1) __builtin_amdgcn_sched_barrier(0);
+            load_vf(kk);
+          }
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             const u32x4 pa = {ph_u[kk][4 * s], ph_u[kk][4 * s + 1], ph_u[kk][4 * s + 2], ph_u[kk][4 * s + 3]};
@@ -569,6 +591,7 @@ __global__ __launch_bounds__(256) void k_attn_h3(
             }
             o[h] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[kk][s], pbh, o[h], 0, 0, 0);
           }
+        }
         continue;
       }
       const float m_new = fmaxf(m_run[h], mx);
@@ -648,10 +671,10 @@ __global__ __launch_bounds__(256) void k_attn_h3(
   if (kt < klen) tile(kt, buf, std::true_type{});
 
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < NQ; ++h) {
     float l_run = psum2[h][0] + psum2[h][1];
     l_run += __shfl_xor(l_run, 32, 64);
-    const int qi = q0 + wave * QW2 + 32 * h + l31;
+    const int qi = q0 + wave * QWN + 32 * h + l31;
     if (qi < qlen) {
       const float inv = (l_run > 0.f ? 1.0f / l_run : 0.f) * scales[3];   // 2^-ev undoes the V multiplier
       float* op = out + (size_t)(qbeg + qi) * o_stride + hoff;
@@ -783,8 +806,24 @@ int carve(void* ws, size_t ws_bytes, int t, int nseg, int d, size_t tp, AttnPlan
 
 int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int* kv_seg, int nseg,
                 int max_len_host, int nhead, float* out, int o_stride, int mode, hipStream_t stream) {
-  dim3 grid(cdiv(max_len_host, QB2) * nhead * nseg);
   ProfScope prof(stream, -1, t);
+  // Default since round 4: 32 queries per wave with a 168-register budget, three waves per SIMD (147 VGPRs in split
+  // mode): 927 vs 956 us per call at the bench shape, 452 vs 458 us in mode 2.  SPR_ATTN_NQ=2 selects the 64-query /
+  // two-wave form.  (Four waves per SIMD -- 118 VGPRs in mode 2, 128 with 42 spilled registers in split mode --
+  // measured 452 and 1 171 us: occupancy is not what this kernel waits for)
+  static const int nq = [] { const char* e = getenv("SPR_ATTN_NQ"); return (e != nullptr && e[0] == '2') ? 2 : 1; }();
+  if (nq == 1) {
+    dim3 grid1(cdiv(max_len_host, QB2 / 2) * nhead * nseg);
+    if (mode == 2)
+      hipLaunchKernelGGL((k_attn_h3<false, true, 1, 3>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
+                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+    else
+      hipLaunchKernelGGL((k_attn_h3<true, true, 1, 3>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
+                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+    SPR_LAUNCH_CHECK();
+    return 0;
+  }
+  dim3 grid(cdiv(max_len_host, QB2) * nhead * nseg);
   // lazy softmax reference (k_attn_h3<*, true>) unless SPR_ATTN_LAZY=0 (A/B timing against the eager form)
   static const bool lazy = [] { const char* e = getenv("SPR_ATTN_LAZY"); return e == nullptr || e[0] != '0'; }();
   if (lazy) {
@@ -929,7 +968,7 @@ extern "C" int spr_attn_inproj_varlen_fwd_r(const float* x_qk, const float* x_v,
     return spr_attn_varlen_fwd(qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, cu, kv_seg, t, nseg,
                                max_len_host, nhead, head_dim, scale, out, o_stride, ws, planes_bytes, stream_);
   }
-  SPR_REQUIRE((long)cdiv(max_len_host, QB2) * nhead * nseg < (1l << 31), "attention: grid too large");
+  SPR_REQUIRE((long)cdiv(max_len_host, QB2 / 2) * nhead * nseg < (1l << 31), "attention: grid too large");
   pl.cu = cu;
   pl.nseg = nseg;
   pl.t_total = t;
@@ -998,7 +1037,7 @@ int spr::attn_zero_gaps(const AttnPlanes& pl, int d, hipStream_t stream) {
 int spr::attn_core_on_planes(const AttnPlanes& pl, const int* kv_seg, int max_len_host, int nhead, float* out,
                              int o_stride, int mode, hipStream_t stream) {
   SPR_REQUIRE(mode == 1 || mode == 2, "attention core on planes: mode must be 1 or 2 (got %d)", mode);
-  SPR_REQUIRE((long)cdiv(max_len_host, QB2) * nhead * pl.nseg < (1l << 31), "attention: grid too large");
+  SPR_REQUIRE((long)cdiv(max_len_host, QB2 / 2) * nhead * pl.nseg < (1l << 31), "attention: grid too large");
   return launch_core(pl, pl.t_total, (size_t)pl.tp, pl.cu, kv_seg, pl.nseg, max_len_host, nhead, out, o_stride, mode,
                      stream);
 }
