@@ -954,6 +954,12 @@ __global__ __launch_bounds__(512, (RingShape<CC, COUT, NS>::MINW)) void k_kpconv
     return;
 #endif
     const unsigned slot = __builtin_amdgcn_readfirstlane(ring_s + slot_off);
+#ifndef SPR_KP_RING_NO_LGKM
+    // Every ds_read of the slot's previous item has RETURNED before the refill is issued (the
+    // ordering used to rest on timing alone -- the LDS retires a wave's reads in order, hundreds of cycles before
+    // a DMA can land -- which no ISA rule guarantees).  A/B against -DSPR_KP_RING_NO_LGKM: scripts/kp_lgkm_ab.sh.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
 #pragma unroll
     for (int pc = 0; pc < PPI; ++pc) {
       const unsigned rid = min(ids.row[pc], (unsigned)(ns - 1));   // shadow slots fetch a real (finite) row
