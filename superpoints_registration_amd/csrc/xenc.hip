@@ -190,14 +190,19 @@ __device__ __forceinline__ f32x16 ln_block(const f32x16& v, int b, int h, float 
 // ~4 cycles of issue; what is not placed INSIDE the 32-cycle shadow of an MFMA is paid in full.  So the
 // stream is laid out by hand and pinned with sched_barrier: a chunk is 16 steps; step i issues
 //   MFMA (lo x hi) | side slice 2i | MFMA (hi x lo) | side slice 2i+1 | MFMA (hi x hi) | two fragment reads
-//   for step i + 3 | (steps 8..15) one 1-KiB piece of the weight DMA
+//   for step i + XPF | (steps 8..15) one 1-KiB piece of the weight DMA
 // where the "side" slices are the epilogue of the PREVIOUS chunk cut into 32 pieces (ReLU + split of the
 // hidden chunk, plane stores, bias initialisation of the next accumulator, ...).  Fragment reads run three
 // steps ahead through a ring of four register pairs carried from chunk to chunk: the last three steps of a
 // chunk read the first fragments of the NEXT chunk, which is acquired (counted DMA wait + barrier) at step 8.
 #define XSB() __builtin_amdgcn_sched_barrier(0)
+#ifndef SPR_XENC_PF
+#define SPR_XENC_PF 3            // fragment reads run this many steps ahead of their MFMAs
+#endif
+constexpr int XPF = SPR_XENC_PF;
+constexpr int XRING = XPF < 4 ? 4 : 8;     // register pairs of the fragment ring (a power of two > XPF)
 struct Carry {
-  f16x8 h[4], l[4];
+  f16x8 h[XRING], l[XRING];
 };
 __device__ __forceinline__ void frag_ld(const unsigned char* slot, int lane, int i, f16x8& h, f16x8& l) {
   const f16x8* fr = reinterpret_cast<const f16x8*>(slot) + lane;
@@ -212,7 +217,7 @@ __device__ __forceinline__ f32x16 mfma1(const f16x8& a, const f16x8& b, f32x16 c
 constexpr int T_BO = 0, T_B2 = 256, T_GM = 512, T_BM = 768, T_GT = 1024, T_BT = 1280, T_BIN = 1536, T_B1 = 2304;
 constexpr int T_PAD = 64;   // the bias tables are read one block past their end by the pipelined initialisations
 __host__ __device__ inline size_t xenc_lds_bytes(int d_ff, int nseg) {
-  return (size_t)XSLOTS * XCHUNK + (size_t)(T_B1 + d_ff + T_PAD + nseg + 1) * 4;
+  return (size_t)XSLOTS * XCHUNK + (size_t)(T_B1 + d_ff + T_PAD + 2 * (nseg + 1)) * 4;
 }
 
 // Diagnostic build only (-DSPR_XENC_STAMP, scripts/xenc_timeline.py): shader-clock stamps of wave 0 of
@@ -238,11 +243,12 @@ __device__ unsigned long long g_xenc_stamps[64 * 64];
 template <bool HEAD, bool FFN, int TAIL>
 __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const float* o_g, const float* x_g, float* xo_g,
                                                        const float* pos_g, float* ln_g, AttnPlanes pl, int T,
-                                                       int ntiles, int* tile_ctr, int stamp_on) {
+                                                       int ntiles, int* tile_ctr, const int* __restrict__ tfirst_g, int stamp_on) {
   extern __shared__ __align__(16) unsigned char ring[];
   float* tab = reinterpret_cast<float*>(ring + XSLOTS * XCHUNK);
   const int d_ff = 32 * c.nf;
-  int* cu_s = reinterpret_cast<int*>(tab + T_B1 + d_ff + T_PAD);
+  int* cu_s = reinterpret_cast<int*>(tab + T_B1 + d_ff + T_PAD);     // cu_seqlens [nseg + 1]
+  int* tf_s = cu_s + pl.nseg + 1;                                      // tiles in front of every segment [nseg + 1]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -264,9 +270,12 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
   }
   for (int i = tid; i < 768; i += 256) tab[T_BIN + i] = TAIL == 2 ? c.bin[i] : 0.f;
   for (int i = tid; i < d_ff + T_PAD; i += 256) tab[T_B1 + i] = (FFN && i < d_ff) ? c.b1[i] : 0.f;
-  if (TAIL == 2)
-    for (int i = tid; i <= pl.nseg; i += 256) cu_s[i] = pl.cu[i];
+  for (int i = tid; i <= pl.nseg; i += 256) {
+    cu_s[i] = pl.cu[i];
+    tf_s[i] = tfirst_g[i];
+  }
   __syncthreads();
+  ntiles = tf_s[pl.nseg];                // (the host only knows an upper bound)
 
   // ---- weight ring -----------------------------------------------------------------------------------
   // Chunk g lives in slot g % 4.  acquire() -- at step 8 of chunk g - 1 -- makes chunk g readable (every wave
@@ -327,26 +336,29 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
   __builtin_amdgcn_s_barrier();
   a_slot = 1;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) frag_ld(slot, lane, i, cy.h[i], cy.l[i]);
-  // chunk with accumulator `acc`, B operand planes xh / xl (one fragment per step), side slices side(0..31)
-  auto chunk_f = [&](f32x16& acc, const f16x8 (&xh)[16], const f16x8 (&xl)[16], auto&& side)
+  for (int i = 0; i < XPF; ++i) frag_ld(slot, lane, i, cy.h[i], cy.l[i]);
+  // chunk with accumulator `acc`, activation planes xh / xl (one fragment per step), side slices side(0..31).
+  // SWAP = false: acc[feature][token] (weights are the A operand); true: acc[token][feature] (activations are the A
+  // operand: the lane is a FEATURE and holds 16 tokens -- the V blocks, whose planes are stored transposed)
+  auto chunk_f = [&](auto swap_tag, f32x16& acc, const f16x8 (&xh)[16], const f16x8 (&xl)[16], auto&& side)
       __attribute__((always_inline)) {
+    constexpr bool SW = decltype(swap_tag)::value;
     const unsigned char* nxt = slot;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       if (i == 8) nxt = acquire();
-      acc = mfma1(cy.l[i & 3], xh[i], acc);
+      acc = SW ? mfma1(xh[i], cy.l[i & (XRING - 1)], acc) : mfma1(cy.l[i & (XRING - 1)], xh[i], acc);
       XSB();
       side(2 * i);
       XSB();
-      acc = mfma1(cy.h[i & 3], xl[i], acc);
+      acc = SW ? mfma1(xl[i], cy.h[i & (XRING - 1)], acc) : mfma1(cy.h[i & (XRING - 1)], xl[i], acc);
       XSB();
       side(2 * i + 1);
       XSB();
-      acc = mfma1(cy.h[i & 3], xh[i], acc);
+      acc = SW ? mfma1(xh[i], cy.h[i & (XRING - 1)], acc) : mfma1(cy.h[i & (XRING - 1)], xh[i], acc);
       XSB();
-      if (i + 3 < 16) frag_ld(slot, lane, i + 3, cy.h[(i + 3) & 3], cy.l[(i + 3) & 3]);
-      else frag_ld(nxt, lane, i + 3 - 16, cy.h[(i + 3) & 3], cy.l[(i + 3) & 3]);
+      if (i + XPF < 16) frag_ld(slot, lane, i + XPF, cy.h[(i + XPF) & (XRING - 1)], cy.l[(i + XPF) & (XRING - 1)]);
+      else frag_ld(nxt, lane, i + XPF - 16, cy.h[(i + XPF) & (XRING - 1)], cy.l[(i + XPF) & (XRING - 1)]);
       if (i >= 8) piece(i - 8);
       XSB();
     }
@@ -359,18 +371,18 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       if (i == 8) nxt = acquire();
-      y[i >> 1] = mfma1(cy.l[i & 3], hh[i & 1], y[i >> 1]);
+      y[i >> 1] = mfma1(cy.l[i & (XRING - 1)], hh[i & 1], y[i >> 1]);
       XSB();
       side(2 * i);
       XSB();
-      y[i >> 1] = mfma1(cy.h[i & 3], hl[i & 1], y[i >> 1]);
+      y[i >> 1] = mfma1(cy.h[i & (XRING - 1)], hl[i & 1], y[i >> 1]);
       XSB();
       side(2 * i + 1);
       XSB();
-      y[i >> 1] = mfma1(cy.h[i & 3], hh[i & 1], y[i >> 1]);
+      y[i >> 1] = mfma1(cy.h[i & (XRING - 1)], hh[i & 1], y[i >> 1]);
       XSB();
-      if (i + 3 < 16) frag_ld(slot, lane, i + 3, cy.h[(i + 3) & 3], cy.l[(i + 3) & 3]);
-      else frag_ld(nxt, lane, i + 3 - 16, cy.h[(i + 3) & 3], cy.l[(i + 3) & 3]);
+      if (i + XPF < 16) frag_ld(slot, lane, i + XPF, cy.h[(i + XPF) & (XRING - 1)], cy.l[(i + XPF) & (XRING - 1)]);
+      else frag_ld(nxt, lane, i + XPF - 16, cy.h[(i + XPF) & (XRING - 1)], cy.l[(i + XPF) & (XRING - 1)]);
       if (i >= 8) piece(i - 8);
       XSB();
     }
@@ -389,10 +401,24 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
 #pragma unroll 1
   for (int it = 0; tile < ntiles; ++it) {
     if (tid == 0) s_tile[(it + 1) & 1] = atomicAdd(tile_ctr, 1);       // the next tile (read at the end of this one)
-    const int tok = tile * XTOK + wave * 32 + r;
-    const bool valid = tok < T;
-    const bool wave_valid = tile * XTOK + wave * 32 < T;   // lane 0 of the wave is valid: its stores do issue
-    const int tokc = valid ? tok : T - 1;
+    // Tiles never straddle a segment (cloud): tile = (segment, 128-token slice of it).  A wave's 32 tokens then sit in
+    // 32 consecutive, 16-byte aligned columns of the transposed V planes (one segment, vstart is a multiple of 8).
+    int sg;
+    {
+      int lo = 0, hi = pl.nseg;                        // largest s with tf[s] <= tile (skips empty segments)
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (tf_s[mid] <= tile) lo = mid; else hi = mid;
+      }
+      sg = lo;
+    }
+    const int seg_beg = cu_s[sg], seg_end = cu_s[sg + 1];
+    const int tok_w = seg_beg + (tile - tf_s[sg]) * XTOK + wave * 32;     // first token of the wave
+    const int tok = tok_w + r;
+    const bool valid = tok < seg_end;
+    const bool wave_valid = tok_w < seg_end;               // lane 0 of the wave is valid: its stores do issue
+    const int tokc = valid ? tok : seg_end - 1;
+    (void)T;
     f32x16 v[8];
     f16x8 ph[16], pw[16];
     XSTAMP(0);
@@ -410,7 +436,7 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
       XSTAMP(1);
 #pragma unroll
       for (int b = 0; b < 8; ++b) {
-        chunk_f(v[b], ph, pw, no_side);
+        chunk_f(std::false_type{}, v[b], ph, pw, no_side);
         if (b == 0) XSTAMP(2);
       }
       XSTAMP(3);
@@ -469,7 +495,7 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
         hl[1] = __builtin_bit_cast(f16x8, (u32x4){lu[4], lu[5], lu[6], lu[7]});
       };
       // F0 (side: bias of hidden chunk 1 into B)
-      chunk_f(A, ph, pw, [&](int s) __attribute__((always_inline)) {
+      chunk_f(std::false_type{}, A, ph, pw, [&](int s) __attribute__((always_inline)) {
         if (s < 4) bias_group(B, b1t + 32, c.bs1, s);
       });
       XSTAMP(6);
@@ -477,17 +503,17 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
 #pragma unroll 1
       for (int j = 0; j < npair; ++j) {
         const int c1 = 2 * j + 1;
-        chunk_f(B, ph, pw, [&](int s) __attribute__((always_inline)) { relu_split(A, c1 + 1, s); });   // F(c1), A = hidden c1-1
+        chunk_f(std::false_type{}, B, ph, pw, [&](int s) __attribute__((always_inline)) { relu_split(A, c1 + 1, s); });   // F(c1), A = hidden c1-1
         pack_h();
         chunk_g(y, hh, hl, no_side);                                                                    // G(c1 - 1)
-        chunk_f(A, ph, pw, [&](int s) __attribute__((always_inline)) { relu_split(B, c1 + 2, s); });   // F(c1 + 1)
+        chunk_f(std::false_type{}, A, ph, pw, [&](int s) __attribute__((always_inline)) { relu_split(B, c1 + 2, s); });   // F(c1 + 1)
         pack_h();
         chunk_g(y, hh, hl, no_side);                                                                    // G(c1)
         if (j == 0) XSTAMP(7);
       }
       {
         const int c1 = c.nf - 1;                                                                        // last pair
-        chunk_f(B, ph, pw, [&](int s) __attribute__((always_inline)) { relu_split(A, c1 + 1, s); });
+        chunk_f(std::false_type{}, B, ph, pw, [&](int s) __attribute__((always_inline)) { relu_split(A, c1 + 1, s); });
         pack_h();
         chunk_g(y, hh, hl, no_side);                                                                    // G(nf - 2)
 #pragma unroll
@@ -531,22 +557,27 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
         }
       }
       XSTAMP(10);
-      int vcol = 0;
-      {
-        int lo = 0, hi = pl.nseg;                      // largest s with cu[s] <= tokc
-        while (hi - lo > 1) {
-          const int mid = (lo + hi) >> 1;
-          if (cu_s[mid] <= tokc) lo = mid; else hi = mid;
-        }
-        vcol = attn_vstart_of(cu_s[lo], lo) + tokc - cu_s[lo];
-      }
+      const int vcol_w = attn_vstart_of(seg_beg, sg) + (tok_w - seg_beg);       // column of the wave's first token
       // 24 feature blocks (8 heads of Q, K, V); the epilogue of block fb - 1 (scale, split, plane stores) and
-      // the bias of block fb + 1 run as side slices of block fb; accumulators A / B alternate
+      // the bias of block fb + 1 run as side slices of block fb; accumulators A / B alternate.  The V blocks
+      // (16..23) are computed transposed (chunk_f SWAP): their accumulator holds 16 tokens of one feature.
       const float* bint = tab + T_BIN;
       f32x16 A, B;
       unsigned int hu[8], lu[8];
 #pragma unroll
       for (int g = 0; g < 4; ++g) bias_group(A, bint, c.bs_in, g);
+      // bias of block fbn, a quarter per call: per register (Q / K) or per lane (V)
+      auto bias_next = [&](f32x16& P, int fbn, int q) __attribute__((always_inline)) {
+        if (fbn >= 16) {
+          const float t = bint[32 * fbn + r] * c.bs_in;
+          P[4 * q + 0] = t;
+          P[4 * q + 1] = t;
+          P[4 * q + 2] = t;
+          P[4 * q + 3] = t;
+        } else {
+          bias_group(P, bint + 32 * fbn, c.bs_in, q);
+        }
+      };
       // epilogue slices of accumulator P = feature block fbp (kind WHICH: 0 Q, 1 K, 2 V), then bias of block fbn
       auto epi = [&](auto which_tag, f32x16& P, int fbp, int fbn, int s) __attribute__((always_inline)) {
         constexpr int WHICH = decltype(which_tag)::value;
@@ -554,62 +585,83 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
         if (s < 8) {
           split_pk_s(P[2 * s] * c.un_in, P[2 * s + 1] * c.un_in, c.pmul[WHICH], hu[s], lu[s]);
         } else if (s < 12) {
-          bias_group(P, bint + 32 * fbn, c.bs_in, s - 8);
-        } else if (s >= 18) {                      // stores behind the acquire of step 8 (slice 16): counted there
+          bias_next(P, fbn, s - 8);
+        } else if (s < 16) {
+          if constexpr (WHICH == 2) {
+            // The lane (feature l & 31, half h) holds tokens {0..3, 8..11, 16..19, 24..27} + 4 h as packed pairs;
+            // exchanging pairs with the partner half gives the h = 0 lane tokens 0..7 and 16..23 and the h = 1
+            // lane tokens 8..15 and 24..31: two contiguous 16-byte pieces per plane.
+            const int i0 = (s - 12) < 2 ? (s - 12) : (s - 12) + 2;       // pairs (0,2) (1,3) (4,6) (5,7)
+            {
+              const auto t = __builtin_amdgcn_permlane32_swap(hu[i0], hu[i0 + 2], false, false);
+              hu[i0] = t[0];
+              hu[i0 + 2] = t[1];
+            }
+            {
+              const auto t = __builtin_amdgcn_permlane32_swap(lu[i0], lu[i0 + 2], false, false);
+              lu[i0] = t[0];
+              lu[i0 + 2] = t[1];
+            }
+          }
+        } else if (s >= 18 && s < 22) {            // stores behind the acquire of step 8 (slice 16): counted there
+          const unsigned int* src = s < 20 ? hu : lu;
+          const int o4 = 4 * (s & 1);
           if constexpr (WHICH < 2) {
             // head-major [head][token][32]: the lane's 16 features of the head as 32 contiguous bytes at
             // d' = 16 h + e.  The order of d inside a head is free as long as Q and K agree (both are
             // written here) -- the scores sum over it.
-            if (s < 22 && valid) {
+            if (valid) {
               _Float16* pb = WHICH == 0 ? (s < 20 ? pl.qh : pl.ql) : (s < 20 ? pl.kh : pl.kl);
               const size_t row = ((size_t)head * pl.t_total + tokc) * 32 + 16 * h + 8 * (s & 1);
-              const unsigned int* src = s < 20 ? hu : lu;
-              const int o4 = 4 * (s & 1);
               store16(pb + row, (u32x4){src[o4], src[o4 + 1], src[o4 + 2], src[o4 + 3]});
             }
           } else {
-            // transposed planes [feature][token column]: one 2-byte store per feature; slices 18..25 take
-            // one register pair each (features f, f + 1 of both planes)
-            if (s < 26 && valid) {
-              const int i = s - 18;
-              const int e = 2 * i;
-              const int f = head * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-              const size_t o0 = (size_t)f * pl.tp + vcol;
-              store2(pl.vth + o0, hu[i]);
-              store2hi(pl.vth + o0 + pl.tp, hu[i]);
-              store2(pl.vtl + o0, lu[i]);
-              store2hi(pl.vtl + o0 + pl.tp, lu[i]);
+            // transposed planes [feature][token column]: piece (s & 1) = tokens 16 (s & 1) + 8 h .. + 7 of feature
+            // row head * 32 + (l & 31); written when the group's first token exists (the rest of a partly valid
+            // group are finite values of the clamped last token, inside the gap in front of the next segment)
+            const int t0 = tok_w + 16 * (s & 1) + 8 * h;
+            if (t0 < seg_end) {
+              _Float16* pb = s < 20 ? pl.vth : pl.vtl;
+              const size_t o0 = (size_t)(head * 32 + r) * pl.tp + vcol_w + 16 * (s & 1) + 8 * h;
+              store16(pb + o0, (u32x4){src[o4], src[o4 + 1], src[o4 + 2], src[o4 + 3]});
             }
           }
         }
       };
-      auto count = [&](int which) __attribute__((always_inline)) {
-        if (wave_valid) s_cnt += which < 2 ? 4 : 32;
+      auto count = [&]() __attribute__((always_inline)) {
+        if (wave_valid) s_cnt += 4;
       };
       // block 0 (side: bias of block 1 into B)
-      chunk_f(A, ph, pw, [&](int s) __attribute__((always_inline)) {
+      chunk_f(std::false_type{}, A, ph, pw, [&](int s) __attribute__((always_inline)) {
         if (s < 4) bias_group(B, bint + 32, c.bs_in, s);
       });
       XSTAMP(11);
-      auto pair = [&](auto which_tag, int fb) __attribute__((always_inline)) {   // blocks fb (odd, into B) and fb + 1 (into A)
-        chunk_f(B, ph, pw, [&](int s) __attribute__((always_inline)) { epi(which_tag, A, fb - 1, fb + 1, s); });
-        count(decltype(which_tag)::value);
-        chunk_f(A, ph, pw, [&](int s) __attribute__((always_inline)) { epi(which_tag, B, fb, fb + 2, s); });
-        count(decltype(which_tag)::value);
+      // blocks fb (odd, into B) and fb + 1 (into A); which_tag = kind of the blocks whose epilogues run beside them
+      auto pair = [&](auto which_tag, auto sw1, auto sw2, int fb) __attribute__((always_inline)) {
+        chunk_f(sw1, B, ph, pw, [&](int s) __attribute__((always_inline)) { epi(which_tag, A, fb - 1, fb + 1, s); });
+        count();
+        chunk_f(sw2, A, ph, pw, [&](int s) __attribute__((always_inline)) { epi(which_tag, B, fb, fb + 2, s); });
+        count();
       };
+      const std::integral_constant<int, 0> kQ{};
+      const std::integral_constant<int, 1> kK{};
+      const std::integral_constant<int, 2> kV{};
+      const std::false_type nsw{};
+      const std::true_type sw{};
 #pragma unroll 1
-      for (int fb = 1; fb < 8; fb += 2) pair(std::integral_constant<int, 0>{}, fb);     // epilogues of blocks 0..7 (Q)
+      for (int fb = 1; fb < 8; fb += 2) pair(kQ, nsw, nsw, fb);        // blocks 1..8, epilogues of blocks 0..7 (Q)
       XSTAMP(12);
 #pragma unroll 1
-      for (int fb = 9; fb < 16; fb += 2) pair(std::integral_constant<int, 1>{}, fb);    // blocks 8..15 (K)
+      for (int fb = 9; fb < 14; fb += 2) pair(kK, nsw, nsw, fb);       // blocks 9..14, epilogues of blocks 8..13 (K)
+      pair(kK, nsw, sw, 15);                                           // blocks 15 and 16 (the first V block)
       XSTAMP(13);
 #pragma unroll 1
-      for (int fb = 17; fb < 22; fb += 2) pair(std::integral_constant<int, 2>{}, fb);   // blocks 16..21 (V)
-      chunk_f(B, ph, pw, [&](int s) __attribute__((always_inline)) { epi(std::integral_constant<int, 2>{}, A, 22, 23, s); });
-      count(2);
+      for (int fb = 17; fb < 22; fb += 2) pair(kV, sw, sw, fb);        // blocks 17..22, epilogues of blocks 16..21 (V)
+      chunk_f(sw, B, ph, pw, [&](int s) __attribute__((always_inline)) { epi(kV, A, 22, 23, s); });
+      count();
 #pragma unroll
-      for (int s = 0; s < 32; ++s) epi(std::integral_constant<int, 2>{}, B, 23, 23, s);   // last block: nothing to hide behind
-      count(2);
+      for (int s = 0; s < 32; ++s) epi(kV, B, 23, 23, s);              // last block: nothing to hide behind
+      count();
       XSTAMP(14);
     }
     tile = s_tile[(it + 1) & 1];   // written before this tile's first barrier: ordered by the barriers since
@@ -711,14 +763,25 @@ size_t stream_chunks(int n_layers, int nf) {
 }
 constexpr size_t kStatsBytes = 64 * 1024;     // stat jobs + results + plane multipliers
 
+// tiles in front of every segment: tf[s] = sum_{s' < s} ceil(len_s' / XTOK), tf[nseg] = number of tiles
+__global__ void k_xenc_tiles(const int* __restrict__ cu, int nseg, int* __restrict__ tf) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int t = 0;
+  for (int s = 0; s < nseg; ++s) {
+    tf[s] = t;
+    t += (cu[s + 1] - cu[s] + XTOK - 1) / XTOK;
+  }
+  tf[nseg] = t;
+}
+
 template <bool HEAD, bool FFN, int TAIL>
 int launch_chain(const ChainConsts& c, const float* o, const float* x, float* xo, const float* pos, float* ln,
-                 const AttnPlanes& pl, int T, int* tile_ctr, hipStream_t stream) {
+                 const AttnPlanes& pl, int T, int* tile_ctr, const int* tfirst, hipStream_t stream) {
   auto kern = k_xenc_chain<HEAD, FFN, TAIL>;
   const size_t lds = xenc_lds_bytes(32 * c.nf, pl.nseg);
   SPR_REQUIRE(lds + 64 <= 160 * 1024, "xenc: d_ff %d with %d segments does not fit the LDS tables", 32 * c.nf, pl.nseg);
   if (int rc = ensure_dyn_lds((const void*)kern, 160 * 1024 - 64)) return rc;
-  const int ntiles = cdiv(T, XTOK);
+  const int ntiles = cdiv(T, XTOK) + pl.nseg;       // upper bound (tiles do not straddle segments); exact count on the device
   int grid = device_cu_count();
   grid = grid < ntiles ? grid : ntiles;
   int stamp_on = 0;
@@ -732,7 +795,7 @@ int launch_chain(const ChainConsts& c, const float* o, const float* x, float* xo
     if (ea != nullptr) stamp_on |= atoi(ea) & 6;
   }
 #endif
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, c, o, x, xo, pos, ln, pl, T, ntiles, tile_ctr, stamp_on);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, c, o, x, xo, pos, ln, pl, T, ntiles, tile_ctr, tfirst, stamp_on);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -986,7 +1049,8 @@ extern "C" int spr_xenc_debug_stamps(unsigned long long* out_host, int clear) {
 
 extern "C" size_t spr_xenc_workspace_bytes(int t, int nseg) {
   if (t < 1 || nseg < 1) return 0;
-  return spr_attn_workspace_bytes(t, nseg, 8, 32) + 3 * align_up((size_t)t * XD * sizeof(float), 256) + 1024;
+  return spr_attn_workspace_bytes(t, nseg, 8, 32) + 3 * align_up((size_t)t * XD * sizeof(float), 256) + 1024 +
+         align_up((size_t)(nseg + 1) * sizeof(int), 256);
 }
 
 // x [t, 256] tokens of all clouds (packed), pos [t, 256] positional embedding, cu [nseg + 1],
@@ -1017,27 +1081,29 @@ extern "C" int spr_xenc_forward(const void* plan_host, const float* x, const flo
   float* xb = (float*)((char*)ws + planes_bytes + 2 * act);
   int* ctr = (int*)((char*)ws + planes_bytes + 3 * act);      // one tile counter per chain launch
   SPR_HIP_CHECK(hipMemsetAsync(ctr, 0, 1024, stream));
+  int* tfirst = (int*)((char*)ws + planes_bytes + 3 * act + 1024);
+  hipLaunchKernelGGL(k_xenc_tiles, dim3(1), dim3(64), 0, stream, cu, nseg, tfirst);
   if (int rc = attn_zero_gaps(pl, XD, stream)) return rc;
   const int L = plan->n_layers;
-  if (int rc = launch_chain<false, false, 2>(plan->prologue, nullptr, x, nullptr, pos, nullptr, pl, t, ctr++, stream)) return rc;
+  if (int rc = launch_chain<false, false, 2>(plan->prologue, nullptr, x, nullptr, pos, nullptr, pl, t, ctr++, tfirst, stream)) return rc;
   const float* cur = x;
   float* nxt = xa;
   for (int l = 0; l < L; ++l) {
     pl.scales = plan->scales_self[l];
     if (int rc = attn_core_on_planes(pl, kv_self, max_len_host, 8, obuf, XD, mode, stream)) return rc;
-    if (int rc = launch_chain<true, false, 2>(plan->a[l], obuf, cur, nxt, pos, nullptr, pl, t, ctr++, stream)) return rc;
+    if (int rc = launch_chain<true, false, 2>(plan->a[l], obuf, cur, nxt, pos, nullptr, pl, t, ctr++, tfirst, stream)) return rc;
     cur = nxt;
     nxt = (nxt == xa) ? xb : xa;
     pl.scales = plan->scales_cross[l];
     if (int rc = attn_core_on_planes(pl, kv_cross, max_len_host, 8, obuf, XD, mode, stream)) return rc;
     if (l + 1 < L) {
-      if (int rc = launch_chain<true, true, 2>(plan->b[l], obuf, cur, nxt, pos, nullptr, pl, t, ctr++, stream)) return rc;
+      if (int rc = launch_chain<true, true, 2>(plan->b[l], obuf, cur, nxt, pos, nullptr, pl, t, ctr++, tfirst, stream)) return rc;
       cur = nxt;
       nxt = (nxt == xa) ? xb : xa;
     } else if (plan->has_final) {
-      if (int rc = launch_chain<true, true, 1>(plan->b[l], obuf, cur, nxt, pos, out, pl, t, ctr++, stream)) return rc;
+      if (int rc = launch_chain<true, true, 1>(plan->b[l], obuf, cur, nxt, pos, out, pl, t, ctr++, tfirst, stream)) return rc;
     } else {
-      if (int rc = launch_chain<true, true, 0>(plan->b[l], obuf, cur, out, pos, nullptr, pl, t, ctr++, stream)) return rc;
+      if (int rc = launch_chain<true, true, 0>(plan->b[l], obuf, cur, out, pos, nullptr, pl, t, ctr++, tfirst, stream)) return rc;
     }
   }
   return 0;
