@@ -8,8 +8,9 @@
 //   dQ       = scale . dS K,    dS = P o (dP - D),  P = exp2(c S - L), dP = dO V^T    (sweep 2 of) k_attn_bwd_dq
 //   dV = P^T dO,  dK = scale . dS^T Q                                                 k_attn_bwd_dkv
 //
-// Arithmetic: exact f32 MFMA (v_mfma_f32_32x32x2_f32) like spr_bgemm, fp32 softmax with v_exp_f32;
-// fixed summation order -> bitwise reproducible gradients.
+// Arithmetic: attention mode 0 (spr_set_attn_mode): exact f32 MFMA (v_mfma_f32_32x32x2_f32) like spr_bgemm; mode 1 / 2
+// (default): the split-fp16 form further down.  fp32 softmax with v_exp_f32 in both; fixed summation order ->
+// bitwise reproducible gradients.
 //
 // Layout trick (no LDS round trip for the probabilities): the 32x32 C tile holds column n = lane % 32 and the
 // rows 8 (r / 4) + 4 (lane / 32) + r % 4 in registers r = 0..15.  A C tile whose ROWS are the contraction
@@ -377,13 +378,417 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(const AttnBwdArgs a) {
   }
 }
 
+
+// ======================================================================================================
+// Split-fp16 form (attention mode 1, the default): the same two kernels with every product on
+// v_mfma_f32_32x32x16_f16 over range-scaled hi/lo operand planes (3 matrix instructions per product and k-step, fp32
+// accumulation -- the forward's arithmetic, spr_common.h split_pk_s), 5.3x less matrix time than the f32 form.
+//   operand scales (powers of two, measured per call): sq, sk, sv, sdo bring max|q|, |k|, |v|, |dO| into
+//   [2^14, 2^15).  S' = sq sk S and dP' = sv sdo dP stay in fp32.  The probabilities are split as P 2^14 (<= 2^14),
+//   dS as P (dP' - D') 2^-21: |dP' - D'| <= 2 . 32 . 2^15 . 2^15 = 2^36 by Cauchy-Schwarz (D' is a convex
+//   combination of the dP' of its row), so no operand can overflow fp16 whatever the data.
+// The staged tiles live in LDS as fp16 planes in two forms: R[row][d] (A operand of the products that contract
+// over d: 8 consecutive d per lane) and C[d][pos(row)] (A operand of the products that contract over the tile's
+// rows), pos() = the order in which a 32x32 accumulator tile holds its rows, so that the accumulator registers
+// of S / dS are the B operand of the next product as they are: k-step s of a 32-row block contracts the rows
+// 16 s + 8 (j >> 2) + 4 h + (j & 3), j = 0..7, of lane half h = registers 8 s + j.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int bu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int bu32x2 __attribute__((ext_vector_type(2)));
+constexpr int RS = 40;                    // R-form row stride in halves (80 B: 16-byte aligned, spreads the banks)
+constexpr int CS = 72;                    // C-form row stride in halves (144 B)
+constexpr int R_HALVES = BT * RS;         // one R plane of a 64-row tile
+constexpr int C_HALVES = BHD * CS;        // one C plane
+constexpr float P_MUL = 16384.f;          // 2^14
+constexpr float DS_MUL = 4.76837158203125e-07f;   // 2^-21
+
+__device__ __forceinline__ int cpos(int rho) {     // position of row rho (0..31) of a block in the C form
+  return 16 * (rho >> 4) + 8 * ((rho >> 2) & 1) + 4 * ((rho >> 3) & 1) + (rho & 3);
+}
+// stores the fetched [64 x 32] tile into the R planes (and the C planes when ch != nullptr), scaled by s
+__device__ __forceinline__ void tile_store_split(const TileRegs& t, float s, _Float16* rh, _Float16* rl, _Float16* ch,
+                                                 _Float16* cl) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float4 v = e == 0 ? t.a : t.b;
+    const int idx = threadIdx.x + 256 * e;
+    const int row = idx >> 3, dc = 4 * (idx & 7);
+    unsigned int h0, l0, h1, l1;
+    split_pk_s(v.x, v.y, s, h0, l0);
+    split_pk_s(v.z, v.w, s, h1, l1);
+    *reinterpret_cast<bu32x2*>(rh + row * RS + dc) = (bu32x2){h0, h1};
+    *reinterpret_cast<bu32x2*>(rl + row * RS + dc) = (bu32x2){l0, l1};
+    if (ch != nullptr) {
+      const int pos = 32 * (row >> 5) + cpos(row & 31);
+      unsigned short* ph = reinterpret_cast<unsigned short*>(ch) + dc * CS + pos;
+      unsigned short* pl = reinterpret_cast<unsigned short*>(cl) + dc * CS + pos;
+      ph[0] = (unsigned short)(h0 & 0xffffu);
+      ph[CS] = (unsigned short)(h0 >> 16);
+      ph[2 * CS] = (unsigned short)(h1 & 0xffffu);
+      ph[3 * CS] = (unsigned short)(h1 >> 16);
+      pl[0] = (unsigned short)(l0 & 0xffffu);
+      pl[CS] = (unsigned short)(l0 >> 16);
+      pl[2 * CS] = (unsigned short)(l1 & 0xffffu);
+      pl[3 * CS] = (unsigned short)(l1 >> 16);
+    }
+  }
+}
+// the lane's 16 values x[16 h' ..] of a row as B-operand planes: b?[s] = x[16 s + 8 h + j], j = 0..7
+__device__ __forceinline__ void row_planes(const float* __restrict__ row, int h, float s, h16x8 (&bh)[2], h16x8 (&bl)[2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const float4 x = *reinterpret_cast<const float4*>(row + 16 * ks + 8 * h);
+    const float4 y = *reinterpret_cast<const float4*>(row + 16 * ks + 8 * h + 4);
+    unsigned int hi[4], lo[4];
+    split_pk_s(x.x, x.y, s, hi[0], lo[0]);
+    split_pk_s(x.z, x.w, s, hi[1], lo[1]);
+    split_pk_s(y.x, y.y, s, hi[2], lo[2]);
+    split_pk_s(y.z, y.w, s, hi[3], lo[3]);
+    bh[ks] = __builtin_bit_cast(h16x8, (bu32x4){hi[0], hi[1], hi[2], hi[3]});
+    bl[ks] = __builtin_bit_cast(h16x8, (bu32x4){lo[0], lo[1], lo[2], lo[3]});
+  }
+}
+__device__ __forceinline__ f32x16 mfma_h(const h16x8& a, const h16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// C = X[row0 + m][.] . B (contraction over d), X in R form
+__device__ __forceinline__ f32x16 mm_rows_h(const _Float16* rh, const _Float16* rl, int row0, int l31, int h,
+                                            const h16x8 (&bh)[2], const h16x8 (&bl)[2]) {
+  f32x16 c;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const h16x8 ah = *reinterpret_cast<const h16x8*>(rh + (row0 + l31) * RS + 16 * ks + 8 * h);
+    const h16x8 al = *reinterpret_cast<const h16x8*>(rl + (row0 + l31) * RS + 16 * ks + 8 * h);
+    c = mfma_h(ah, bl[ks], c);
+    c = mfma_h(al, bh[ks], c);
+    c = mfma_h(ah, bh[ks], c);
+  }
+  return c;
+}
+// the accumulator tile b (scaled by s) as B-operand planes of a product that contracts over its rows
+__device__ __forceinline__ void acc_planes(const f32x16& b, float s, h16x8 (&bh)[2], h16x8 (&bl)[2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    unsigned int hi[4], lo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_pk_s(b[8 * ks + 2 * i], b[8 * ks + 2 * i + 1], s, hi[i], lo[i]);
+    bh[ks] = __builtin_bit_cast(h16x8, (bu32x4){hi[0], hi[1], hi[2], hi[3]});
+    bl[ks] = __builtin_bit_cast(h16x8, (bu32x4){lo[0], lo[1], lo[2], lo[3]});
+  }
+}
+// acc += X^T . B, X in C form (32-row block blk), B = acc_planes of a C-layout tile
+__device__ __forceinline__ void mm_cols_acc_h(f32x16& acc, const _Float16* ch, const _Float16* cl, int blk, int l31, int h,
+                                              const h16x8 (&bh)[2], const h16x8 (&bl)[2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const h16x8 ah = *reinterpret_cast<const h16x8*>(ch + l31 * CS + 32 * blk + 16 * ks + 8 * h);
+    const h16x8 al = *reinterpret_cast<const h16x8*>(cl + l31 * CS + 32 * blk + 16 * ks + 8 * h);
+    acc = mfma_h(ah, bl[ks], acc);
+    acc = mfma_h(al, bh[ks], acc);
+    acc = mfma_h(ah, bh[ks], acc);
+  }
+}
+
+// scales[0..3] = sq, sk, sv, sdo from the four max-|x| partial arrays
+__global__ __launch_bounds__(256) void k_attn_bwd_scales(const float* __restrict__ parts, float* __restrict__ scales) {
+  __shared__ float sh[17];
+  for (int i = 0; i < 4; ++i) {
+    const float m = block_absmax(parts + (size_t)i * kAmaxParts, sh, kAmaxParts);
+    if (threadIdx.x == 0) scales[i] = pow2f(pow2_exp_for(m));
+    __syncthreads();
+  }
+}
+
+constexpr int DQ_BUF_HALVES = 4 * R_HALVES + 2 * C_HALVES;     // K: R + C planes, V: R planes
+constexpr int DKV_BUF_HALVES = 4 * R_HALVES + 4 * C_HALVES;    // Q and dO: R + C planes
+
+// grid (query tile, head, query segment)
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_h(const AttnBwdArgs a, const float* __restrict__ scales) {
+  __shared__ __align__(16) _Float16 tiles[2 * DQ_BUF_HALVES];
+  __shared__ float red_m[2][BT], red_l[2][BT];
+  const int head = blockIdx.y, seg = blockIdx.z;
+  const int qbeg = a.cu[seg], qlen = a.cu[seg + 1] - qbeg;
+  const int q0 = blockIdx.x * BT;
+  if (q0 >= qlen) return;
+  const int ksg = a.kv_seg[seg];
+  const int kbeg = a.cu[ksg], klen = a.cu[ksg + 1] - kbeg;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int qb = wave & 1, kb = wave >> 1;
+  const int hoff = head * BHD;
+  const float sq = scales[0], sk = scales[1], sv = scales[2], sdo = scales[3];
+  const float c = a.scale * kLog2e / (sq * sk);
+  auto KRh = [&](int b) { return tiles + b * DQ_BUF_HALVES; };
+  auto KRl = [&](int b) { return tiles + b * DQ_BUF_HALVES + R_HALVES; };
+  auto VRh = [&](int b) { return tiles + b * DQ_BUF_HALVES + 2 * R_HALVES; };
+  auto VRl = [&](int b) { return tiles + b * DQ_BUF_HALVES + 3 * R_HALVES; };
+  auto KCh = [&](int b) { return tiles + b * DQ_BUF_HALVES + 4 * R_HALVES; };
+  auto KCl = [&](int b) { return tiles + b * DQ_BUF_HALVES + 4 * R_HALVES + C_HALVES; };
+
+  const int qi = q0 + 32 * qb + l31;
+  const bool qvalid = qi < qlen;
+  const int qic = qvalid ? qi : qlen - 1;
+  h16x8 qh[2], ql[2], doh[2], dol[2];
+  row_planes(a.q + (size_t)(qbeg + qic) * a.qs + hoff, h, sq, qh, ql);
+  row_planes(a.dout + (size_t)(qbeg + qic) * a.dos + hoff, h, sdo, doh, dol);
+  const float dq_row = a.dsum[(size_t)(qbeg + qic) * a.nhead + head] * (sv * sdo);
+  const int ntile = (klen + BT - 1) / BT;
+
+  // ---- sweep 1: L = log2 sum_j exp2(c s_j) per query ----
+  float m_run = -INFINITY, l_run = 0.f;
+  {
+    TileRegs rk = tile_fetch(a.k, a.ks, kbeg, klen, 0, hoff);
+    tile_store_split(rk, sk, KRh(0), KRl(0), nullptr, nullptr);
+    __syncthreads();
+    for (int it = 0; it < ntile; ++it) {
+      const int buf = it & 1;
+      const bool more = it + 1 < ntile;
+      if (more) rk = tile_fetch(a.k, a.ks, kbeg, klen, (it + 1) * BT, hoff);
+      const f32x16 s = mm_rows_h(KRh(buf), KRl(buf), 32 * kb, l31, h, qh, ql);       // S'^T[key][query]
+      float x[16], mx = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = it * BT + 32 * kb + crow(r, h);
+        x[r] = key < klen ? s[r] * c : -INFINITY;
+        mx = fmaxf(mx, x[r]);
+      }
+      if (mx > -INFINITY) {
+        const float m_new = fmaxf(m_run, mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += __builtin_amdgcn_exp2f(x[r] - m_new);
+        l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + sum;
+        m_run = m_new;
+      }
+      if (more) tile_store_split(rk, sk, KRh(buf ^ 1), KRl(buf ^ 1), nullptr, nullptr);
+      __syncthreads();
+    }
+  }
+  {
+    const float m_o = __shfl_xor(m_run, 32, 64), l_o = __shfl_xor(l_run, 32, 64);
+    const float m_n = fmaxf(m_run, m_o);
+    float l_n = 0.f;
+    if (m_run > -INFINITY) l_n += l_run * __builtin_amdgcn_exp2f(m_run - m_n);
+    if (m_o > -INFINITY) l_n += l_o * __builtin_amdgcn_exp2f(m_o - m_n);
+    m_run = m_n;
+    l_run = l_n;
+  }
+  if (h == 0) {
+    red_m[kb][32 * qb + l31] = m_run;
+    red_l[kb][32 * qb + l31] = l_run;
+  }
+  __syncthreads();
+  float lse;
+  {
+    const float m0 = red_m[0][32 * qb + l31], m1 = red_m[1][32 * qb + l31];
+    const float l0 = red_l[0][32 * qb + l31], l1 = red_l[1][32 * qb + l31];
+    const float m_n = fmaxf(m0, m1);
+    float l_n = 0.f;
+    if (m0 > -INFINITY) l_n += l0 * __builtin_amdgcn_exp2f(m0 - m_n);
+    if (m1 > -INFINITY) l_n += l1 * __builtin_amdgcn_exp2f(m1 - m_n);
+    lse = m_n + __builtin_amdgcn_logf(l_n);     // v_log_f32 = log2
+  }
+  if (kb == 0 && h == 0 && qvalid) a.lse[(size_t)(qbeg + qi) * a.nhead + head] = lse;
+  __syncthreads();
+
+  // ---- sweep 2: dQ^T[d][query] = sum_keys K^T dS^T ----
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  {
+    TileRegs rk = tile_fetch(a.k, a.ks, kbeg, klen, 0, hoff);
+    TileRegs rv = tile_fetch(a.v, a.vs, kbeg, klen, 0, hoff);
+    tile_store_split(rk, sk, KRh(0), KRl(0), KCh(0), KCl(0));
+    tile_store_split(rv, sv, VRh(0), VRl(0), nullptr, nullptr);
+    __syncthreads();
+    for (int it = 0; it < ntile; ++it) {
+      const int buf = it & 1;
+      const bool more = it + 1 < ntile;
+      if (more) {
+        rk = tile_fetch(a.k, a.ks, kbeg, klen, (it + 1) * BT, hoff);
+        rv = tile_fetch(a.v, a.vs, kbeg, klen, (it + 1) * BT, hoff);
+      }
+      const f32x16 s = mm_rows_h(KRh(buf), KRl(buf), 32 * kb, l31, h, qh, ql);       // S'^T
+      const f32x16 dp = mm_rows_h(VRh(buf), VRl(buf), 32 * kb, l31, h, doh, dol);    // dP'^T = V dO^T
+      f32x16 ds;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = it * BT + 32 * kb + crow(r, h);
+        const float p = key < klen ? __builtin_amdgcn_exp2f(s[r] * c - lse) : 0.f;
+        ds[r] = p * (dp[r] - dq_row);
+      }
+      h16x8 bh[2], bl[2];
+      acc_planes(ds, DS_MUL, bh, bl);
+      mm_cols_acc_h(acc, KCh(buf), KCl(buf), kb, l31, h, bh, bl);
+      if (more) {
+        tile_store_split(rk, sk, KRh(buf ^ 1), KRl(buf ^ 1), KCh(buf ^ 1), KCl(buf ^ 1));
+        tile_store_split(rv, sv, VRh(buf ^ 1), VRl(buf ^ 1), nullptr, nullptr);
+      }
+      __syncthreads();
+    }
+  }
+  // sum the two key-block waves in a fixed order, unscale, store: lane (query l31, h) holds d = 8 a + 4 h + b
+  float (*red_acc)[16][64] = reinterpret_cast<float (*)[16][64]>(tiles);      // [2][16][64] floats, tiles are done
+  if (kb == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red_acc[qb][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (kb == 0 && qvalid) {
+    const float u0 = 2097152.f / sk, u1 = a.scale / (sv * sdo);     // 1 / (sk . sv sdo 2^-21), in two exact steps
+    float* dst = a.dq + (size_t)(qbeg + qi) * (a.nhead * BHD) + hoff + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 o;
+      o.x = (acc[4 * g] + red_acc[qb][4 * g][lane]) * u0 * u1;
+      o.y = (acc[4 * g + 1] + red_acc[qb][4 * g + 1][lane]) * u0 * u1;
+      o.z = (acc[4 * g + 2] + red_acc[qb][4 * g + 2][lane]) * u0 * u1;
+      o.w = (acc[4 * g + 3] + red_acc[qb][4 * g + 3][lane]) * u0 * u1;
+      *reinterpret_cast<float4*>(dst + 8 * g) = o;
+    }
+  }
+}
+
+// grid (key tile, head, key segment); dynamic LDS: 2 x DKV_BUF_HALVES halves + 4 x 64 floats
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_h(const AttnBwdArgs a, const float* __restrict__ scales) {
+  extern __shared__ __align__(16) unsigned char dkv_smem[];
+  _Float16* tiles = reinterpret_cast<_Float16*>(dkv_smem);
+  float* Lt = reinterpret_cast<float*>(dkv_smem + (size_t)2 * DKV_BUF_HALVES * 2);     // [2][BT]
+  float* Dt = Lt + 2 * BT;                                                               // [2][BT]
+  const int head = blockIdx.y, ksg = blockIdx.z;
+  const int kbeg = a.cu[ksg], klen = a.cu[ksg + 1] - kbeg;
+  const int k0 = blockIdx.x * BT;
+  if (k0 >= klen) return;
+  const int seg = a.q_seg[ksg];
+  const int qbeg = a.cu[seg], qlen = a.cu[seg + 1] - qbeg;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int qb = wave & 1, kb = wave >> 1;
+  const int hoff = head * BHD;
+  const float sq = scales[0], sk = scales[1], sv = scales[2], sdo = scales[3];
+  const float c = a.scale * kLog2e / (sq * sk);
+  const float dmul = sv * sdo;
+  auto QRh = [&](int b) { return tiles + b * DKV_BUF_HALVES; };
+  auto QRl = [&](int b) { return tiles + b * DKV_BUF_HALVES + R_HALVES; };
+  auto ORh = [&](int b) { return tiles + b * DKV_BUF_HALVES + 2 * R_HALVES; };
+  auto ORl = [&](int b) { return tiles + b * DKV_BUF_HALVES + 3 * R_HALVES; };
+  auto QCh = [&](int b) { return tiles + b * DKV_BUF_HALVES + 4 * R_HALVES; };
+  auto QCl = [&](int b) { return tiles + b * DKV_BUF_HALVES + 4 * R_HALVES + C_HALVES; };
+  auto OCh = [&](int b) { return tiles + b * DKV_BUF_HALVES + 4 * R_HALVES + 2 * C_HALVES; };
+  auto OCl = [&](int b) { return tiles + b * DKV_BUF_HALVES + 4 * R_HALVES + 3 * C_HALVES; };
+
+  const int ki = k0 + 32 * kb + l31;
+  const bool kvalid = ki < klen;
+  const int kic = kvalid ? ki : klen - 1;
+  h16x8 kh[2], kl[2], vh[2], vl[2];
+  row_planes(a.k + (size_t)(kbeg + kic) * a.ks + hoff, h, sk, kh, kl);
+  row_planes(a.v + (size_t)(kbeg + kic) * a.vs + hoff, h, sv, vh, vl);
+  f32x16 acc_v, acc_k;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_v[r] = acc_k[r] = 0.f;
+  const int ntile = (qlen + BT - 1) / BT;
+  float rl = 0.f, rd = 0.f;
+  auto fetch_stats = [&](int row0) {
+    if (tid < BT) {
+      const int r = row0 + tid;
+      rl = r < qlen ? a.lse[(size_t)(qbeg + r) * a.nhead + head] : 0.f;
+      rd = r < qlen ? a.dsum[(size_t)(qbeg + r) * a.nhead + head] * dmul : 0.f;
+    }
+  };
+  auto store_stats = [&](int buf) {
+    if (tid < BT) {
+      Lt[buf * BT + tid] = rl;
+      Dt[buf * BT + tid] = rd;
+    }
+  };
+  TileRegs rq = tile_fetch(a.q, a.qs, qbeg, qlen, 0, hoff);
+  TileRegs ro = tile_fetch(a.dout, a.dos, qbeg, qlen, 0, hoff);
+  fetch_stats(0);
+  tile_store_split(rq, sq, QRh(0), QRl(0), QCh(0), QCl(0));
+  tile_store_split(ro, sdo, ORh(0), ORl(0), OCh(0), OCl(0));
+  store_stats(0);
+  __syncthreads();
+  for (int it = 0; it < ntile; ++it) {
+    const int buf = it & 1;
+    const bool more = it + 1 < ntile;
+    if (more) {
+      rq = tile_fetch(a.q, a.qs, qbeg, qlen, (it + 1) * BT, hoff);
+      ro = tile_fetch(a.dout, a.dos, qbeg, qlen, (it + 1) * BT, hoff);
+      fetch_stats((it + 1) * BT);
+    }
+    const f32x16 s = mm_rows_h(QRh(buf), QRl(buf), 32 * qb, l31, h, kh, kl);      // S'[query][key]
+    const f32x16 dp = mm_rows_h(ORh(buf), ORl(buf), 32 * qb, l31, h, vh, vl);     // dP' = dO V^T
+    f32x16 p, ds;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 l4 = *reinterpret_cast<const float4*>(&Lt[buf * BT + 32 * qb + 8 * g + 4 * h]);
+      const float4 d4 = *reinterpret_cast<const float4*>(&Dt[buf * BT + 32 * qb + 8 * g + 4 * h]);
+      const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int r = 4 * g + b;
+        const int qrow = it * BT + 32 * qb + 8 * g + 4 * h + b;
+        const float pv = (qrow < qlen && kvalid) ? __builtin_amdgcn_exp2f(s[r] * c - lv[b]) : 0.f;
+        p[r] = pv;
+        ds[r] = pv * (dp[r] - dv[b]);
+      }
+    }
+    {
+      h16x8 bh[2], bl[2];
+      acc_planes(p, P_MUL, bh, bl);
+      mm_cols_acc_h(acc_v, OCh(buf), OCl(buf), qb, l31, h, bh, bl);      // dV^T[d][key] += dO^T P
+      acc_planes(ds, DS_MUL, bh, bl);
+      mm_cols_acc_h(acc_k, QCh(buf), QCl(buf), qb, l31, h, bh, bl);      // dK^T[d][key] += Q^T dS
+    }
+    if (more) {
+      tile_store_split(rq, sq, QRh(buf ^ 1), QRl(buf ^ 1), QCh(buf ^ 1), QCl(buf ^ 1));
+      tile_store_split(ro, sdo, ORh(buf ^ 1), ORl(buf ^ 1), OCh(buf ^ 1), OCl(buf ^ 1));
+      store_stats(buf ^ 1);
+    }
+    __syncthreads();
+  }
+  float (*red_acc)[2][16][64] = reinterpret_cast<float (*)[2][16][64]>(dkv_smem);   // [2][2][16][64]: the tiles are done
+  if (qb == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      red_acc[0][kb][r][lane] = acc_v[r];
+      red_acc[1][kb][r][lane] = acc_k[r];
+    }
+  }
+  __syncthreads();
+  if (qb == 0 && kvalid) {
+    const float uv = 1.f / (sdo * P_MUL);
+    const float u0 = 2097152.f / sq, u1 = a.scale / (sv * sdo);
+    float* dv_dst = a.dv + (size_t)(kbeg + ki) * (a.nhead * BHD) + hoff + 4 * h;
+    float* dk_dst = a.dk + (size_t)(kbeg + ki) * (a.nhead * BHD) + hoff + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 o, w;
+      o.x = (acc_v[4 * g] + red_acc[0][kb][4 * g][lane]) * uv;
+      o.y = (acc_v[4 * g + 1] + red_acc[0][kb][4 * g + 1][lane]) * uv;
+      o.z = (acc_v[4 * g + 2] + red_acc[0][kb][4 * g + 2][lane]) * uv;
+      o.w = (acc_v[4 * g + 3] + red_acc[0][kb][4 * g + 3][lane]) * uv;
+      w.x = (acc_k[4 * g] + red_acc[1][kb][4 * g][lane]) * u0 * u1;
+      w.y = (acc_k[4 * g + 1] + red_acc[1][kb][4 * g + 1][lane]) * u0 * u1;
+      w.z = (acc_k[4 * g + 2] + red_acc[1][kb][4 * g + 2][lane]) * u0 * u1;
+      w.w = (acc_k[4 * g + 3] + red_acc[1][kb][4 * g + 3][lane]) * u0 * u1;
+      *reinterpret_cast<float4*>(dv_dst + 8 * g) = o;
+      *reinterpret_cast<float4*>(dk_dst + 8 * g) = w;
+    }
+  }
+}
+
 }  // namespace
 }  // namespace spr
 
 using namespace spr;
 
 extern "C" size_t spr_attn_bwd_workspace_bytes(int t, int nhead) {
-  return 2 * align_up((size_t)(t > 0 ? t : 1) * (size_t)(nhead > 0 ? nhead : 1) * sizeof(float), 256);
+  // lse, dsum [t, nhead]; four max-|x| partial arrays and the four operand scales of the split-fp16 form
+  return 2 * align_up((size_t)(t > 0 ? t : 1) * (size_t)(nhead > 0 ? nhead : 1) * sizeof(float), 256) +
+         align_up((size_t)4 * kAmaxParts * sizeof(float), 256) + 256;
 }
 
 // q, k, v, out (the forward's output), dout: [t, nhead * 32] with unit inner stride and the given row strides;
@@ -415,6 +820,26 @@ extern "C" int spr_attn_varlen_bwd(const float* q, int q_stride, const float* k,
   hipLaunchKernelGGL(k_attn_bwd_rowdot, dim3(cdiv((long)t * nhead, 256)), dim3(256), 0, stream, out, o_stride, dout,
                      do_stride, t, nhead, a.dsum);
   const dim3 grid(cdiv(max_len_host, BT), nhead, nseg);
+  if (attn_mode() != 0) {
+    // split-fp16 form: operand scales from the measured maxima of q, k, v, dO
+    float* parts = w.take<float>((size_t)4 * kAmaxParts);
+    float* scales = w.take<float>(4);
+    SPR_REQUIRE(scales != nullptr, "attn_bwd: workspace carve failed");
+    if (int rc = launch_absmax2(q, t, d, q_stride, parts, k, t, d, k_stride, parts + kAmaxParts, stream)) return rc;
+    if (int rc = launch_absmax2(v, t, d, v_stride, parts + 2 * kAmaxParts, dout, t, d, do_stride, parts + 3 * kAmaxParts,
+                                stream))
+      return rc;
+    hipLaunchKernelGGL(k_attn_bwd_scales, dim3(1), dim3(256), 0, stream, parts, scales);
+    hipLaunchKernelGGL(k_attn_bwd_dq_h, grid, dim3(256), 0, stream, a, scales);
+    constexpr size_t dkv_lds = (size_t)2 * DKV_BUF_HALVES * 2 + 4 * BT * sizeof(float);
+    static_assert(dkv_lds >= sizeof(float) * 2 * 2 * 16 * 64, "the final reduction reuses the tile buffers");
+    static const int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv_h),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dkv_lds);
+    SPR_REQUIRE(attr_rc == 0, "attn_bwd: cannot reserve %zu bytes of LDS", dkv_lds);
+    hipLaunchKernelGGL(k_attn_bwd_dkv_h, grid, dim3(256), dkv_lds, stream, a, scales);
+    SPR_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_attn_bwd_dq, grid, dim3(256), 0, stream, a);
   hipLaunchKernelGGL(k_attn_bwd_dkv, grid, dim3(256), 0, stream, a);
   SPR_LAUNCH_CHECK();

@@ -121,7 +121,15 @@ def test_kpconv_backward(device, tag):
     assert _rel(dw.grad, cw.grad) <= 2e-5, f"kpconv {tag} dW {_rel(dw.grad, cw.grad):.2e}"
 
 
-def test_attention_backward(device):
+@pytest.fixture(params=[1, 0], ids=["split-fp16", "exact-f32"])
+def attn_mode(request):
+    """Both arithmetic forms of the attention kernels (forward AND backward follow spr_set_attn_mode)."""
+    ops.set_attn_mode(request.param)
+    yield request.param
+    ops.set_attn_mode(1)
+
+
+def test_attention_backward(device, attn_mode):
     lens, kv_seg = [170, 33, 129, 65], [2, 3, 0, 1]
     tot = sum(lens)
     qkv = synthetic.rand((tot, 768), 9, -1.5, 1.5)
@@ -145,7 +153,40 @@ def test_attention_backward(device):
     assert _rel(dq.grad, cq.grad) <= 2e-5, f"attention dqkv {_rel(dq.grad, cq.grad):.2e}"
 
 
-def test_attention_backward_many_tiles_and_reproducible(device):
+def _attention_f64(q0, k0, v0, go, lens, kv_seg):
+    cq, ck, cv = (t.double().requires_grad_(True) for t in (q0, k0, v0))
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    outs = []
+    for s in range(len(lens)):
+        ks = kv_seg[s]
+        q = cq[offs[s]:offs[s + 1]].view(-1, 8, 32).transpose(0, 1)
+        k = ck[offs[ks]:offs[ks + 1]].view(-1, 8, 32).transpose(0, 1)
+        v = cv[offs[ks]:offs[ks + 1]].view(-1, 8, 32).transpose(0, 1)
+        a = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(32), -1)
+        outs.append((a @ v).transpose(0, 1).reshape(-1, 256))
+    torch.cat(outs).backward(go.double())
+    return cq.grad, ck.grad, cv.grad
+
+
+@pytest.mark.parametrize("qs,ks,vs,gs", [(1.0, 1.0, 1.0, 1.0), (1e-4, 3e3, 1e5, 1e-7), (40.0, 1.0, 1e-6, 1e6),
+                                         (6.0, 6.0, 1.0, 1.0)])
+def test_attention_backward_split_operand_ranges(device, qs, ks, vs, gs):
+    """The split-fp16 backward scales every operand by a measured power of two and dS by a static bound: operands
+    far from 1, and peaked softmax rows (|s| ~ 40: P ~ 1, the largest dS), keep the float32-level accuracy."""
+    lens, kv_seg = [200, 150, 70, 131], [1, 0, 3, 2]
+    tot = sum(lens)
+    q0, k0, v0 = (synthetic.rand((tot, 256), s, -1.0, 1.0) * m for s, m in ((31, qs), (32, ks), (33, vs)))
+    go = synthetic.rand((tot, 256), 34) * gs
+    cu = ops.lengths_to_cu(lens, device)
+    seg = torch.tensor(kv_seg, dtype=torch.int32, device=device)
+    lq, lk, lv = _leaf(q0, device), _leaf(k0, device), _leaf(v0, device)
+    ops.attention(lq, lk, lv, cu, seg, max(lens), 8, lens_host=lens, kv_seg_host=kv_seg).backward(go.to(device))
+    for got, ref, nm in zip((lq.grad, lk.grad, lv.grad), _attention_f64(q0, k0, v0, go, lens, kv_seg), "qkv"):
+        assert torch.isfinite(got).all()
+        assert _rel(got, ref) <= 2e-5, f"attention d{nm} at scales {(qs, ks, vs, gs)}: {_rel(got, ref):.2e}"
+
+
+def test_attention_backward_many_tiles_and_reproducible(device, attn_mode):
     """Several 64-row tiles per segment on both sides, self and cross segments of different lengths; two runs
     must agree bit for bit (fixed summation order: no atomics in spr_attn_varlen_bwd)."""
     lens, kv_seg = [450, 321, 64, 577], [1, 0, 3, 2]
@@ -161,19 +202,8 @@ def test_attention_backward_many_tiles_and_reproducible(device):
         grads.append((lq.grad.clone(), lk.grad.clone(), lv.grad.clone()))
     for a, b in zip(grads[0], grads[1]):
         assert torch.equal(a, b)
-    cq, ck, cv = (t.double().requires_grad_(True) for t in (q0, k0, v0))
-    offs = np.concatenate([[0], np.cumsum(lens)])
-    outs = []
-    for s in range(4):
-        ks = kv_seg[s]
-        q = cq[offs[s]:offs[s + 1]].view(-1, 8, 32).transpose(0, 1)
-        k = ck[offs[ks]:offs[ks + 1]].view(-1, 8, 32).transpose(0, 1)
-        v = cv[offs[ks]:offs[ks + 1]].view(-1, 8, 32).transpose(0, 1)
-        a = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(32), -1)
-        outs.append((a @ v).transpose(0, 1).reshape(-1, 256))
-    torch.cat(outs).backward(go.double())
-    for got, ref, nm in zip(grads[0], (cq.grad, ck.grad, cv.grad), "qkv"):
-        assert _rel(got, ref) <= 2e-5, f"attention d{nm} {_rel(got, ref):.2e}"      # exact-f32 products, fp32 softmax
+    for got, ref, nm in zip(grads[0], _attention_f64(q0, k0, v0, go, lens, kv_seg), "qkv"):
+        assert _rel(got, ref) <= 2e-5, f"attention d{nm} {_rel(got, ref):.2e}"      # both forms, fp32 softmax
 
 
 def test_procrustes_backward(device):
