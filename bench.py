@@ -64,7 +64,8 @@ def parse():
     ap.add_argument("--attn-mode", type=int, default=1,
                     help="1 = split-fp16 (default), 0 = exact f32, 2 = single-pass fp16 operands")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the training-step leg (N = 1 only)")
-    ap.add_argument("--train-pairs", type=int, default=4, help="pairs per training step of the train_step leg")
+    ap.add_argument("--train-pairs", type=int, default=16,
+                    help="pairs per training step of the train_step leg (16 fill the chip: 4 pairs run at 0.7x the rate)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the short exact-f32 and fp16-attention legs that follow the headline timing")
     ap.add_argument("--canonical-order", action="store_true",
@@ -181,9 +182,10 @@ def train_leg(cfg, args, dev):
                 stage_ms=dict(forward=round(stage[0] / steps, 2), loss=round(stage[1] / steps, 2),
                               backward=round(stage[2] / steps, 2), clip_adamw=round(stage[3] / steps, 2)),
                 loss_total=round(float(losses["total"].detach()), 5),
-                arithmetic="forward as the headline; backward: dX and dW of the projections and the KPConv dW in the forward's "
-                           "split-fp16 arithmetic; KPConv d(weighted features) and attention (flash-style, "
-                           "csrc/attention_bwd.hip) exact f32 MFMA")
+                arithmetic="forward as the headline (operator route: the fused cross-encoder chains are inference only); "
+                           "backward: dX / dW of the projections, the KPConv dW and d(weighted features) and the "
+                           "flash-style attention backward (csrc/attention_bwd.hip) all in the forward's range-scaled "
+                           "split-fp16 arithmetic; the loss-head products (InfoNCE, matching) exact f32 MFMA")
 
 
 def main():

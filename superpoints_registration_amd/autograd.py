@@ -192,8 +192,14 @@ class KPConvFn(torch.autograd.Function):
         wflat = w.detach().contiguous().view(n_kp * cin, cout)
         dx = dw = None
         if ctx.needs_input_grad[3]:
-            dwf = torch.empty((nq, n_kp * cin), dtype=torch.float32, device=x.device)
-            bgemm(g, wflat, dwf, [(0, 0, 0, nq, n_kp * cin, cout)], (cout, 1), (1, cout), (n_kp * cin, 1))
+            if _ops._modes["gemm"] == 1 and cout % 32 == 0:
+                # d wf = g W_flat^T is the forward's NT product with W_flat [15 cin, cout] as the weight: the
+                # range-scaled split-fp16 MFMA path (g's range is measured once, dW below reuses it)
+                _ops.ensure_range(g)
+                dwf = _ops.linear_raw(g, wflat)
+            else:
+                dwf = torch.empty((nq, n_kp * cin), dtype=torch.float32, device=x.device)
+                bgemm(g, wflat, dwf, [(0, 0, 0, nq, n_kp * cin, cout)], (cout, 1), (1, cout), (n_kp * cin, 1))
             dx = torch.empty((ns, cin), dtype=torch.float32, device=x.device)
             ws = _ops._workspace(L.spr_scatter_workspace_bytes(ns, cin), x.device)
             _lib.check(L.spr_kpconv_bwd_dx(_ops._ptr(q_pts), nq, _ops._ptr(s_pts), ns, _ops._ptr(nbr32), int(stride), kmax,
