@@ -170,22 +170,28 @@ __global__ __launch_bounds__(256) void k_scatter_rows_add(const float* __restric
 }
 
 // ---- KPConv backward helpers (kpconv_blocks.py:309-412) --------------------------------------
-// One wave per query.  Per neighbour the 15 influence weights are computed by lanes 0..14 and
-// broadcast through LDS; lanes then walk the channels.
+// One wave per query.
 //   WF mode : wf[n, p * cin + c] = sum_k infl[p][k] x[idx[n,k], c]     (recomputed forward, un-normalised)
-//             cnt[n] = max(1, #{k : sum_c x[idx[n,k], :] > 0})          (flag from k_rowflag-like pass)
+//             cnt[n] = max(1, #{k : sum_c x[idx[n,k], :] > 0})
 //   DX mode : dx[idx[n,k], c] += sum_p infl[p][k] dwf[n, p * cin + c]
 constexpr int kKPmax = 16;
-template <bool DX>
-__global__ __launch_bounds__(256) void k_kpconv_aux(const float* __restrict__ q_xyz, int nq,
-                                                    const float* __restrict__ s_xyz, int ns,
-                                                    const int* __restrict__ nbr, int nbr_stride, int kmax,
-                                                    const float* __restrict__ x, int cin,
-                                                    const float* __restrict__ kpts, int n_kp, float inv_extent,
-                                                    const float* __restrict__ dwf, float* __restrict__ wf,
-                                                    float* __restrict__ cnt_out, const float* __restrict__ parts,
-                                                    unsigned long long* __restrict__ dx_acc) {
-  __shared__ float infl[4][kKPmax];
+// The influence weights of up to 64 neighbours are computed side by side (lane =
+// neighbour: id, support point, 15 distances) and parked in LDS, then the lanes walk the channels with one
+// broadcast read of a neighbour's 16 weights per 15 FMAs -- the per-neighbour dependent chain (id -> point ->
+// sqrt -> LDS -> barrier) of the round-3 form is gone: the 16-pair training step 154 -> 145 ms.  HALF (cin == 32): the
+// two half-waves take the even / odd neighbours and are summed at the end.  cin == 1: everything stays in the
+// neighbour lanes (15 wave sums).
+template <bool DX, bool HALF>
+__global__ __launch_bounds__(256) void k_kpconv_aux2(const float* __restrict__ q_xyz, int nq,
+                                                     const float* __restrict__ s_xyz, int ns,
+                                                     const int* __restrict__ nbr, int nbr_stride, int kmax,
+                                                     const float* __restrict__ x, int cin,
+                                                     const float* __restrict__ kpts, int n_kp, float inv_extent,
+                                                     const float* __restrict__ dwf, float* __restrict__ wf,
+                                                     float* __restrict__ cnt_out, const float* __restrict__ parts,
+                                                     unsigned long long* __restrict__ dx_acc) {
+  __shared__ __align__(16) float infl_s[4][64][kKPmax];
+  __shared__ int id_s[4][64];
   int fx = 0;
   if (DX) {   // |sum_p infl[p] dwf[p]| <= n_kp max |dwf|
     __shared__ float sh[17];
@@ -195,59 +201,129 @@ __global__ __launch_bounds__(256) void k_kpconv_aux(const float* __restrict__ q_
   const int n = blockIdx.x * 4 + wave;
   if (n >= nq) return;   // whole wave
   const float qx = q_xyz[3 * (size_t)n], qy = q_xyz[3 * (size_t)n + 1], qz = q_xyz[3 * (size_t)n + 2];
-  float kx = 0.f, ky = 0.f, kz = 0.f;
-  if (lane < n_kp) {
-    kx = kpts[3 * lane];
-    ky = kpts[3 * lane + 1];
-    kz = kpts[3 * lane + 2];
-  }
-  const int nchunk = (cin + 63) / 64;
+  const int half = HALF ? lane >> 5 : 0;
+  const int cl = HALF ? lane & 31 : lane;
+  const int nchunk = HALF ? 1 : (cin + 63) / 64;
   int cnt = 0;
-  for (int c0 = 0; c0 < nchunk; ++c0) {
-    const int c = c0 * 64 + lane;
-    const bool cok = c < cin;
-    float acc[kKPmax];
+  float acc1[kKPmax];          // cin == 1: per-neighbour-lane partial sums
 #pragma unroll
-    for (int p = 0; p < kKPmax; ++p) acc[p] = 0.f;
-    float dw[kKPmax];
-    if (DX) {
-#pragma unroll
-      for (int p = 0; p < kKPmax; ++p) dw[p] = (cok && p < n_kp) ? dwf[((size_t)n * n_kp + p) * cin + c] : 0.f;
-    }
-    for (int k = 0; k < kmax; ++k) {
-      const int id = nbr[(size_t)n * nbr_stride + k];
-      const bool ok = id >= 0 && id < ns;
-      if (!ok) continue;   // wave uniform
-      if (lane < n_kp) {
-        const float dx_ = (s_xyz[3 * (size_t)id] - qx) - kx, dy_ = (s_xyz[3 * (size_t)id + 1] - qy) - ky,
-                    dz_ = (s_xyz[3 * (size_t)id + 2] - qz) - kz;
-        infl[wave][lane] = fmaxf(0.f, 1.f - sqrtf(dx_ * dx_ + dy_ * dy_ + dz_ * dz_) * inv_extent);
+  for (int p = 0; p < kKPmax; ++p) acc1[p] = 0.f;
+  for (int kb = 0; kb < kmax; kb += 64) {
+    // ---- phase A: lane = neighbour ----
+    const int kk = kb + lane;
+    int id = kk < kmax ? nbr[(size_t)n * nbr_stride + kk] : -1;
+    const bool ok = id >= 0 && id < ns;
+    if (!ok) id = -1;
+    float w[kKPmax];
+    {
+      float px = 0.f, py = 0.f, pz = 0.f;
+      if (ok) {
+        px = s_xyz[3 * (size_t)id] - qx;
+        py = s_xyz[3 * (size_t)id + 1] - qy;
+        pz = s_xyz[3 * (size_t)id + 2] - qz;
       }
-      __builtin_amdgcn_wave_barrier();
-      if (DX) {
+#pragma unroll
+      for (int p = 0; p < kKPmax; ++p) {
         float v = 0.f;
-#pragma unroll
-        for (int p = 0; p < kKPmax; ++p)
-          if (p < n_kp) v += infl[wave][p] * dw[p];
-        if (cok && v != 0.f) fx_add(dx_acc + (size_t)id * cin + c, v, fx);
-      } else {
-        const float xv = cok ? x[(size_t)id * cin + c] : 0.f;
-#pragma unroll
-        for (int p = 0; p < kKPmax; ++p)
-          if (p < n_kp) acc[p] += infl[wave][p] * xv;
-        if (c0 == 0) {   // neighbour count of the reference: rows whose feature sum is > 0
-          float s = 0.f;
-          for (int cc = lane; cc < cin; cc += 64) s += x[(size_t)id * cin + cc];
-          s = wave_sum(s);
-          cnt += s > 0.f ? 1 : 0;
+        if (p < n_kp) {
+          const float dx_ = px - kpts[3 * p], dy_ = py - kpts[3 * p + 1], dz_ = pz - kpts[3 * p + 2];
+          v = ok ? fmaxf(0.f, 1.f - sqrtf(dx_ * dx_ + dy_ * dy_ + dz_ * dz_) * inv_extent) : 0.f;
+        }
+        w[p] = v;
+      }
+    }
+    if (!DX) {   // neighbour count of the reference: rows whose feature sum is > 0
+      float s = 0.f;
+      if (ok) {
+        const float* xr = x + (size_t)id * cin;
+        if ((cin & 3) == 0) {
+          for (int c = 0; c < cin; c += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + c);
+            s += (v.x + v.y) + (v.z + v.w);
+          }
+        } else {
+          for (int c = 0; c < cin; ++c) s += xr[c];
         }
       }
-      __builtin_amdgcn_wave_barrier();
+      cnt += __builtin_popcountll(__builtin_amdgcn_ballot_w64(ok && s > 0.f));
     }
-    if (!DX && cok) {
+    if (cin == 1) {
+      if (!DX) {
+        const float xv = ok ? x[id] : 0.f;
 #pragma unroll
-      for (int p = 0; p < kKPmax; ++p)
-        if (p < n_kp) wf[((size_t)n * n_kp + p) * cin + c] = acc[p];
+        for (int p = 0; p < kKPmax; ++p) acc1[p] += w[p] * xv;
+        continue;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();      // the previous chunk's reads are done (one wave: program order)
+#pragma unroll
+    for (int p4 = 0; p4 < kKPmax / 4; ++p4)
+      *reinterpret_cast<float4*>(&infl_s[wave][lane][4 * p4]) = make_float4(w[4 * p4], w[4 * p4 + 1], w[4 * p4 + 2], w[4 * p4 + 3]);
+    id_s[wave][lane] = id;
+    __builtin_amdgcn_wave_barrier();
+    const int nk = min(64, kmax - kb);
+    // ---- phase B: lane = channel ----
+    for (int c0 = 0; c0 < nchunk; ++c0) {
+      const int c = c0 * 64 + cl;
+      const bool cok = c < cin;
+      float acc[kKPmax];
+#pragma unroll
+      for (int p = 0; p < kKPmax; ++p) acc[p] = 0.f;
+      if (DX) {
+#pragma unroll
+        for (int p = 0; p < kKPmax; ++p) acc[p] = (cok && p < n_kp) ? dwf[((size_t)n * n_kp + p) * cin + c] : 0.f;
+      }
+      const int step = HALF ? 2 : 1;
+#pragma unroll 2
+      for (int k0 = 0; k0 < nk; k0 += step) {
+        const int k = k0 + half;
+        const int idk = k < nk ? id_s[wave][k] : -1;
+        if (!HALF && idk < 0) continue;     // wave uniform
+        const bool use = idk >= 0 && cok;
+        float iw[kKPmax];
+#pragma unroll
+        for (int p4 = 0; p4 < kKPmax / 4; ++p4) {
+          const float4 v = *reinterpret_cast<const float4*>(&infl_s[wave][k & 63][4 * p4]);
+          iw[4 * p4] = v.x;
+          iw[4 * p4 + 1] = v.y;
+          iw[4 * p4 + 2] = v.z;
+          iw[4 * p4 + 3] = v.w;
+        }
+        if (DX) {
+          float v = 0.f;
+#pragma unroll
+          for (int p = 0; p < kKPmax; ++p)
+            if (p < n_kp) v += iw[p] * acc[p];
+          if (use && v != 0.f) fx_add(dx_acc + (size_t)idk * cin + c, v, fx);
+        } else {
+          const float xv = use ? x[(size_t)idk * cin + c] : 0.f;
+#pragma unroll
+          for (int p = 0; p < kKPmax; ++p)
+            if (p < n_kp) acc[p] += iw[p] * xv;
+        }
+      }
+      if (!DX) {
+        if (HALF) {
+#pragma unroll
+          for (int p = 0; p < kKPmax; ++p) acc[p] += __shfl_xor(acc[p], 32, 64);
+        }
+        // (kmax <= 64: one chunk, plain store; more: later chunks add to what the first wrote)
+        if (cok && half == 0) {
+#pragma unroll
+          for (int p = 0; p < kKPmax; ++p)
+            if (p < n_kp) {
+              float* dst = wf + ((size_t)n * n_kp + p) * cin + c;
+              *dst = kb == 0 ? acc[p] : *dst + acc[p];
+            }
+        }
+      }
+    }
+  }
+  if (!DX && cin == 1) {
+#pragma unroll
+    for (int p = 0; p < kKPmax; ++p) {
+      const float t = wave_sum(acc1[p]);
+      if (p < n_kp && lane == 0) wf[(size_t)n * n_kp + p] = t;
     }
   }
   if (!DX && lane == 0) cnt_out[n] = (float)(cnt > 1 ? cnt : 1);
@@ -397,9 +473,14 @@ extern "C" int spr_kpconv_weighted_features(const float* q_xyz, int nq, const fl
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(nq > 0 && ns > 0 && cin >= 1 && n_kp >= 1 && n_kp <= kKPmax && kp_extent > 0.f && kmax >= 1 &&
                   kmax <= nbr_stride, "kpconv_weighted_features: bad arguments");
-  hipLaunchKernelGGL(k_kpconv_aux<false>, dim3(cdiv(nq, 4)), dim3(256), 0, stream, q_xyz, nq, s_xyz, ns, nbr,
-                     nbr_stride, kmax, x, cin, kernel_points, n_kp, 1.0f / kp_extent, (const float*)nullptr, wf, cnt,
-                     (const float*)nullptr, (unsigned long long*)nullptr);
+  if (cin == 32)
+    hipLaunchKernelGGL((k_kpconv_aux2<false, true>), dim3(cdiv(nq, 4)), dim3(256), 0, stream, q_xyz, nq, s_xyz, ns, nbr,
+                       nbr_stride, kmax, x, cin, kernel_points, n_kp, 1.0f / kp_extent, (const float*)nullptr, wf, cnt,
+                       (const float*)nullptr, (unsigned long long*)nullptr);
+  else
+    hipLaunchKernelGGL((k_kpconv_aux2<false, false>), dim3(cdiv(nq, 4)), dim3(256), 0, stream, q_xyz, nq, s_xyz, ns, nbr,
+                       nbr_stride, kmax, x, cin, kernel_points, n_kp, 1.0f / kp_extent, (const float*)nullptr, wf, cnt,
+                       (const float*)nullptr, (unsigned long long*)nullptr);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -415,9 +496,14 @@ extern "C" int spr_kpconv_bwd_dx(const float* q_xyz, int nq, const float* s_xyz,
   FxScratch f;
   if (int rc = fx_scratch(ws, ws_bytes, ns, cin, stream, &f)) return rc;
   if (int rc = launch_absmax(dwf, nq, n_kp * cin, n_kp * cin, f.parts, stream)) return rc;
-  hipLaunchKernelGGL(k_kpconv_aux<true>, dim3(cdiv(nq, 4)), dim3(256), 0, stream, q_xyz, nq, s_xyz, ns, nbr,
-                     nbr_stride, kmax, (const float*)nullptr, cin, kernel_points, n_kp, 1.0f / kp_extent, dwf,
-                     (float*)nullptr, (float*)nullptr, f.parts, f.acc);
+  if (cin == 32)
+    hipLaunchKernelGGL((k_kpconv_aux2<true, true>), dim3(cdiv(nq, 4)), dim3(256), 0, stream, q_xyz, nq, s_xyz, ns, nbr,
+                       nbr_stride, kmax, (const float*)nullptr, cin, kernel_points, n_kp, 1.0f / kp_extent, dwf,
+                       (float*)nullptr, (float*)nullptr, f.parts, f.acc);
+  else
+    hipLaunchKernelGGL((k_kpconv_aux2<true, false>), dim3(cdiv(nq, 4)), dim3(256), 0, stream, q_xyz, nq, s_xyz, ns, nbr,
+                       nbr_stride, kmax, (const float*)nullptr, cin, kernel_points, n_kp, 1.0f / kp_extent, dwf,
+                       (float*)nullptr, (float*)nullptr, f.parts, f.acc);
   hipLaunchKernelGGL(k_fx_to_float, dim3(cdiv((long)ns * cin, 256)), dim3(256), 0, stream, f.acc, (long)ns * cin,
                      f.parts, (float)n_kp, dx);
   SPR_LAUNCH_CHECK();
