@@ -483,6 +483,14 @@ extern "C" int spr_bgemm(const float* A, const float* B, float* C, const void* d
   if (force != 64 && max_m >= 128 && max_n >= 96) {
     const long tiles = (long)cdiv(max_m, 128) * cdiv(max_n, 128);
     SPR_REQUIRE(tiles < (1l << 31), "bgemm: grid too large");
+    if (tiles * nbatch < 160) {
+      // fewer tiles than compute units (the per-pair products of the loss heads: 38 tiles): half-height tiles
+      const long tiles64 = (long)cdiv(max_m, 64) * cdiv(max_n, 128);
+      hipLaunchKernelGGL((k_bgemm_f32_t<64, 128>), dim3((unsigned)tiles64, nbatch), dim3(256), 0, stream, A, B, C,
+                         (const BgemmDesc*)desc_dev, sa_i, sa_k, sb_k, sb_j, sc_i, sc_j, alpha, beta);
+      SPR_LAUNCH_CHECK();
+      return 0;
+    }
     hipLaunchKernelGGL((k_bgemm_f32_t<128, 128>), dim3((unsigned)tiles, nbatch), dim3(256), 0, stream, A, B, C,
                        (const BgemmDesc*)desc_dev, sa_i, sa_k, sb_k, sb_j, sc_i, sc_j, alpha, beta);
     SPR_LAUNCH_CHECK();
