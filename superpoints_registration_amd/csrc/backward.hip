@@ -22,7 +22,7 @@ __global__ void k_act_bwd(const float* __restrict__ y, const float* __restrict__
 }
 
 // column sums of x [m, n] over a fixed number of row chunks: parts [nchunk][n]
-constexpr int kColChunks = 128;
+constexpr int kColChunks = 512;
 __global__ __launch_bounds__(256) void k_colsum_parts(const float* __restrict__ x, long m, int n,
                                                       float* __restrict__ parts) {
   const int chunk = blockIdx.y;
@@ -33,6 +33,45 @@ __global__ __launch_bounds__(256) void k_colsum_parts(const float* __restrict__ 
   float s = 0.f;
   for (long r = r0; r < r1; ++r) s += x[r * n + j];
   parts[(long)chunk * n + j] = s;
+}
+// the same for n | 1024 (every bias of the model): the block sweeps the matrix as a flat float4 stream -- 4 KB per
+// step whatever n is (the column-per-thread form above kept 32 of 256 threads busy for n = 32) -- each thread
+// stays on its four columns, threads of equal columns are summed through LDS in a fixed order.
+__global__ __launch_bounds__(256) void k_colsum_flat(const float* __restrict__ x, long m, int n,
+                                                     float* __restrict__ parts) {
+  __shared__ float4 sh[256];
+  const long total4 = m * n / 4;
+  const long steps = (total4 + 255) / 256;
+  const long per = (steps + kColChunks - 1) / kColChunks;
+  const long s0 = (long)blockIdx.x * per, s1 = s0 + per < steps ? s0 + per : steps;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  long st = s0;
+  for (; st + 1 < s1; st += 2) {
+    const long f0 = st * 256 + threadIdx.x, f1 = f0 + 256;
+    const float4 u = x4[f0];                       // f0 < total4: st is not the last step
+    const float4 v = f1 < total4 ? x4[f1] : make_float4(0.f, 0.f, 0.f, 0.f);
+    a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+    b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+  }
+  if (st < s1) {
+    const long f0 = st * 256 + threadIdx.x;
+    if (f0 < total4) {
+      const float4 u = x4[f0];
+      a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+    }
+  }
+  sh[threadIdx.x] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  __syncthreads();
+  const int ng = n / 4;
+  if ((int)threadIdx.x < ng) {
+    float4 t = sh[threadIdx.x];
+    for (int k = threadIdx.x + ng; k < 256; k += ng) {
+      const float4 v = sh[k];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4*>(parts + (long)blockIdx.x * n + 4 * threadIdx.x) = t;
+  }
 }
 
 // ---- LayerNorm backward (transformers.py:121,:196-197: y = LN(x) gamma + beta; optional second
@@ -383,7 +422,10 @@ extern "C" int spr_colsum(const float* x, long m, int n, float* out, void* ws, s
   SPR_REQUIRE(x && out && m >= 1 && n >= 1, "colsum: bad arguments");
   SPR_REQUIRE(ws && ws_bytes >= spr_colsum_workspace_bytes(n), "colsum: workspace too small");
   float* parts = (float*)ws;
-  hipLaunchKernelGGL(k_colsum_parts, dim3(cdiv(n, 256), kColChunks), dim3(256), 0, stream, x, m, n, parts);
+  if (n >= 4 && 1024 % n == 0 && ((uintptr_t)x & 15) == 0)
+    hipLaunchKernelGGL(k_colsum_flat, dim3(kColChunks), dim3(256), 0, stream, x, (long)m, n, parts);
+  else
+    hipLaunchKernelGGL(k_colsum_parts, dim3(cdiv(n, 256), kColChunks), dim3(256), 0, stream, x, m, n, parts);
   SPR_LAUNCH_CHECK();
   return spr_reduce_parts(parts, kColChunks, n, 1.0f, out, 0, stream_);
 }
