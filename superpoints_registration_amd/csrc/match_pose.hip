@@ -38,9 +38,19 @@ struct PairDesc {
 // ---- row / column log-sum-exp over the scaled correlation ------------------
 // lse over j of (c[i][j]*scale - sub[j])   (sub may be NULL); optionally +1
 // inside the log-sum (the slack entry exp(0)).
+// The potentials are float in the forward and double in the backward (PT): the gradients of alpha / beta sum N x M
+// terms that cancel down to the slack mass, and an error of 1e-7 in u_i or v_j moves a whole row / column of them
+// together -- with float potentials d alpha was off by 4e-4, with double ones by 3e-5 (the terms themselves stay
+// float: their rounding errors are independent and average out).
+__device__ __forceinline__ float wave_sum_t(float v) { return wave_sum(v); }
+__device__ __forceinline__ double wave_sum_t(double v) { return wave_sum_d(v); }
+__device__ __forceinline__ float lse_log(float s) { return logf(s); }
+__device__ __forceinline__ double lse_log(double s) { return log(s); }
+
+template <typename PT>
 __global__ void k_row_lse(const float* __restrict__ mat, const PairDesc* __restrict__ pd,
-                          float* __restrict__ row_out /*packed by src token*/,
-                          const float* __restrict__ col_sub /*packed by tgt token*/, int slack) {
+                          PT* __restrict__ row_out /*packed by src token*/,
+                          const PT* __restrict__ col_sub /*packed by tgt token*/, int slack) {
   const PairDesc p = pd[blockIdx.y];
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
@@ -48,39 +58,43 @@ __global__ void k_row_lse(const float* __restrict__ mat, const PairDesc* __restr
   const float* r = mat + p.off + (size_t)row * p.m;
   float mx = slack ? 0.f : -INFINITY;
   for (int j = lane; j < p.m; j += 64) {
-    const float v = r[j] - (col_sub ? col_sub[p.tgt_beg + j] : 0.f);
+    const float v = (float)((PT)r[j] - (col_sub ? col_sub[p.tgt_beg + j] : (PT)0));
     mx = fmaxf(mx, v);
   }
   mx = wave_max(mx);
-  float s = 0.f;
+  PT s = 0;
   for (int j = lane; j < p.m; j += 64) {
-    const float v = r[j] - (col_sub ? col_sub[p.tgt_beg + j] : 0.f);
-    s += expf(v - mx);
+    const PT v = (PT)r[j] - (col_sub ? col_sub[p.tgt_beg + j] : (PT)0);
+    s += (PT)expf((float)(v - (PT)mx));
   }
-  s = wave_sum(s);
-  if (slack) s += expf(0.f - mx);
-  if (lane == 0) row_out[p.src_beg + row] = mx + logf(s);
+  s = wave_sum_t(s);
+  if (slack) s += (PT)expf(0.f - mx);
+  if (lane == 0) row_out[p.src_beg + row] = (PT)mx + lse_log(s);
 }
 
 // block = 1024 threads: 64 columns x 16 row lanes
 constexpr int kColLanes = 16;
+template <typename PT>
 __global__ __launch_bounds__(1024) void k_col_lse(const float* __restrict__ mat,
                                                  const PairDesc* __restrict__ pd,
-                                                 float* __restrict__ col_out,
-                                                 const float* __restrict__ row_sub, int slack) {
+                                                 PT* __restrict__ col_out,
+                                                 const PT* __restrict__ row_sub, int slack) {
   const PairDesc p = pd[blockIdx.y];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
-  __shared__ float smx[kColLanes][64], ssum[kColLanes][64];
-  float mx = -INFINITY, s = 0.f;
+  __shared__ float smx[kColLanes][64];
+  __shared__ PT ssum[kColLanes][64];
+  float mx = -INFINITY;
+  PT s = 0;
   if (col < p.m) {
     for (int i = rl; i < p.n; i += kColLanes) {
-      const float v = mat[p.off + (size_t)i * p.m + col] - (row_sub ? row_sub[p.src_beg + i] : 0.f);
+      const PT vd = (PT)mat[p.off + (size_t)i * p.m + col] - (row_sub ? row_sub[p.src_beg + i] : (PT)0);
+      const float v = (float)vd;
       if (v > mx) {
-        s = s * expf(mx - v) + 1.f;
+        s = s * (PT)expf(mx - v) + (PT)expf((float)(vd - (PT)v));
         mx = v;
       } else {
-        s += expf(v - mx);
+        s += (PT)expf((float)(vd - (PT)mx));
       }
     }
   }
@@ -90,11 +104,168 @@ __global__ __launch_bounds__(1024) void k_col_lse(const float* __restrict__ mat,
   if (rl == 0 && col < p.m) {
     float M = slack ? 0.f : -INFINITY;
     for (int k = 0; k < kColLanes; ++k) M = fmaxf(M, smx[k][cl]);
-    float S = slack ? expf(0.f - M) : 0.f;
+    PT S = slack ? (PT)expf(0.f - M) : (PT)0;
     for (int k = 0; k < kColLanes; ++k)
-      if (smx[k][cl] > -INFINITY) S += ssum[k][cl] * expf(smx[k][cl] - M);
-    col_out[p.tgt_beg + col] = M + logf(S);
+      if (smx[k][cl] > -INFINITY) S += ssum[k][cl] * (PT)expf(smx[k][cl] - M);
+    col_out[p.tgt_beg + col] = (PT)M + lse_log(S);
   }
+}
+
+// e^x through v_exp_f32 with the argument x log2(e) formed in two pieces (the product's rounding error, up to
+// 2^-24 |x| log2 e, would otherwise show as a relative error of 4e-6 at |x| = 60): ~1.5 ulp, three instructions
+// where expf() spends a dozen on range reduction these passes do not need (x <= 0 here, e^-126 may flush)
+__device__ __forceinline__ float exp_neg(float x) {
+  x = fmaxf(x, -200.f);                                                       // -inf (masked entries) -> e^-200 = 0
+  const float hi = x * 1.44269502162933349609375f;                           // fl32(log2 e)
+  const float lo = __builtin_fmaf(x, 1.44269502162933349609375f, -hi);       // product residue (exact)
+  return __builtin_amdgcn_exp2f(hi + __builtin_fmaf(x, 1.92596299112661746e-8f, lo));   // + x (log2 e - fl32)
+}
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// one wave per row, the whole row (M <= 256 RV) held in registers between the max and the sum
+template <int RV, typename PT>
+__global__ __launch_bounds__(256) void k_row_lse_v(const float* __restrict__ mat, const PairDesc* __restrict__ pd,
+                                                   PT* __restrict__ row_out, const PT* __restrict__ col_sub,
+                                                   int slack) {
+  const PairDesc p = pd[blockIdx.y];
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= p.n) return;
+  const float* r = mat + p.off + (size_t)row * p.m;
+  const PT* cs = col_sub ? col_sub + p.tgt_beg : nullptr;
+  PT v[RV][4];
+  float mx = slack ? 0.f : -INFINITY;
+#pragma unroll
+  for (int i = 0; i < RV; ++i) {
+    const int j = 4 * (lane + 64 * i);
+    if (j + 3 < p.m) {
+      typedef PT pt4u __attribute__((ext_vector_type(4), aligned(sizeof(PT))));
+      const f4u a = *reinterpret_cast<const f4u*>(r + j);
+      pt4u b = {0, 0, 0, 0};
+      if (cs) b = *reinterpret_cast<const pt4u*>(cs + j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = (PT)a[e] - b[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[i][e] = j + e < p.m ? (PT)r[j + e] - (cs ? cs[j + e] : (PT)0) : (PT)-INFINITY;
+    }
+    mx = fmaxf(mx, fmaxf(fmaxf((float)v[i][0], (float)v[i][1]), fmaxf((float)v[i][2], (float)v[i][3])));
+  }
+  mx = wave_max(mx);
+  PT s = 0;
+#pragma unroll
+  for (int i = 0; i < RV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += (PT)exp_neg((float)(v[i][e] - (PT)mx));      // columns past the end: e^-inf = 0
+  s = wave_sum_t(s);
+  if (slack) s += (PT)expf(0.f - mx);
+  if (lane == 0) row_out[p.src_beg + row] = (PT)mx + lse_log(s);
+}
+
+// block = 512 threads: 16 column quads (64 columns) x 32 row lanes; four rows in flight per thread, one
+// running maximum per column that moves at most once per four rows
+constexpr int kColLanesVV = 32;
+template <typename PT>
+__global__ __launch_bounds__(512) void k_col_lse_v(const float* __restrict__ mat, const PairDesc* __restrict__ pd,
+                                                  PT* __restrict__ col_out, const PT* __restrict__ row_sub,
+                                                  int slack) {
+  const PairDesc p = pd[blockIdx.y];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + 4 * cl;
+  __shared__ float smx[kColLanesV][64];
+  __shared__ PT ssum[kColLanesV][64];
+  float mx[4];
+  PT s[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    mx[e] = -INFINITY;
+    s[e] = 0;
+  }
+  if (col < p.m) {
+    // branch-free loads (four rows in flight need their loads back to back): the row index is clamped and masked
+    // afterwards; the last, partial column quad reads the row's last four columns and shifts
+    const int shift = col + 3 < p.m ? 0 : col - (p.m - 4);          // 0, or 1..3 for the partial quad (M >= 4)
+    const float* base = mat + p.off + (col - shift);
+    const PT* rs = row_sub ? row_sub + p.src_beg : nullptr;
+    for (int i0 = rl; i0 < p.n; i0 += 4 * kColLanesV) {
+      f4u a[4];
+      PT sub[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = min(i0 + q * kColLanesV, p.n - 1);
+        a[q] = *reinterpret_cast<const f4u*>(base + (size_t)i * p.m);
+        sub[q] = rs ? rs[i] : (PT)0;
+      }
+      PT v[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool rok = i0 + q * kColLanesV < p.n;
+        const float t0 = shift == 0 ? a[q][0] : shift == 1 ? a[q][1] : shift == 2 ? a[q][2] : a[q][3];
+        const float t1 = shift == 0 ? a[q][1] : shift == 1 ? a[q][2] : shift == 2 ? a[q][3] : INFINITY;
+        const float t2 = shift == 0 ? a[q][2] : shift == 1 ? a[q][3] : INFINITY;
+        const float t3 = shift == 0 ? a[q][3] : INFINITY;
+        v[q][0] = rok ? (PT)t0 - sub[q] : (PT)-INFINITY;
+        v[q][1] = rok && t1 < INFINITY ? (PT)t1 - sub[q] : (PT)-INFINITY;
+        v[q][2] = rok && t2 < INFINITY ? (PT)t2 - sub[q] : (PT)-INFINITY;
+        v[q][3] = rok && t3 < INFINITY ? (PT)t3 - sub[q] : (PT)-INFINITY;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float m4 = fmaxf(fmaxf((float)v[0][e], (float)v[1][e]), fmaxf((float)v[2][e], (float)v[3][e]));
+        if (m4 > mx[e]) {
+          s[e] *= (PT)exp_neg(mx[e] - m4);        // first time: 0 * exp(-inf) = 0
+          mx[e] = m4;
+        }
+        if (mx[e] > -INFINITY) {
+          const PT m = (PT)mx[e];
+          s[e] += ((PT)exp_neg((float)(v[0][e] - m)) + (PT)exp_neg((float)(v[1][e] - m))) +
+                  ((PT)exp_neg((float)(v[2][e] - m)) + (PT)exp_neg((float)(v[3][e] - m)));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    smx[rl][4 * cl + e] = mx[e];
+    ssum[rl][4 * cl + e] = s[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < p.m) {
+      float M = slack ? 0.f : -INFINITY;
+      for (int k = 0; k < kColLanesV; ++k) M = fmaxf(M, smx[k][threadIdx.x]);
+      PT S = slack ? (PT)expf(0.f - M) : (PT)0;
+      for (int k = 0; k < kColLanesV; ++k)
+        if (smx[k][threadIdx.x] > -INFINITY) S += ssum[k][threadIdx.x] * (PT)expf(smx[k][threadIdx.x] - M);
+      col_out[p.tgt_beg + c] = (PT)M + lse_log(S);
+    }
+  }
+}
+
+// launches of the two passes for `np` pairs starting at descriptor pg
+template <typename PT>
+void launch_row_lse(const float* mat, const PairDesc* pg, int np, int max_n, int max_m, PT* out, const PT* col_sub,
+                    int slack, hipStream_t stream) {
+  const dim3 grid(cdiv((long)max_n * 64, 256), np);
+  if (max_m <= 1024)
+    hipLaunchKernelGGL((k_row_lse_v<4, PT>), grid, dim3(256), 0, stream, mat, pg, out, col_sub, slack);
+  else if (max_m <= 2048)
+    hipLaunchKernelGGL((k_row_lse_v<8, PT>), grid, dim3(256), 0, stream, mat, pg, out, col_sub, slack);
+  else if (max_m <= 4096 && sizeof(PT) == 4)
+    hipLaunchKernelGGL((k_row_lse_v<16, float>), grid, dim3(256), 0, stream, mat, pg, (float*)out, (const float*)col_sub, slack);
+  else
+    hipLaunchKernelGGL(k_row_lse<PT>, grid, dim3(256), 0, stream, mat, pg, out, col_sub, slack);
+}
+template <typename PT>
+void launch_col_lse(const float* mat, const PairDesc* pg, int np, int max_m, PT* out, const PT* row_sub, int slack,
+                    hipStream_t stream, int min_m) {
+  if (min_m < 4) {   // (a pair with fewer than four target tokens: the one-column-per-thread form)
+    hipLaunchKernelGGL(k_col_lse<PT>, dim3(cdiv(max_m, 64), np), dim3(1024), 0, stream, mat, pg, out, row_sub, slack);
+    return;
+  }
+  hipLaunchKernelGGL(k_col_lse_v<PT>, dim3(cdiv(max_m, 64), np), dim3(16 * kColLanesV), 0, stream, mat, pg, out, row_sub, slack);
 }
 
 // ---- dual softmax arg-max ---------------------------------------------------
@@ -605,20 +776,20 @@ __global__ __launch_bounds__(256) void k_procrustes_bwd(const float* __restrict_
 // Final step, row part: Y_ij = gP_ij P_ij with gP_ij = dw_i + dthat_i . (tgt_j - that_i) / (w_i + 1e-6);
 // dA = Y, du_i = -sum_j Y_ij.   One wave per src row.
 __global__ void k_sk_bwd_final(const float* __restrict__ mat, float* __restrict__ dmat,
-                               const PairDesc* __restrict__ pd, const float* __restrict__ u,
-                               const float* __restrict__ v, const float* __restrict__ xyz,
+                               const PairDesc* __restrict__ pd, const double* __restrict__ u,
+                               const double* __restrict__ v, const float* __restrict__ xyz,
                                const float* __restrict__ dw, const float* __restrict__ dthat,
                                float* __restrict__ du) {
   const PairDesc p = pd[blockIdx.y];
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (row >= p.n) return;
   const int gi = p.src_beg + row;
-  const float ui = u[gi];
+  const double ui = u[gi];
   const float* ar = mat + p.off + (size_t)row * p.m;
   float* dr = dmat + p.off + (size_t)row * p.m;
   float wsum = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
   for (int j = lane; j < p.m; j += 64) {
-    const float pij = expf(ar[j] - ui - v[p.tgt_beg + j]);
+    const float pij = expf((float)((double)ar[j] - ui - v[p.tgt_beg + j]));
     const float* t = xyz + 3 * (size_t)(p.tgt_beg + j);
     wsum += pij;
     tx += pij * t[0];
@@ -634,7 +805,7 @@ __global__ void k_sk_bwd_final(const float* __restrict__ mat, float* __restrict_
   const float gw = dw[gi], gx = dthat[3 * (size_t)gi], gy = dthat[3 * (size_t)gi + 1], gz = dthat[3 * (size_t)gi + 2];
   float s = 0.f;
   for (int j = lane; j < p.m; j += 64) {
-    const float pij = expf(ar[j] - ui - v[p.tgt_beg + j]);
+    const float pij = expf((float)((double)ar[j] - ui - v[p.tgt_beg + j]));
     const float* t = xyz + 3 * (size_t)(p.tgt_beg + j);
     const float gp = gw + (gx * (t[0] - hx) + gy * (t[1] - hy) + gz * (t[2] - hz)) / dn;
     const float y = gp * pij;
@@ -665,18 +836,18 @@ __global__ __launch_bounds__(1024) void k_sk_colsum_neg(const float* __restrict_
 // column step of iteration t (v_t from u_t): C_ij = e^{A_ij - u_i - v_j}; dA_ij += dv_j C_ij;
 // du_i -= sum_j dv_j C_ij.   One wave per src row.
 __global__ void k_sk_bwd_col(const float* __restrict__ mat, float* __restrict__ dmat,
-                             const PairDesc* __restrict__ pd, const float* __restrict__ u,
-                             const float* __restrict__ v, const float* __restrict__ dv, float* __restrict__ du) {
+                             const PairDesc* __restrict__ pd, const double* __restrict__ u,
+                             const double* __restrict__ v, const float* __restrict__ dv, float* __restrict__ du) {
   const PairDesc p = pd[blockIdx.y];
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (row >= p.n) return;
   const int gi = p.src_beg + row;
-  const float ui = u[gi];
+  const double ui = u[gi];
   const float* ar = mat + p.off + (size_t)row * p.m;
   float* dr = dmat + p.off + (size_t)row * p.m;
   float s = 0.f;
   for (int j = lane; j < p.m; j += 64) {
-    const float c = dv[p.tgt_beg + j] * expf(ar[j] - ui - v[p.tgt_beg + j]);
+    const float c = dv[p.tgt_beg + j] * expf((float)((double)ar[j] - ui - v[p.tgt_beg + j]));
     dr[j] += c;
     s += c;
   }
@@ -686,8 +857,8 @@ __global__ void k_sk_bwd_col(const float* __restrict__ mat, float* __restrict__ 
 // row step of iteration t (u_t from v_{t-1}): R_ij = e^{A_ij - v_j - u_i}; dA_ij += du_i R_ij;
 // dv_prev_j = -sum_i du_i R_ij  (written, not accumulated: v_{t-1} has no other consumer).
 __global__ __launch_bounds__(1024) void k_sk_bwd_row(const float* __restrict__ mat, float* __restrict__ dmat,
-                                                    const PairDesc* __restrict__ pd, const float* __restrict__ u,
-                                                    const float* __restrict__ vprev,
+                                                    const PairDesc* __restrict__ pd, const double* __restrict__ u,
+                                                    const double* __restrict__ vprev,
                                                     const float* __restrict__ du, float* __restrict__ dvprev) {
   const PairDesc p = pd[blockIdx.y];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -695,10 +866,10 @@ __global__ __launch_bounds__(1024) void k_sk_bwd_row(const float* __restrict__ m
   __shared__ float ss[kColLanes][64];
   float s = 0.f;
   if (col < p.m) {
-    const float vj = vprev ? vprev[p.tgt_beg + col] : 0.f;
+    const double vj = vprev ? vprev[p.tgt_beg + col] : 0.0;
     for (int i = rl; i < p.n; i += kColLanes) {
       const size_t o = p.off + (size_t)i * p.m + col;
-      const float r = du[p.src_beg + i] * expf(mat[o] - vj - u[p.src_beg + i]);
+      const float r = du[p.src_beg + i] * expf((float)((double)mat[o] - vj - u[p.src_beg + i]));
       dmat[o] += r;
       s += r;
     }
@@ -858,7 +1029,7 @@ struct Corr {
   GemmGroup* gg;
   std::vector<PairDesc> h;
   long long total;
-  int max_n, max_m, per_group, ngroups;
+  int max_n, max_m, min_m, per_group, ngroups;
   bool grouped;
   const float *sparts, *tparts;
   int first(int g) const { return g * per_group; }
@@ -882,10 +1053,12 @@ int corr_setup(Corr& c, const float* feat, int d, const int* cu_dev, const int* 
   SPR_REQUIRE(c.mat && c.pd, "match: workspace carve failed");
   c.max_n = 0;
   c.max_m = 0;
+  c.min_m = 1 << 30;
   for (int b = 0; b < npairs; ++b) {
     SPR_REQUIRE(c.h[b].n > 0 && c.h[b].m > 0, "match: empty cloud in pair %d", b);
     c.max_n = c.h[b].n > c.max_n ? c.h[b].n : c.max_n;
     c.max_m = c.h[b].m > c.max_m ? c.h[b].m : c.max_m;
+    c.min_m = c.h[b].m < c.min_m ? c.h[b].m : c.min_m;
   }
   static const long long budget = [] { const char* e = getenv("SPR_MATCH_GROUP_MB"); return (long long)(e ? atoi(e) : 250) << 20; }();
   const long long pair_bytes = (long long)c.max_n * c.max_m * 4;
@@ -966,10 +1139,8 @@ extern "C" int spr_match_dualsoftmax2(const float* feat, int d, const int* cu, c
       const long long cnt = c.end(g) - c.beg(g);
       hipLaunchKernelGGL(k_scale, dim3(cdiv(cnt, 256)), dim3(256), 0, stream, c.mat + c.beg(g), cnt, scale);
     }
-    hipLaunchKernelGGL(k_row_lse, dim3(cdiv((long)c.max_n * 64, 256), np), dim3(256), 0, stream, c.mat, pg, row_lse,
-                       (const float*)nullptr, 0);
-    hipLaunchKernelGGL(k_col_lse, dim3(cdiv(c.max_m, 64), np), dim3(1024), 0, stream, c.mat, pg, col_lse,
-                       (const float*)nullptr, 0);
+    launch_row_lse<float>(c.mat, pg, np, c.max_n, c.max_m, row_lse, nullptr, 0, stream);
+    launch_col_lse<float>(c.mat, pg, np, c.max_m, col_lse, nullptr, 0, stream, c.min_m);
     hipLaunchKernelGGL(k_match_cols, dim3(cdiv(c.max_m, 64), np), dim3(1024), 0, stream, c.mat, pg, row_lse, col_lse,
                        match_val, match_ind, match_val2);
     hipLaunchKernelGGL(k_match_rows, dim3(cdiv((long)c.max_n * 64, 256), np), dim3(256), 0, stream, c.mat, pg, row_lse,
@@ -1038,9 +1209,8 @@ extern "C" int spr_sinkhorn_correspondences(const float* feat, int d, const floa
                          beta);
     }
     for (int it = 0; it < n_iters; ++it) {
-      hipLaunchKernelGGL(k_row_lse, dim3(cdiv((long)c.max_n * 64, 256), np), dim3(256), 0, stream, c.mat, pg, u,
-                         (const float*)v, 1);
-      hipLaunchKernelGGL(k_col_lse, dim3(cdiv(c.max_m, 64), np), dim3(1024), 0, stream, c.mat, pg, v, (const float*)u, 1);
+      launch_row_lse<float>(c.mat, pg, np, c.max_n, c.max_m, u, v, 1, stream);
+      launch_col_lse<float>(c.mat, pg, np, c.max_m, v, (const float*)u, 1, stream, c.min_m);
     }
     hipLaunchKernelGGL(k_sinkhorn_final, dim3(cdiv((long)c.max_n * 64, 256), np), dim3(256), 0, stream, c.mat, pg, u, v,
                        xyz, out_w, out_that);
@@ -1080,7 +1250,7 @@ extern "C" size_t spr_sinkhorn_bwd_workspace_bytes(const int* cu_host, int npair
   }
   const int it = n_iters > 0 ? n_iters : 1;
   return 3 * align_up((size_t)off * 4, 256) + align_up(sizeof(PairDesc) * npairs, 256) +
-         2 * align_up(sizeof(GemmRec) * npairs, 256) + (size_t)(2 * it + 4) * align_up((size_t)tmax * 4, 256) +
+         2 * align_up(sizeof(GemmRec) * npairs, 256) + (size_t)(4 * it + 5) * align_up((size_t)tmax * 4, 256) + 1024 +
          2 * align_up(kAmaxParts * sizeof(float), 256) + align_up(2 * 1024 * sizeof(double), 256) + 2048;
 }
 
@@ -1116,41 +1286,41 @@ extern "C" int spr_sinkhorn_bwd(const float* feat, int d, const float* xyz, cons
   GemmRec* rs = w.take<GemmRec>(npairs);
   GemmRec* rt = w.take<GemmRec>(npairs);
   const int it_n = n_iters > 0 ? n_iters : 1;
-  float* U = w.take<float>((size_t)it_n * T);
-  float* V = w.take<float>((size_t)it_n * T);
+  double* U = w.take<double>((size_t)it_n * T);      // potentials in double (see k_row_lse)
+  double* V = w.take<double>((size_t)it_n * T);
   float* du = w.take<float>(T);
   float* dva = w.take<float>(T);
   float* dvb = w.take<float>(T);
-  float* zero = w.take<float>(T);
+  double* zero = w.take<double>(T);
   double* parts = w.take<double>(2 * 1024);
   SPR_REQUIRE(parts != nullptr, "sinkhorn_bwd: workspace carve failed");
   const float scale = 1.0f / sqrtf((float)d);
   SPR_HIP_CHECK(hipMemsetAsync(dmat, 0, sizeof(float) * (size_t)total, stream));
   SPR_HIP_CHECK(hipMemcpyAsync(corr, mat, sizeof(float) * (size_t)total, hipMemcpyDeviceToDevice, stream));
   hipLaunchKernelGGL(k_affinity, dim3(cdiv(total, 256)), dim3(256), 0, stream, mat, total, scale, alpha, beta);
-  SPR_HIP_CHECK(hipMemsetAsync(zero, 0, sizeof(float) * T, stream));
+  SPR_HIP_CHECK(hipMemsetAsync(zero, 0, sizeof(double) * T, stream));
   const dim3 grow(cdiv((long)max_n * 64, 256), npairs), gcol(cdiv(max_m, 64), npairs);
   // forward potentials, every iteration kept
   for (int it = 0; it < n_iters; ++it) {
-    const float* vprev = it == 0 ? zero : V + (size_t)(it - 1) * T;
-    hipLaunchKernelGGL(k_row_lse, grow, dim3(256), 0, stream, mat, pd, U + (size_t)it * T, vprev, 1);
-    hipLaunchKernelGGL(k_col_lse, gcol, dim3(1024), 0, stream, mat, pd, V + (size_t)it * T,
-                       (const float*)(U + (size_t)it * T), 1);
+    const double* vprev = it == 0 ? zero : V + (size_t)(it - 1) * T;
+    launch_row_lse<double>(mat, pd, npairs, max_n, max_m, U + (size_t)it * T, vprev, 1, stream);
+    launch_col_lse<double>(mat, pd, npairs, max_m, V + (size_t)it * T, (const double*)(U + (size_t)it * T), 1, stream,
+                           cc.min_m);
   }
-  const float* un = n_iters > 0 ? U + (size_t)(n_iters - 1) * T : zero;
-  const float* vn = n_iters > 0 ? V + (size_t)(n_iters - 1) * T : zero;
+  const double* un = n_iters > 0 ? U + (size_t)(n_iters - 1) * T : zero;
+  const double* vn = n_iters > 0 ? V + (size_t)(n_iters - 1) * T : zero;
   // final step: dA = gP * P, du_n, dv_n
   hipLaunchKernelGGL(k_sk_bwd_final, grow, dim3(256), 0, stream, mat, dmat, pd, un, vn, xyz, dw, dthat, du);
   hipLaunchKernelGGL(k_sk_colsum_neg, gcol, dim3(1024), 0, stream, dmat, pd, dva);
   float* dv_cur = dva;
   float* dv_prev = dvb;
   for (int it = n_iters - 1; it >= 0; --it) {
-    const float* ut = U + (size_t)it * T;
-    const float* vt = V + (size_t)it * T;
+    const double* ut = U + (size_t)it * T;
+    const double* vt = V + (size_t)it * T;
     // v_t = colLSE(A - u_t): adds to dA and to du_t
     hipLaunchKernelGGL(k_sk_bwd_col, grow, dim3(256), 0, stream, mat, dmat, pd, ut, vt, (const float*)dv_cur, du);
     // u_t = rowLSE(A - v_{t-1}): adds to dA, produces dv_{t-1} (v_0 = 0 is a constant)
-    const float* vprev = it == 0 ? nullptr : V + (size_t)(it - 1) * T;
+    const double* vprev = it == 0 ? nullptr : V + (size_t)(it - 1) * T;
     hipLaunchKernelGGL(k_sk_bwd_row, gcol, dim3(1024), 0, stream, mat, dmat, pd, ut, vprev, (const float*)du,
                        it == 0 ? (float*)nullptr : dv_prev);
     if (it > 0) {

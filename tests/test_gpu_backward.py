@@ -339,7 +339,7 @@ def test_parameter_gradients_match_the_reference(device, tag, which):
       * outside the KPConv encoder (transformer, projections, loss parameters):
         | ||g|| - ||r|| | <= 1e-4 ||r|| and every pinned entry within 1e-4 of the tensor's scale;
       * KPConv-encoder tensors and the two Sinkhorn scalars alpha / beta (sums over all N x M
-        affinities): norm within 5e-4 (2e-3 for the scalars), RMS deviation of the pinned entries
+        affinities): norm within 5e-4 (1e-3 for the scalars), RMS deviation of the pinned entries
         <= 2e-2 of their RMS; at most half of the encoder tensors may exceed the 1e-4 entry bound.
     Why the encoder is different: its gradients pass through LeakyReLU / max-pool / K-nearest
     DECISIONS.  Our forward agrees with the reference to ~1e-6; an activation that close to zero
@@ -373,8 +373,8 @@ def test_parameter_gradients_match_the_reference(device, tag, which):
         rms = np.sqrt(np.mean((got_e - ref_e) ** 2)) / max(np.sqrt(np.mean(ref_e ** 2)), 1e-30)
         nerr = abs(np.linalg.norm(gr) - ref_norm) / max(ref_norm, 1e-30)
         n_checked += 1
-        if name in ("alpha", "beta"):
-            assert nerr <= 2e-3, f"{tag}/{which} {name}: deviates by {nerr:.2e}"
+        if name in ("alpha", "beta"):        # (round 4: Sinkhorn potentials of the backward in float64; observed <= 6e-4)
+            assert nerr <= 1e-3, f"{tag}/{which} {name}: deviates by {nerr:.2e}"
         elif name.startswith("kpf_encoder."):
             n_enc += 1
             enc_loose += err > 1e-4
