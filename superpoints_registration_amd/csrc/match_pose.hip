@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void k_row_lse_v(const float* __restrict__ mat
 
 // block = 512 threads: 16 column quads (64 columns) x 32 row lanes; four rows in flight per thread, one
 // running maximum per column that moves at most once per four rows
-constexpr int kColLanesVV = 32;
+constexpr int kColLanesV = 32;
 template <typename PT>
 __global__ __launch_bounds__(512) void k_col_lse_v(const float* __restrict__ mat, const PairDesc* __restrict__ pd,
                                                   PT* __restrict__ col_out, const PT* __restrict__ row_sub,
