@@ -818,6 +818,18 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
   static const int nq = [] { const char* e = getenv("SPR_ATTN_NQ"); return (e != nullptr && e[0] == '2') ? 2 : 1; }();
   if (nq == 1) {
     dim3 grid1(cdiv(max_len_host, QB2 / 2) * nhead * nseg);
+    // experiment switch (profiles/r04_attn_counters.txt): the same kernel compiled for FOUR waves per SIMD
+    static const bool wps4 = [] { const char* e = getenv("SPR_ATTN_WPS"); return e != nullptr && e[0] == '4'; }();
+    if (wps4) {
+      if (mode == 2)
+        hipLaunchKernelGGL((k_attn_h3<false, true, 1, 4>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
+                           pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+      else
+        hipLaunchKernelGGL((k_attn_h3<true, true, 1, 4>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
+                           pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+      SPR_LAUNCH_CHECK();
+      return 0;
+    }
     if (mode == 2)
       hipLaunchKernelGGL((k_attn_h3<false, true, 1, 3>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
                          pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
