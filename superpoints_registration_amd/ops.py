@@ -789,6 +789,18 @@ class XencPlan:
     def __init__(self, key, prepared, plan, keep):
         self.key, self.prepared, self.plan, self.keep = key, prepared, plan, keep
 
+    # The host plan holds device addresses inside `prepared`: a copy must not outlive the original.  A copied or
+    # unpickled module simply has no plan and builds its own on first use (copy.deepcopy(model), torch.save(model)).
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (_no_plan, ())
+
+
+def _no_plan():
+    return None
+
 
 def xenc_available() -> bool:
     return _XENC_ON and _modes["gemm"] == 1 and _modes["attn"] in (1, 2)

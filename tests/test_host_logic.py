@@ -207,3 +207,15 @@ def test_segment_permutation_and_its_inverse():
     kv, inv = ops._segment_perms([2, 0, 3, 1], "cpu")
     assert inv.tolist() == [1, 3, 0, 2] and all(kv[inv[k]] == k for k in range(4))
     assert ops._segment_perms([2, 0, 3, 1], "cpu")[0] is kv     # cached per permutation and device
+
+
+def test_prepared_encoder_plan_does_not_travel_with_copies():
+    """ops.XencPlan (prepared weights of the fused cross-encoder chains) holds device addresses: a deep copy or a
+    pickle of a module that carries one gets no plan and rebuilds its own on first use."""
+    import copy
+    import pickle
+    from superpoints_registration_amd import ops
+    plan = ops.XencPlan(("key",), object(), object(), [])
+    holder = {"_spr_xenc": plan, "other": 3}
+    assert copy.deepcopy(holder) == {"_spr_xenc": None, "other": 3}
+    assert pickle.loads(pickle.dumps(plan)) is None
