@@ -105,6 +105,25 @@ def _tn_product(L, Rm, rows, nl, nr, f64=False):
     return _reduce_parts(parts, nchunk, nl * nr, out)
 
 
+def _nn_product(A, B, n, k, d):
+    """out[n, d] = A[n, k] @ B[k, d] (row-major, contiguous, exact f32).  A product whose output is a handful of
+    tiles but whose contraction is long (the per-pair loss-head products: 38 tiles, k ~ 1 500) is split over k into
+    batches of one launch + the fixed-order reduction of the weight gradients: the chip is filled and the K loop
+    is a quarter as long.  The split is a function of the shapes only (bitwise reproducible)."""
+    tiles = ((n + 127) // 128) * ((d + 127) // 128)
+    nsplit = max(1, min(8, k // 256, 256 // max(tiles, 1)))
+    if nsplit == 1:
+        out = torch.empty((n, d), dtype=torch.float32, device=A.device)
+        return bgemm(A, B, out, [(0, 0, 0, n, d, k)], (k, 1), (d, 1), (d, 1))
+    chunk = ((k + nsplit - 1) // nsplit + 15) // 16 * 16
+    nsplit = (k + chunk - 1) // chunk
+    parts = torch.empty((nsplit, n, d), dtype=torch.float32, device=A.device)
+    recs = [(c * chunk, c * chunk * d, c * n * d, n, d, min(chunk, k - c * chunk)) for c in range(nsplit)]
+    bgemm(A, B, parts, recs, (k, 1), (d, 1), (d, 1))
+    out = torch.empty((n, d), dtype=torch.float32, device=A.device)
+    return _reduce_parts(parts, nsplit, n * d, out)
+
+
 def _colsum(x):
     m, n = x.shape
     L = _lib.lib()
@@ -535,8 +554,7 @@ class InfoNCEFn(torch.autograd.Function):
                                               _ops._ptr(wsym), _ops._ptr(t), _ops._ptr(ws), ws.numel(), _ops._stream(a)),
                    "spr_infonce_pair_dlogits")
         dl = (dl * (gout / mask.sum())).contiguous()
-        dt = torch.empty((n, d), dtype=torch.float32, device=dev)          # d(A W_sym) = dl B
-        bgemm(dl, p, dt, [(0, 0, 0, n, d, m)], (m, 1), (d, 1), (d, 1))
+        dt = _nn_product(dl, p, n, m, d)                                    # d(A W_sym) = dl B
         da = torch.empty((n, d), dtype=torch.float32, device=dev)          # dA = dt W_sym^T = dt W_sym
         bgemm(dt, wsym, da, [(0, 0, 0, n, d, d)], (d, 1), (d, 1), (d, 1))
         # dB = dl^T t and dW_sym = A^T dt contract over the n anchors into small outputs ([m, d], [d, d] = 24 and 4

@@ -33,7 +33,7 @@ namespace {
 
 struct BgemmDesc {
   long long a_off, b_off, c_off;
-  int m, n, k, pad;
+  int m, n, k, pad;   // pad: 0, or the leading dimension of A for this batch
 };
 
 constexpr int TB = 64;    // output tile edge
@@ -47,6 +47,12 @@ __global__ __launch_bounds__(256) void k_bgemm_f32(const float* __restrict__ A, 
   __shared__ float As[KB * LDT];   // [k][i]
   __shared__ float Bs[KB * LDT];   // [k][j]
   const BgemmDesc d = desc[blockIdx.y];
+  // per-batch leading dimension of A (d.pad > 0): replaces whichever A stride is not 1 -- batches whose matrices have
+  // their own row length (the per-pair score matrices) then fit one launch
+  if (d.pad > 0) {
+    if (sa_k == 1) sa_i = d.pad;
+    else sa_k = d.pad;
+  }
   const int tn = (d.n + TB - 1) / TB, tm = (d.m + TB - 1) / TB;
   const int tile = blockIdx.x;
   if (tile >= tn * tm) return;
@@ -126,6 +132,12 @@ __global__ __launch_bounds__(256) void k_bgemm_f32_t(const float* __restrict__ A
   __shared__ float As[2][KB * LDA];   // [k][i]
   __shared__ float Bs[2][KB * LDB];   // [k][j]
   const BgemmDesc d = desc[blockIdx.y];
+  // per-batch leading dimension of A (d.pad > 0): replaces whichever A stride is not 1 -- batches whose matrices have
+  // their own row length (the per-pair score matrices) then fit one launch
+  if (d.pad > 0) {
+    if (sa_k == 1) sa_i = d.pad;
+    else sa_k = d.pad;
+  }
   const int tn = (d.n + TN - 1) / TN, tm = (d.m + TM - 1) / TM;
   const int tile = blockIdx.x;
   if (tile >= tn * tm) return;

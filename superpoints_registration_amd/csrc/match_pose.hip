@@ -932,9 +932,9 @@ __global__ void k_build_grad_recs(const PairDesc* __restrict__ pd, int npairs, i
   if (b >= npairs) return;
   const PairDesc p = pd[b];
   // dFs[n, d] = dcorr[n, m] Ft[m, d]
-  rs[b] = GemmRec{p.off, (long long)p.tgt_beg * d, (long long)p.src_beg * d, p.n, d, p.m, 0};
+  rs[b] = GemmRec{p.off, (long long)p.tgt_beg * d, (long long)p.src_beg * d, p.n, d, p.m, p.m};   // pad = lda
   // dFt[m, d] = dcorr^T[m, n] Fs[n, d]
-  rt[b] = GemmRec{p.off, (long long)p.src_beg * d, (long long)p.tgt_beg * d, p.m, d, p.n, 0};
+  rt[b] = GemmRec{p.off, (long long)p.src_beg * d, (long long)p.tgt_beg * d, p.m, d, p.n, p.m};
 }
 
 int build_pairs(const int* cu_host, int npairs, PairDesc* h, long long* total) {
@@ -1335,13 +1335,12 @@ extern "C" int spr_sinkhorn_bwd(const float* feat, int d, const float* xyz, cons
   const int nparts = 1024;
   hipLaunchKernelGGL(k_affinity_bwd, dim3(nparts), dim3(256), 0, stream, corr, mat, dmat, total, scale, beta, parts);
   hipLaunchKernelGGL(k_affinity_bwd_final, dim3(1), dim3(64), 0, stream, parts, nparts, alpha, beta, dalpha, dbeta);
-  // correlation -> features: dFs = dcorr Ft, dFt = dcorr^T Fs (exact-f32 batched GEMM, one launch per pair
-  // because the matrix row stride is the pair's own M)
+  // correlation -> features: dFs = dcorr Ft, dFt = dcorr^T Fs (exact-f32 batched GEMM)
   hipLaunchKernelGGL(k_build_grad_recs, dim3(cdiv(npairs, 64)), dim3(64), 0, stream, pd, npairs, d, rs, rt);
   SPR_LAUNCH_CHECK();
-  for (int b = 0; b < npairs; ++b) {
-    if (int rc = spr_bgemm(dmat, feat, dfeat, rs + b, 1, h[b].n, d, h[b].m, 1, d, 1, d, 1, 1.0f, 0.0f, stream_)) return rc;
-    if (int rc = spr_bgemm(dmat, feat, dfeat, rt + b, 1, h[b].m, d, 1, h[b].m, d, 1, d, 1, 1.0f, 0.0f, stream_)) return rc;
-  }
+  // all pairs in one launch per product: the records carry each pair's own leading dimension (BgemmDesc.pad), a
+  // pair alone is 38 tiles of 128 x 128
+  if (int rc = spr_bgemm(dmat, feat, dfeat, rs, npairs, max_n, d, max_m, 1, d, 1, d, 1, 1.0f, 0.0f, stream_)) return rc;
+  if (int rc = spr_bgemm(dmat, feat, dfeat, rt, npairs, max_m, d, 1, max_m, d, 1, d, 1, 1.0f, 0.0f, stream_)) return rc;
   return 0;
 }
