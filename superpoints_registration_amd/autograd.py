@@ -417,7 +417,7 @@ class SinkhornFn(torch.autograd.Function):
         dev = feat.device
         ws = _ops._workspace(L.spr_sinkhorn_bwd_workspace_bytes(arr, npairs, n_iters), dev)
         T, d = feat.shape
-        dfeat = torch.zeros((T, d), dtype=torch.float32, device=dev)
+        dfeat = torch.empty((T, d), dtype=torch.float32, device=dev)
         dal = torch.zeros((1,), dtype=torch.float32, device=dev)
         dbe = torch.zeros((1,), dtype=torch.float32, device=dev)
         a_t, b_t = _ops._dev_scalar(alpha, dev), _ops._dev_scalar(beta, dev)

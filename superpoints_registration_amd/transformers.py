@@ -194,8 +194,12 @@ class TransformerCrossEncoder(nn.Module):
         self.return_intermediate = return_intermediate
 
     # -- fused stack (csrc/xenc.hip): two attention cores + two row-chain kernels per layer ---------
-    def _xenc_eligible(self, x, pos, pos_bound) -> bool:
+    def _xenc_eligible(self, x, pos, pos_bound, nseg: int = 0) -> bool:
         if pos is None or pos_bound is None or not ops.xenc_available() or x.shape[1] != 256:
+            return False
+        # the chains keep cu_seqlens and the tile prefix of every segment in LDS behind the 128 KB weight ring
+        # (csrc/xenc.hip xenc_lds_bytes: 23 232 bytes for 4 d_ff + 8 (segments + 1))
+        if 4 * max(l.linear1.out_features for l in self.layers) + 8 * (nseg + 1) > 23232:
             return False
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False                                  # training: the differentiable per-operator route
@@ -221,7 +225,7 @@ class TransformerCrossEncoder(nn.Module):
         """pos_bound: an upper bound of max |pos| the caller guarantees (1.0 for the sine embedding).  With it
         (and the shipped layer configuration, inference) the stack runs as the fused chains of csrc/xenc.hip;
         without it operator by operator."""
-        if self._xenc_eligible(x, pos, pos_bound):
+        if self._xenc_eligible(x, pos, pos_bound, int(cu.numel()) - 1):
             return ops.xenc_forward(self._xenc_plan(float(pos_bound)), x, pos, cu, seg_self, seg_cross, max_len)
         for layer in self.layers:
             x = layer.forward_packed(x, cu, seg_self, seg_cross, max_len, pos=pos, seg_host=seg_host)

@@ -135,3 +135,23 @@ def test_operand_magnitudes(device):
             fused = enc.forward_packed(x, cu, s_self, s_cross, mx, pos=pos, pos_bound=1.0)
         ref = _oracle64(enc, x, pos, s_l, t_l)
         _close(fused.cpu().numpy(), ref, 2e-5, f"fused stack, x scale {xs}, w scale {ws}")
+
+
+def test_many_small_segments(device):
+    """Hundreds of tiny clouds (one tile each, most of it empty) through the fused route; beyond the LDS tables'
+    capacity (cu_seqlens + tile prefix live behind the weight ring) the stack falls back to the operators."""
+    enc = _encoder(device, 1, 64, True)
+    g = torch.Generator().manual_seed(13)
+    for npairs, fused_expected in ((300, True), (1500, False)):
+        s_l = [int(v) for v in torch.randint(1, 9, (npairs,), generator=g)]
+        t_l = [int(v) for v in torch.randint(1, 9, (npairs,), generator=g)]
+        T = sum(s_l) + sum(t_l)
+        x = torch.randn(T, 256, generator=g).to(device)
+        pos = torch.rand(T, 256, generator=g).mul(2).sub(1).to(device)
+        cu, s_self, s_cross, mx = make_segments(s_l, t_l, device)
+        enc._spr_xenc = None
+        with torch.no_grad():
+            y = enc.forward_packed(x, cu, s_self, s_cross, mx, pos=pos, pos_bound=1.0)
+            assert (enc._spr_xenc is not None) == fused_expected
+            plain = enc.forward_packed(x, cu, s_self, s_cross, mx, pos=pos)
+        _close(y.cpu().numpy(), plain.cpu().numpy(), 5e-6, f"{2 * npairs} segments")
