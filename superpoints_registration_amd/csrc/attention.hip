@@ -352,7 +352,7 @@ __device__ __forceinline__ float half_swap_max(float x) {
 // NQ = 32-query blocks per wave: 2 (default: 64 queries per wave, 256 per workgroup, ~250 VGPRs, two waves per
 // SIMD) or 1 (32 queries per wave, 128 per workgroup, <= 128 VGPRs: four waves per SIMD -- the same instruction
 // stream at twice the occupancy; K / V^T fragments are then read from LDS twice as often per query).
-template <bool H3, bool LAZY = false, int NQ = 2, int WPS = (NQ == 1 ? 3 : 2)>
+template <bool H3, bool LAZY = false, int NQ = 2, int WPS = (NQ == 1 ? 3 : 2), bool PIPE = false>
 __global__ __launch_bounds__(256, WPS) void k_attn_h3(
     const _Float16* __restrict__ qh_g, const _Float16* __restrict__ ql_g,
     const _Float16* __restrict__ kh_g, const _Float16* __restrict__ kl_g,
@@ -656,6 +656,145 @@ __global__ __launch_bounds__(256, WPS) void k_attn_h3(
     }
   };
 
+  // PIPE (NQ = 1, lazy softmax): the same tile as two 32-key halves whose phases are staggered inside the wave --
+  // the score MFMAs of half 1 are independent of the exponentials of half 0, and the PV MFMAs of half 0 of the
+  // exponentials of half 1, so 12 of the tile's 24 MFMAs have vector work of the same wave to run beside.  The lazy
+  // reference is checked per half; a recentring at half 1 finds the probabilities of half 0 already converted: its
+  // shift is rounded up to an integer so that they can be rescaled exactly (a power of two) in their fp16 planes.
+  auto tile_pipe = [&](int kt, int buf, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    constexpr float kLazyOff = 4.0f;
+    h16x8 kfh[2], kfl[2], vfh[2], vfl[2];
+    auto load_kf = [&](int kk) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        kfh[s] = *reinterpret_cast<const h16x8*>(Kh[buf] + (32 * kk + l31) * KH + 16 * s + 8 * lh);
+        if constexpr (H3) kfl[s] = *reinterpret_cast<const h16x8*>(Kl[buf] + (32 * kk + l31) * KH + 16 * s + 8 * lh);
+      }
+    };
+    auto load_vf = [&](int kk) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const _Float16* ph_ = Vth[buf] + l31 * VH + 32 * kk + 16 * s + 4 * lh;
+        const _Float16* pl_ = Vtl[buf] + l31 * VH + 32 * kk + 16 * s + 4 * lh;
+        const h16x4 a0 = *reinterpret_cast<const h16x4*>(ph_);
+        const h16x4 a1 = *reinterpret_cast<const h16x4*>(ph_ + 8);
+        vfh[s] = (h16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        if constexpr (H3) {
+          const h16x4 b0 = *reinterpret_cast<const h16x4*>(pl_);
+          const h16x4 b1 = *reinterpret_cast<const h16x4*>(pl_ + 8);
+          vfl[s] = (h16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        }
+      }
+    };
+    auto scores = [&](f32x16& acc) __attribute__((always_inline)) {
+      acc = negm[0];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if constexpr (H3) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], ql[0][s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[s], qh[0][s], acc, 0, 0, 0);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], qh[0][s], acc, 0, 0, 0);
+      }
+    };
+    auto rowmax = [&](f32x16& acc, int kk) __attribute__((always_inline)) {
+      if (TAIL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = kt + 32 * kk + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (j >= klen) acc[r] = -INFINITY;
+        }
+      }
+      float mx = fmaxf(acc[0], acc[1]);
+#pragma unroll
+      for (int r = 2; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+      return half_swap_max(mx);
+    };
+    auto convert = [&](const f32x16& acc, unsigned int (&ph)[8], unsigned int (&pl)[8]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(acc[r]), p1 = __builtin_amdgcn_exp2f(acc[r + 1]);
+        psum_a[0] += p0;
+        psum_b[0] += p1;
+        const unsigned int hi_u = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(p0, p1));
+        ph[r >> 1] = hi_u;
+        if constexpr (H3) {
+          unsigned int lo_u;
+          asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+              "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+              : "=&v"(lo_u)
+              : "v"(hi_u), "v"(p0), "v"(p1));
+          pl[r >> 1] = lo_u;
+        }
+      }
+    };
+    auto pv = [&](const unsigned int (&ph)[8], const unsigned int (&pl)[8]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const u32x4 pa = {ph[4 * s], ph[4 * s + 1], ph[4 * s + 2], ph[4 * s + 3]};
+        const h16x8 pbh = __builtin_bit_cast(h16x8, pa);
+        if constexpr (H3) {
+          const u32x4 pb = {pl[4 * s], pl[4 * s + 1], pl[4 * s + 2], pl[4 * s + 3]};
+          const h16x8 pbl = __builtin_bit_cast(h16x8, pb);
+          o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbl, o[0], 0, 0, 0);
+          o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[s], pbh, o[0], 0, 0, 0);
+        }
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbh, o[0], 0, 0, 0);
+      }
+    };
+    // ---- half 0: scores, reference check ----
+    f32x16 s0, s1;
+    load_kf(0);
+    scores(s0);
+    const float mx0 = rowmax(s0, 0);
+    const bool first = kt == 0;
+    if (first || __builtin_amdgcn_ballot_w64(mx0 > 15.5f) != 0) {
+      const float delta = first ? mx0 - kLazyOff : fmaxf(mx0 - kLazyOff, 0.f);
+      const float corr = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);   // o, psum are 0 on the first tile
+      psum_a[0] *= corr;
+      psum_b[0] *= corr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[0][r] *= corr;
+        negm[0][r] -= delta;
+        s0[r] -= delta;
+      }
+    }
+    // ---- scores of half 1 beside the exponentials of half 0 ----
+    unsigned int ph0[8], pl0[8], ph1[8], pl1[8];
+    load_kf(1);
+    scores(s1);
+    convert(s0, ph0, pl0);
+    const float mx1 = rowmax(s1, 1);
+    if (__builtin_amdgcn_ballot_w64(mx1 > 15.5f) != 0) {
+      const float delta = ceilf(fmaxf(mx1 - kLazyOff, 0.f));          // integer: corr is an exact power of two
+      const float corr = __builtin_amdgcn_exp2f(-delta);
+      psum_a[0] *= corr;
+      psum_b[0] *= corr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[0][r] *= corr;
+        negm[0][r] -= delta;
+        s1[r] -= delta;
+      }
+      typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+      const _Float16 ch = (_Float16)corr;                              // below 2^-24: the old probabilities vanish
+      const h16x2 c2 = {ch, ch};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ph0[i] = __builtin_bit_cast(unsigned int, __builtin_bit_cast(h16x2, ph0[i]) * c2);
+        if constexpr (H3) pl0[i] = __builtin_bit_cast(unsigned int, __builtin_bit_cast(h16x2, pl0[i]) * c2);
+      }
+    }
+    // ---- PV of half 0 beside the exponentials of half 1, then PV of half 1 ----
+    load_vf(0);
+    pv(ph0, pl0);
+    convert(s1, ph1, pl1);
+    load_vf(1);
+    pv(ph1, pl1);
+  };
+
   if (klen > 0) {
     fetch(0);
     stash(0);
@@ -667,12 +806,16 @@ __global__ __launch_bounds__(256, WPS) void k_attn_h3(
     const bool more = kt + KT2 < klen;
     if (more) fetch(kt + KT2);
     __builtin_amdgcn_sched_barrier(0);
-    tile(kt, buf, std::false_type{});
+    if constexpr (PIPE) tile_pipe(kt, buf, std::false_type{});
+    else tile(kt, buf, std::false_type{});
     __builtin_amdgcn_sched_barrier(0);
     if (more) stash(buf ^ 1);
     __syncthreads();
   }
-  if (kt < klen) tile(kt, buf, std::true_type{});
+  if (kt < klen) {
+    if constexpr (PIPE) tile_pipe(kt, buf, std::true_type{});
+    else tile(kt, buf, std::true_type{});
+  }
 
 #pragma unroll
   for (int h = 0; h < NQ; ++h) {
@@ -827,6 +970,27 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
       else
         hipLaunchKernelGGL((k_attn_h3<true, true, 1, 4>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
                            pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+      SPR_LAUNCH_CHECK();
+      return 0;
+    }
+    static const int pipe = [] { const char* e = getenv("SPR_ATTN_PIPE"); return e != nullptr ? atoi(e) : 0; }();
+    if (pipe == 1) {        // experiment: the two key halves of a tile staggered inside the wave (tile_pipe)
+      if (mode == 2)
+        hipLaunchKernelGGL((k_attn_h3<false, true, 1, 3, true>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl,
+                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+      else
+        hipLaunchKernelGGL((k_attn_h3<true, true, 1, 3, true>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl,
+                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+      SPR_LAUNCH_CHECK();
+      return 0;
+    }
+    if (pipe == 2) {        // the same at two waves per SIMD (256 registers)
+      if (mode == 2)
+        hipLaunchKernelGGL((k_attn_h3<false, true, 1, 2, true>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl,
+                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+      else
+        hipLaunchKernelGGL((k_attn_h3<true, true, 1, 2, true>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl,
+                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
       SPR_LAUNCH_CHECK();
       return 0;
     }
