@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SPR_VERSION 4
+#define SPR_VERSION 5
 
 /* activation codes for spr_linear / spr_instnorm */
 #define SPR_ACT_NONE 0
@@ -451,6 +451,16 @@ int spr_sinkhorn_correspondences(const float* feat, int d, const float* xyz,
                                  const float* alpha, const float* beta, int n_iters,
                                  int slack, float* out_w, float* out_that,
                                  void* ws, size_t ws_bytes, void* stream);
+
+/* spr_match_dualsoftmax2 + spr_sinkhorn_correspondences of the same features in one call -- RegTR's inference
+ * forward runs them back to back on the conditioned features (qk_regtr_full.py:453-479 then :525-536).  The scaled
+ * correlation matrices are computed and stored once; the Sinkhorn passes evaluate the affinity as they read them.
+ * Outputs bit for bit those of the two separate calls; match_val2 may be NULL; workspace:
+ * spr_match_workspace_bytes. */
+int spr_match_sinkhorn(const float* feat, int d, const float* xyz, const int* cu, const int* cu_host,
+                       int npairs, const float* alpha, const float* beta, int n_iters, float* match_val,
+                       float* match_val2, int* match_ind, float* out_w, float* out_that, void* ws,
+                       size_t ws_bytes, void* stream);
 
 /* ---- small helpers ----------------------------------------------------------*/
 /* out[i] = x[idx[i]] rows of width c (idx i32, rows >= n_src read zeros). */

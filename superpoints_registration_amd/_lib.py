@@ -91,6 +91,7 @@ SIGNATURES = {
     "spr_pose_scores": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp]),
     "spr_weighted_procrustes": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "spr_sinkhorn_workspace_bytes": (_sz, [_vp, _i]),
+    "spr_match_sinkhorn": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "spr_sinkhorn_correspondences": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp, _vp,
                                           _sz, _vp]),
     "spr_loss_workspace_bytes": (_sz, [_i, _i, _i]),

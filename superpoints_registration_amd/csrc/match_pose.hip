@@ -42,6 +42,17 @@ struct PairDesc {
 // terms that cancel down to the slack mass, and an error of 1e-7 in u_i or v_j moves a whole row / column of them
 // together -- with float potentials d alpha was off by 4e-4, with double ones by 3e-5 (the terms themselves stay
 // float: their rounding errors are independent and average out).
+// Optional elementwise view of the stored matrix: the Sinkhorn affinity -(max(x, 0) - softplus(alpha)) / (e^beta +
+// 0.02) of the scaled correlation x, evaluated as the passes read it (aff = {scale, softplus alpha, 1 / den} from
+// k_epi_params; the same float operations as the GEMM epilogue kEpiAffinity, so a matrix stored with kEpiScale and read
+// through this view gives bit for bit the values of one stored with kEpiAffinity).  aff == nullptr: identity.
+struct Aff {
+  bool on;
+  float sp, inv_den;
+  __device__ __forceinline__ explicit Aff(const float* aff)
+      : on(aff != nullptr), sp(aff ? aff[1] : 0.f), inv_den(aff ? aff[2] : 0.f) {}
+  __device__ __forceinline__ float operator()(float x) const { return on ? -(fmaxf(x, 0.f) - sp) * inv_den : x; }
+};
 __device__ __forceinline__ float wave_sum_t(float v) { return wave_sum(v); }
 __device__ __forceinline__ double wave_sum_t(double v) { return wave_sum_d(v); }
 __device__ __forceinline__ float lse_log(float s) { return logf(s); }
@@ -50,21 +61,23 @@ __device__ __forceinline__ double lse_log(double s) { return log(s); }
 template <typename PT>
 __global__ void k_row_lse(const float* __restrict__ mat, const PairDesc* __restrict__ pd,
                           PT* __restrict__ row_out /*packed by src token*/,
-                          const PT* __restrict__ col_sub /*packed by tgt token*/, int slack) {
+                          const PT* __restrict__ col_sub /*packed by tgt token*/, int slack,
+                          const float* __restrict__ aff = nullptr) {
   const PairDesc p = pd[blockIdx.y];
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (row >= p.n) return;
+  const Aff af(aff);
   const float* r = mat + p.off + (size_t)row * p.m;
   float mx = slack ? 0.f : -INFINITY;
   for (int j = lane; j < p.m; j += 64) {
-    const float v = (float)((PT)r[j] - (col_sub ? col_sub[p.tgt_beg + j] : (PT)0));
+    const float v = (float)((PT)af(r[j]) - (col_sub ? col_sub[p.tgt_beg + j] : (PT)0));
     mx = fmaxf(mx, v);
   }
   mx = wave_max(mx);
   PT s = 0;
   for (int j = lane; j < p.m; j += 64) {
-    const PT v = (PT)r[j] - (col_sub ? col_sub[p.tgt_beg + j] : (PT)0);
+    const PT v = (PT)af(r[j]) - (col_sub ? col_sub[p.tgt_beg + j] : (PT)0);
     s += (PT)expf((float)(v - (PT)mx));
   }
   s = wave_sum_t(s);
@@ -78,17 +91,19 @@ template <typename PT>
 __global__ __launch_bounds__(1024) void k_col_lse(const float* __restrict__ mat,
                                                  const PairDesc* __restrict__ pd,
                                                  PT* __restrict__ col_out,
-                                                 const PT* __restrict__ row_sub, int slack) {
+                                                 const PT* __restrict__ row_sub, int slack,
+                                                 const float* __restrict__ aff = nullptr) {
   const PairDesc p = pd[blockIdx.y];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
   __shared__ float smx[kColLanes][64];
   __shared__ PT ssum[kColLanes][64];
+  const Aff af(aff);
   float mx = -INFINITY;
   PT s = 0;
   if (col < p.m) {
     for (int i = rl; i < p.n; i += kColLanes) {
-      const PT vd = (PT)mat[p.off + (size_t)i * p.m + col] - (row_sub ? row_sub[p.src_beg + i] : (PT)0);
+      const PT vd = (PT)af(mat[p.off + (size_t)i * p.m + col]) - (row_sub ? row_sub[p.src_beg + i] : (PT)0);
       const float v = (float)vd;
       if (v > mx) {
         s = s * (PT)expf(mx - v) + (PT)expf((float)(vd - (PT)v));
@@ -127,11 +142,12 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 template <int RV, typename PT>
 __global__ __launch_bounds__(256) void k_row_lse_v(const float* __restrict__ mat, const PairDesc* __restrict__ pd,
                                                    PT* __restrict__ row_out, const PT* __restrict__ col_sub,
-                                                   int slack) {
+                                                   int slack, const float* __restrict__ aff) {
   const PairDesc p = pd[blockIdx.y];
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (row >= p.n) return;
+  const Aff af(aff);
   const float* r = mat + p.off + (size_t)row * p.m;
   const PT* cs = col_sub ? col_sub + p.tgt_beg : nullptr;
   PT v[RV][4];
@@ -145,10 +161,10 @@ __global__ __launch_bounds__(256) void k_row_lse_v(const float* __restrict__ mat
       pt4u b = {0, 0, 0, 0};
       if (cs) b = *reinterpret_cast<const pt4u*>(cs + j);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[i][e] = (PT)a[e] - b[e];
+      for (int e = 0; e < 4; ++e) v[i][e] = (PT)af(a[e]) - b[e];
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[i][e] = j + e < p.m ? (PT)r[j + e] - (cs ? cs[j + e] : (PT)0) : (PT)-INFINITY;
+      for (int e = 0; e < 4; ++e) v[i][e] = j + e < p.m ? (PT)af(r[j + e]) - (cs ? cs[j + e] : (PT)0) : (PT)-INFINITY;
     }
     mx = fmaxf(mx, fmaxf(fmaxf((float)v[i][0], (float)v[i][1]), fmaxf((float)v[i][2], (float)v[i][3])));
   }
@@ -169,8 +185,9 @@ constexpr int kColLanesV = 32;
 template <typename PT>
 __global__ __launch_bounds__(512) void k_col_lse_v(const float* __restrict__ mat, const PairDesc* __restrict__ pd,
                                                   PT* __restrict__ col_out, const PT* __restrict__ row_sub,
-                                                  int slack) {
+                                                  int slack, const float* __restrict__ aff) {
   const PairDesc p = pd[blockIdx.y];
+  const Aff af(aff);
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int col = blockIdx.x * 64 + 4 * cl;
   __shared__ float smx[kColLanesV][64];
@@ -201,10 +218,11 @@ __global__ __launch_bounds__(512) void k_col_lse_v(const float* __restrict__ mat
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const bool rok = i0 + q * kColLanesV < p.n;
-        const float t0 = shift == 0 ? a[q][0] : shift == 1 ? a[q][1] : shift == 2 ? a[q][2] : a[q][3];
-        const float t1 = shift == 0 ? a[q][1] : shift == 1 ? a[q][2] : shift == 2 ? a[q][3] : INFINITY;
-        const float t2 = shift == 0 ? a[q][2] : shift == 1 ? a[q][3] : INFINITY;
-        const float t3 = shift == 0 ? a[q][3] : INFINITY;
+        const float a0 = af(a[q][0]), a1 = af(a[q][1]), a2 = af(a[q][2]), a3 = af(a[q][3]);
+        const float t0 = shift == 0 ? a0 : shift == 1 ? a1 : shift == 2 ? a2 : a3;
+        const float t1 = shift == 0 ? a1 : shift == 1 ? a2 : shift == 2 ? a3 : INFINITY;
+        const float t2 = shift == 0 ? a2 : shift == 1 ? a3 : INFINITY;
+        const float t3 = shift == 0 ? a3 : INFINITY;
         v[q][0] = rok ? (PT)t0 - sub[q] : (PT)-INFINITY;
         v[q][1] = rok && t1 < INFINITY ? (PT)t1 - sub[q] : (PT)-INFINITY;
         v[q][2] = rok && t2 < INFINITY ? (PT)t2 - sub[q] : (PT)-INFINITY;
@@ -247,25 +265,25 @@ __global__ __launch_bounds__(512) void k_col_lse_v(const float* __restrict__ mat
 // launches of the two passes for `np` pairs starting at descriptor pg
 template <typename PT>
 void launch_row_lse(const float* mat, const PairDesc* pg, int np, int max_n, int max_m, PT* out, const PT* col_sub,
-                    int slack, hipStream_t stream) {
+                    int slack, hipStream_t stream, const float* aff = nullptr) {
   const dim3 grid(cdiv((long)max_n * 64, 256), np);
   if (max_m <= 1024)
-    hipLaunchKernelGGL((k_row_lse_v<4, PT>), grid, dim3(256), 0, stream, mat, pg, out, col_sub, slack);
+    hipLaunchKernelGGL((k_row_lse_v<4, PT>), grid, dim3(256), 0, stream, mat, pg, out, col_sub, slack, aff);
   else if (max_m <= 2048)
-    hipLaunchKernelGGL((k_row_lse_v<8, PT>), grid, dim3(256), 0, stream, mat, pg, out, col_sub, slack);
+    hipLaunchKernelGGL((k_row_lse_v<8, PT>), grid, dim3(256), 0, stream, mat, pg, out, col_sub, slack, aff);
   else if (max_m <= 4096 && sizeof(PT) == 4)
-    hipLaunchKernelGGL((k_row_lse_v<16, float>), grid, dim3(256), 0, stream, mat, pg, (float*)out, (const float*)col_sub, slack);
+    hipLaunchKernelGGL((k_row_lse_v<16, float>), grid, dim3(256), 0, stream, mat, pg, (float*)out, (const float*)col_sub, slack, aff);
   else
-    hipLaunchKernelGGL(k_row_lse<PT>, grid, dim3(256), 0, stream, mat, pg, out, col_sub, slack);
+    hipLaunchKernelGGL(k_row_lse<PT>, grid, dim3(256), 0, stream, mat, pg, out, col_sub, slack, aff);
 }
 template <typename PT>
 void launch_col_lse(const float* mat, const PairDesc* pg, int np, int max_m, PT* out, const PT* row_sub, int slack,
-                    hipStream_t stream, int min_m) {
+                    hipStream_t stream, int min_m, const float* aff = nullptr) {
   if (min_m < 4) {   // (a pair with fewer than four target tokens: the one-column-per-thread form)
-    hipLaunchKernelGGL(k_col_lse<PT>, dim3(cdiv(max_m, 64), np), dim3(1024), 0, stream, mat, pg, out, row_sub, slack);
+    hipLaunchKernelGGL(k_col_lse<PT>, dim3(cdiv(max_m, 64), np), dim3(1024), 0, stream, mat, pg, out, row_sub, slack, aff);
     return;
   }
-  hipLaunchKernelGGL(k_col_lse_v<PT>, dim3(cdiv(max_m, 64), np), dim3(16 * kColLanesV), 0, stream, mat, pg, out, row_sub, slack);
+  hipLaunchKernelGGL(k_col_lse_v<PT>, dim3(cdiv(max_m, 64), np), dim3(16 * kColLanesV), 0, stream, mat, pg, out, row_sub, slack, aff);
 }
 
 // ---- dual softmax arg-max ---------------------------------------------------
@@ -439,15 +457,16 @@ __global__ void k_affinity(float* __restrict__ mat, long long total, float scale
 __global__ void k_sinkhorn_final(const float* __restrict__ mat, const PairDesc* __restrict__ pd,
                                  const float* __restrict__ u, const float* __restrict__ v,
                                  const float* __restrict__ xyz, float* __restrict__ out_w,
-                                 float* __restrict__ out_t) {
+                                 float* __restrict__ out_t, const float* __restrict__ aff = nullptr) {
   const PairDesc p = pd[blockIdx.y];
   const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (row >= p.n) return;
+  const Aff af(aff);
   const float ui = u[p.src_beg + row];
   float w = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
   for (int j = lane; j < p.m; j += 64) {
-    const float pij = expf(mat[p.off + (size_t)row * p.m + j] - ui - v[p.tgt_beg + j]);
+    const float pij = expf(af(mat[p.off + (size_t)row * p.m + j]) - ui - v[p.tgt_beg + j]);
     const float* t = xyz + 3 * (size_t)(p.tgt_beg + j);
     w += pij;
     tx += pij * t[0];
@@ -1213,7 +1232,64 @@ extern "C" int spr_sinkhorn_correspondences(const float* feat, int d, const floa
       launch_col_lse<float>(c.mat, pg, np, c.max_m, v, (const float*)u, 1, stream, c.min_m);
     }
     hipLaunchKernelGGL(k_sinkhorn_final, dim3(cdiv((long)c.max_n * 64, 256), np), dim3(256), 0, stream, c.mat, pg, u, v,
-                       xyz, out_w, out_that);
+                       xyz, out_w, out_that, (const float*)nullptr);
+  }
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+// spr_match_dualsoftmax2 + spr_sinkhorn_correspondences of the SAME features in one call (what RegTR's inference
+// forward runs back to back, qk_regtr_full.py:453-479 and :525-536): the scaled correlation matrices are computed
+// and stored once; the Sinkhorn passes read them through the affinity view (struct Aff).  Outputs are bit for bit
+// those of the two separate calls.  match_val2 may be NULL.  Workspace: spr_match_workspace_bytes.
+extern "C" int spr_match_sinkhorn(const float* feat, int d, const float* xyz, const int* cu, const int* cu_host,
+                                  int npairs, const float* alpha, const float* beta, int n_iters, float* match_val,
+                                  float* match_val2, int* match_ind, float* out_w, float* out_that, void* ws,
+                                  size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(npairs >= 1 && d % 32 == 0 && n_iters >= 0, "match_sinkhorn: bad arguments");
+  SPR_REQUIRE(feat && xyz && cu && cu_host && alpha && beta && match_val && match_ind && out_w && out_that,
+              "match_sinkhorn: null argument");
+  SPR_REQUIRE(ws_bytes >= match_ws_bytes(cu_host, npairs), "match_sinkhorn: workspace too small");
+  Workspace w(ws, ws_bytes);
+  const float scale = 1.0f / sqrtf((float)d);
+  float* epi = w.take<float>(4);       // {scale}: the GEMM epilogue
+  float* aff = w.take<float>(4);       // {scale, softplus alpha, 1 / (e^beta + 0.02)}: the view of the Sinkhorn passes
+  SPR_REQUIRE(aff != nullptr, "match_sinkhorn: workspace carve failed");
+  hipLaunchKernelGGL(k_epi_params, dim3(1), dim3(64), 0, stream, scale, (const float*)nullptr, (const float*)nullptr, epi);
+  hipLaunchKernelGGL(k_epi_params, dim3(1), dim3(64), 0, stream, scale, alpha, beta, aff);
+  Corr c;
+  if (corr_setup(c, feat, d, cu, cu_host, npairs, w, stream, false)) return 1;
+  const int T = cu_host[2 * npairs];
+  float* row_lse = w.take<float>(T);
+  float* col_lse = w.take<float>(T);
+  float* u = w.take<float>(T);
+  float* v = w.take<float>(T);
+  SPR_REQUIRE(v != nullptr, "match_sinkhorn: workspace carve failed");
+  SPR_HIP_CHECK(hipMemsetAsync(u, 0, sizeof(float) * T, stream));
+  SPR_HIP_CHECK(hipMemsetAsync(v, 0, sizeof(float) * T, stream));
+  for (int g = 0; g < c.ngroups; ++g) {
+    bool scaled = false;
+    if (corr_gemm(c, g, kEpiScale, epi, stream, &scaled)) return 1;
+    const int np = c.count(g);
+    PairDesc* pg = c.pd + c.first(g);
+    if (!scaled) {
+      const long long cnt = c.end(g) - c.beg(g);
+      hipLaunchKernelGGL(k_scale, dim3(cdiv(cnt, 256)), dim3(256), 0, stream, c.mat + c.beg(g), cnt, scale);
+    }
+    const dim3 grow(cdiv((long)c.max_n * 64, 256), np), gcol(cdiv(c.max_m, 64), np);
+    launch_row_lse<float>(c.mat, pg, np, c.max_n, c.max_m, row_lse, nullptr, 0, stream);
+    launch_col_lse<float>(c.mat, pg, np, c.max_m, col_lse, nullptr, 0, stream, c.min_m);
+    hipLaunchKernelGGL(k_match_cols, gcol, dim3(1024), 0, stream, c.mat, pg, row_lse, col_lse, match_val, match_ind,
+                       match_val2);
+    hipLaunchKernelGGL(k_match_rows, grow, dim3(256), 0, stream, c.mat, pg, row_lse, col_lse, match_val, match_ind,
+                       match_val2);
+    for (int it = 0; it < n_iters; ++it) {
+      launch_row_lse<float>(c.mat, pg, np, c.max_n, c.max_m, u, (const float*)v, 1, stream, aff);
+      launch_col_lse<float>(c.mat, pg, np, c.max_m, v, (const float*)u, 1, stream, c.min_m, aff);
+    }
+    hipLaunchKernelGGL(k_sinkhorn_final, grow, dim3(256), 0, stream, c.mat, pg, u, v, xyz, out_w, out_that,
+                       (const float*)aff);
   }
   SPR_LAUNCH_CHECK();
   return 0;

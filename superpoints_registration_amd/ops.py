@@ -976,6 +976,33 @@ def sinkhorn_correspondences_raw(feat, xyz, cu, cu_host: Sequence[int], npairs: 
     return w, that
 
 
+def match_and_sinkhorn(feat, xyz, cu, cu_host: Sequence[int], npairs: int, alpha, beta, n_iters: int,
+                       top2: bool = False):
+    """match_dualsoftmax(_top2) and sinkhorn_correspondences of the same features in one call
+    (spr_match_sinkhorn: the correlation matrices are computed and stored once).  Inference only -- with gradients
+    wanted use the two operators.  Returns (val, val2 or None, ind, w, t_hat), bit for bit the separate results."""
+    if _wants_grad(feat, alpha, beta):
+        raise RuntimeError("match_and_sinkhorn is an inference operator (use match_dualsoftmax + sinkhorn_correspondences)")
+    feat = _dev(feat, "feat", torch.float32)
+    alpha_t, beta_t = _dev_scalar(alpha, feat.device), _dev_scalar(beta, feat.device)
+    xyz = _dev(xyz, "xyz", torch.float32)
+    cu = _dev(cu, "cu", torch.int32)
+    T, d = feat.shape
+    tsrc = int(cu_host[npairs])
+    arr = _cu_host_arr(cu_host)
+    L = _lib.lib()
+    ws = _workspace(L.spr_match_workspace_bytes(arr, npairs), feat.device)
+    val = torch.zeros((T,), dtype=torch.float32, device=feat.device)
+    val2 = torch.zeros((T,), dtype=torch.float32, device=feat.device) if top2 else None
+    ind = torch.zeros((T,), dtype=torch.int32, device=feat.device)
+    w = torch.empty((tsrc,), dtype=torch.float32, device=feat.device)
+    that = torch.empty((tsrc, 3), dtype=torch.float32, device=feat.device)
+    _lib.check(L.spr_match_sinkhorn(_ptr(feat), d, _ptr(xyz), _ptr(cu), arr, npairs, _ptr(alpha_t), _ptr(beta_t),
+                                    int(n_iters), _ptr(val), _ptr(val2), _ptr(ind), _ptr(w), _ptr(that), _ptr(ws),
+                                    ws.numel(), _stream(feat)), "spr_match_sinkhorn")
+    return val, val2, ind, w, that
+
+
 def weighted_procrustes(a, b, w, pair_cu) -> torch.Tensor:
     """a12.  a,b [T,3], w [T] or None, pair_cu int32 [P+1] -> [P,3,4].  Differentiable in a, b, w
     (autograd.ProcrustesFn)."""

@@ -169,7 +169,13 @@ class RegTR(nn.Module):
         if refine and torch.is_grad_enabled() and self.training:
             raise NotImplementedError("the config-off refinements are inference-time options")
         val2 = None
-        if cfg.get('use_ratio_test', False):
+        w = t_hat = None
+        if (cfg.use_sinkhorn and not refine and bool(cfg.slack) and not torch.is_grad_enabled()):
+            # inference: both heads read the same correlation matrices -- computed and stored once
+            val, val2, ind, w, t_hat = ops.match_and_sinkhorn(cond, xyz_c, cu, cu_host, B, self.alpha, self.beta,
+                                                              int(cfg.sinkhorn_itr),
+                                                              top2=bool(cfg.get('use_ratio_test', False)))
+        elif cfg.get('use_ratio_test', False):
             val, val2, ind = ops.match_dualsoftmax_top2(cond, cu, cu_host, B)
         else:
             val, ind = ops.match_dualsoftmax(cond, cu, cu_host, B)
@@ -180,9 +186,10 @@ class RegTR(nn.Module):
             refined = self._refined_pose(xyz_c, overlap, val, val2, ind, cu, cu_host, B, cond)
             pose = refined['pose']
         elif cfg.use_sinkhorn:
-            w, t_hat = ops.sinkhorn_correspondences(cond, xyz_c, cu, cu_host, B,
-                                                    self.alpha, self.beta,   # device scalars, no sync
-                                                    int(cfg.sinkhorn_itr), bool(cfg.slack))
+            if w is None:
+                w, t_hat = ops.sinkhorn_correspondences(cond, xyz_c, cu, cu_host, B,
+                                                        self.alpha, self.beta,   # device scalars, no sync
+                                                        int(cfg.sinkhorn_itr), bool(cfg.slack))
             pose = ops.weighted_procrustes(src_xyz_all, t_hat, w, cu[:B + 1].contiguous())
         else:
             pose = self._pose_from_matches(xyz_c, val, ind, cu, cu_host, B)

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_version_and_error_channel():
     L = _lib.lib()
-    assert L.spr_version() == 4
+    assert L.spr_version() == 5
     assert isinstance(L.spr_last_error(), bytes)
 
 

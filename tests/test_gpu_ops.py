@@ -345,3 +345,28 @@ def test_sinkhorn_and_match_vs_reference(gold, inp, device):
     val2, ind2 = ops.match_dualsoftmax(feat2, torch.tensor(cu_host2, dtype=torch.int32, device=device), cu_host2, 1)
     assert np.array_equal(ind2.cpu().numpy()[:47], gold["ds.ind_mn"])
     _close(val2.cpu().numpy()[:47], gold["ds.val_mn"], 1e-5, "dual softmax val (N<=M)")
+
+
+def test_match_and_sinkhorn_is_the_two_operators_bit_for_bit(device):
+    """spr_match_sinkhorn stores the scaled correlation once and lets the Sinkhorn passes evaluate the affinity as
+    they read it: every output must equal the separate calls' exactly -- ragged pairs, several groups of pairs
+    (SPR_MATCH_GROUP_MB is not touched: the 250 MB budget holds all of these in one group; the grouping itself is
+    covered by the model tests at bench size)."""
+    g = torch.Generator().manual_seed(3)
+    n_l, m_l = [60, 333, 1, 129, 257], [47, 290, 5, 130, 64]
+    cu_host = [0]
+    for n in n_l + m_l:
+        cu_host.append(cu_host[-1] + n)
+    T, B = cu_host[-1], len(n_l)
+    feat = (torch.randn(T, 256, generator=g) * 0.7).to(device)
+    xyz = torch.randn(T, 3, generator=g).to(device)
+    cu = torch.tensor(cu_host, dtype=torch.int32, device=device)
+    alpha = torch.tensor(0.8, device=device)
+    beta = torch.tensor(-0.4, device=device)
+    w0, t0 = ops.sinkhorn_correspondences(feat, xyz, cu, cu_host, B, alpha, beta, 3)
+    v0, v20, i0 = ops.match_dualsoftmax_top2(feat, cu, cu_host, B)
+    v1, v21, i1, w1, t1 = ops.match_and_sinkhorn(feat, xyz, cu, cu_host, B, alpha, beta, 3, top2=True)
+    for a, b, nm in ((v0, v1, "val"), (v20, v21, "val2"), (i0, i1, "ind"), (w0, w1, "w"), (t0, t1, "t_hat")):
+        assert torch.equal(a, b), nm
+    v2, none, i2, w2, t2 = ops.match_and_sinkhorn(feat, xyz, cu, cu_host, B, alpha, beta, 3)
+    assert none is None and torch.equal(v2, v0) and torch.equal(i2, i0) and torch.equal(w2, w0)
