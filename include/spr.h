@@ -369,6 +369,8 @@ int spr_xenc_forward(const void* plan_host, const float* x, const float* pos, co
  * reproducible).  dq, dk, dv [t, nhead * 32] contiguous, fully written.  head_dim = 32.
  */
 size_t spr_attn_bwd_workspace_bytes(int t, int nhead);
+/* the same with room for the pre-split operand planes of the split-fp16 form (faster; optional) */
+size_t spr_attn_bwd_workspace_bytes2(int t, int nseg, int nhead);
 int spr_attn_varlen_bwd(const float* q, int q_stride, const float* k, int k_stride, const float* v,
                         int v_stride, const float* out, int o_stride, const float* dout,
                         int do_stride, const int* cu, const int* kv_seg, const int* q_seg, int t,

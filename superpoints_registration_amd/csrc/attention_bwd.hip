@@ -501,11 +501,142 @@ __global__ __launch_bounds__(256) void k_attn_bwd_scales(const float* __restrict
   }
 }
 
+// ---- operand planes written once per call (k_attn_bwd_pack) -----------------------------------------------------
+// Every workgroup of the two kernels stages 31 tiles of the OTHER side; converting them from fp32 on the way (the
+// first form of this round) repeats the split and the transposing 2-byte LDS writes 31 times per tile.  With the
+// planes in memory a staged tile is 16-byte copies: R form [head][token][32] hi / lo for q, k, v, dO; C form
+// [head][d][column] hi / lo for q, k, dO with column = cst[segment] + 64 tile + pos(row) -- segments start at
+// multiples of 64 columns (cst), rows past a segment's end are stored as zeros.
+struct BwdPlanes {
+  _Float16 *rq[2], *rk[2], *rv[2], *ro[2];
+  _Float16 *cq[2], *ck[2], *co[2];
+  int* cst;       // [nseg + 1]
+  int t, tc;      // tokens, columns of a C plane row
+};
+struct Stage {
+  TileRegs f;                  // fp32 route
+  bu32x4 rh, rl, ch, cl;       // plane route
+};
+template <bool PL>
+__device__ __forceinline__ void stage_fetch(Stage& st, const float* __restrict__ x, int stride, int hoff,
+                                            _Float16* const (&rp)[2], _Float16* const (&cp)[2], bool want_c, int T,
+                                            int tc, int head, int seg_beg, int len, int row0, int ccol0) {
+  if constexpr (!PL) {
+    st.f = tile_fetch(x, stride, seg_beg, len, row0, hoff);
+  } else {
+    const int row = row0 + (threadIdx.x >> 2), chunk = threadIdx.x & 3;
+    st.rh = st.rl = (bu32x4){0u, 0u, 0u, 0u};
+    if (row < len) {
+      const size_t o = ((size_t)head * T + seg_beg + row) * BHD + 8 * chunk;
+      st.rh = *reinterpret_cast<const bu32x4*>(rp[0] + o);
+      st.rl = *reinterpret_cast<const bu32x4*>(rp[1] + o);
+    }
+    if (want_c) {
+      const int d = threadIdx.x >> 3, c8 = threadIdx.x & 7;
+      const size_t o = ((size_t)head * BHD + d) * tc + ccol0 + 8 * c8;
+      st.ch = *reinterpret_cast<const bu32x4*>(cp[0] + o);
+      st.cl = *reinterpret_cast<const bu32x4*>(cp[1] + o);
+    }
+  }
+}
+template <bool PL>
+__device__ __forceinline__ void stage_store(const Stage& st, float s, _Float16* rh, _Float16* rl, _Float16* ch,
+                                            _Float16* cl) {
+  if constexpr (!PL) {
+    tile_store_split(st.f, s, rh, rl, ch, cl);
+  } else {
+    const int row = threadIdx.x >> 2, chunk = threadIdx.x & 3;
+    *reinterpret_cast<bu32x4*>(rh + row * RS + 8 * chunk) = st.rh;
+    *reinterpret_cast<bu32x4*>(rl + row * RS + 8 * chunk) = st.rl;
+    if (ch != nullptr) {
+      const int d = threadIdx.x >> 3, c8 = threadIdx.x & 7;
+      *reinterpret_cast<bu32x4*>(ch + d * CS + 8 * c8) = st.ch;
+      *reinterpret_cast<bu32x4*>(cl + d * CS + 8 * c8) = st.cl;
+    }
+  }
+}
+// the lane's B-operand planes of one row, from the fp32 tensor (split here) or from the R planes
+template <bool PL>
+__device__ __forceinline__ void row_operand(const float* __restrict__ x, size_t xoff, float s, _Float16* const (&rp)[2],
+                                            size_t prow, int h, h16x8 (&bh)[2], h16x8 (&bl)[2]) {
+  if constexpr (!PL) {
+    row_planes(x + xoff, h, s, bh, bl);
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bh[ks] = *reinterpret_cast<const h16x8*>(rp[0] + prow * BHD + 16 * ks + 8 * h);
+      bl[ks] = *reinterpret_cast<const h16x8*>(rp[1] + prow * BHD + 16 * ks + 8 * h);
+    }
+  }
+}
+
+// first C column of every segment
+__global__ void k_attn_bwd_cst(const int* __restrict__ cu, int nseg, int* __restrict__ cst) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int c = 0;
+  for (int s = 0; s < nseg; ++s) {
+    cst[s] = c;
+    c += (cu[s + 1] - cu[s] + BT - 1) / BT * BT;
+  }
+  cst[nseg] = c;
+}
+
+// grid (tile, head, 4 segment + tensor): splits one [64 x 32] tile of q / k / v / dO into its planes
+__global__ __launch_bounds__(256) void k_attn_bwd_pack(const AttnBwdArgs a, const BwdPlanes pl,
+                                                       const float* __restrict__ scales) {
+  __shared__ __align__(16) _Float16 th[BHD * CS], tl[BHD * CS];
+  const int which = blockIdx.z & 3, seg = blockIdx.z >> 2, head = blockIdx.y;
+  const int beg = a.cu[seg], len = a.cu[seg + 1] - beg;
+  const int row0 = blockIdx.x * BT;
+  if (row0 >= len) return;
+  const float* x = which == 0 ? a.q : which == 1 ? a.k : which == 2 ? a.v : a.dout;
+  const int stride = which == 0 ? a.qs : which == 1 ? a.ks : which == 2 ? a.vs : a.dos;
+  _Float16* const* rp = which == 0 ? pl.rq : which == 1 ? pl.rk : which == 2 ? pl.rv : pl.ro;
+  _Float16* const* cp = which == 0 ? pl.cq : which == 1 ? pl.ck : pl.co;
+  const float s = scales[which];
+  const int row = threadIdx.x >> 2, chunk = threadIdx.x & 3;
+  const int r = row0 + row;
+  float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+  if (r < len) {
+    const float4* src = reinterpret_cast<const float4*>(x + (size_t)(beg + r) * stride + head * BHD + 8 * chunk);
+    v0 = src[0];
+    v1 = src[1];
+  }
+  unsigned int hi[4], lo[4];
+  split_pk_s(v0.x, v0.y, s, hi[0], lo[0]);
+  split_pk_s(v0.z, v0.w, s, hi[1], lo[1]);
+  split_pk_s(v1.x, v1.y, s, hi[2], lo[2]);
+  split_pk_s(v1.z, v1.w, s, hi[3], lo[3]);
+  if (r < len) {
+    const size_t o = ((size_t)head * pl.t + beg + r) * BHD + 8 * chunk;
+    *reinterpret_cast<bu32x4*>(rp[0] + o) = (bu32x4){hi[0], hi[1], hi[2], hi[3]};
+    *reinterpret_cast<bu32x4*>(rp[1] + o) = (bu32x4){lo[0], lo[1], lo[2], lo[3]};
+  }
+  if (which == 2) return;      // V is only ever contracted over d
+  const int pos = 32 * (row >> 5) + cpos(row & 31);
+  unsigned short* ph = reinterpret_cast<unsigned short*>(th) + (8 * chunk) * CS + pos;
+  unsigned short* pw = reinterpret_cast<unsigned short*>(tl) + (8 * chunk) * CS + pos;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ph[(2 * i) * CS] = (unsigned short)(hi[i] & 0xffffu);
+    ph[(2 * i + 1) * CS] = (unsigned short)(hi[i] >> 16);
+    pw[(2 * i) * CS] = (unsigned short)(lo[i] & 0xffffu);
+    pw[(2 * i + 1) * CS] = (unsigned short)(lo[i] >> 16);
+  }
+  __syncthreads();
+  const int d = threadIdx.x >> 3, c8 = threadIdx.x & 7;
+  const size_t o = ((size_t)head * BHD + d) * pl.tc + pl.cst[seg] + row0 + 8 * c8;
+  *reinterpret_cast<bu32x4*>(cp[0] + o) = *reinterpret_cast<const bu32x4*>(th + d * CS + 8 * c8);
+  *reinterpret_cast<bu32x4*>(cp[1] + o) = *reinterpret_cast<const bu32x4*>(tl + d * CS + 8 * c8);
+}
+
 constexpr int DQ_BUF_HALVES = 4 * R_HALVES + 2 * C_HALVES;     // K: R + C planes, V: R planes
 constexpr int DKV_BUF_HALVES = 4 * R_HALVES + 4 * C_HALVES;    // Q and dO: R + C planes
 
 // grid (query tile, head, query segment)
-__global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_h(const AttnBwdArgs a, const float* __restrict__ scales) {
+template <bool PL>
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_h(const AttnBwdArgs a, const float* __restrict__ scales,
+                                                          const BwdPlanes pl) {
   __shared__ __align__(16) _Float16 tiles[2 * DQ_BUF_HALVES];
   __shared__ float red_m[2][BT], red_l[2][BT];
   const int head = blockIdx.y, seg = blockIdx.z;
@@ -531,28 +662,44 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_h(const AttnBwdArgs a, c
   const bool qvalid = qi < qlen;
   const int qic = qvalid ? qi : qlen - 1;
   h16x8 qh[2], ql[2], doh[2], dol[2];
-  row_planes(a.q + (size_t)(qbeg + qic) * a.qs + hoff, h, sq, qh, ql);
-  row_planes(a.dout + (size_t)(qbeg + qic) * a.dos + hoff, h, sdo, doh, dol);
+  row_operand<PL>(a.q, (size_t)(qbeg + qic) * a.qs + hoff, sq, pl.rq, (size_t)head * pl.t + qbeg + qic, h, qh, ql);
+  row_operand<PL>(a.dout, (size_t)(qbeg + qic) * a.dos + hoff, sdo, pl.ro, (size_t)head * pl.t + qbeg + qic, h, doh, dol);
+  const int kc0 = PL ? pl.cst[ksg] : 0;
+  auto fetchK = [&](Stage& st, int row0, bool want_c) __attribute__((always_inline)) {
+    stage_fetch<PL>(st, a.k, a.ks, hoff, pl.rk, pl.ck, want_c, pl.t, pl.tc, head, kbeg, klen, row0, kc0 + row0);
+  };
+  auto fetchV = [&](Stage& st, int row0) __attribute__((always_inline)) {
+    stage_fetch<PL>(st, a.v, a.vs, hoff, pl.rv, pl.rv, false, pl.t, pl.tc, head, kbeg, klen, row0, 0);
+  };
   const float dq_row = a.dsum[(size_t)(qbeg + qic) * a.nhead + head] * (sv * sdo);
   const int ntile = (klen + BT - 1) / BT;
 
   // ---- sweep 1: L = log2 sum_j exp2(c s_j) per query ----
   float m_run = -INFINITY, l_run = 0.f;
   {
-    TileRegs rk = tile_fetch(a.k, a.ks, kbeg, klen, 0, hoff);
-    tile_store_split(rk, sk, KRh(0), KRl(0), nullptr, nullptr);
+    Stage rk;
+    fetchK(rk, 0, false);
+    stage_store<PL>(rk, sk, KRh(0), KRl(0), nullptr, nullptr);
     __syncthreads();
     for (int it = 0; it < ntile; ++it) {
       const int buf = it & 1;
       const bool more = it + 1 < ntile;
-      if (more) rk = tile_fetch(a.k, a.ks, kbeg, klen, (it + 1) * BT, hoff);
+      if (more) fetchK(rk, (it + 1) * BT, false);
       const f32x16 s = mm_rows_h(KRh(buf), KRl(buf), 32 * kb, l31, h, qh, ql);       // S'^T[key][query]
       float x[16], mx = -INFINITY;
+      if (more) {                 // only the last tile of a segment can hold rows past its end
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = it * BT + 32 * kb + crow(r, h);
-        x[r] = key < klen ? s[r] * c : -INFINITY;
-        mx = fmaxf(mx, x[r]);
+        for (int r = 0; r < 16; ++r) {
+          x[r] = s[r] * c;
+          mx = fmaxf(mx, x[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = it * BT + 32 * kb + crow(r, h);
+          x[r] = key < klen ? s[r] * c : -INFINITY;
+          mx = fmaxf(mx, x[r]);
+        }
       }
       if (mx > -INFINITY) {
         const float m_new = fmaxf(m_run, mx);
@@ -562,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_h(const AttnBwdArgs a, c
         l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + sum;
         m_run = m_new;
       }
-      if (more) tile_store_split(rk, sk, KRh(buf ^ 1), KRl(buf ^ 1), nullptr, nullptr);
+      if (more) stage_store<PL>(rk, sk, KRh(buf ^ 1), KRl(buf ^ 1), nullptr, nullptr);
       __syncthreads();
     }
   }
@@ -598,33 +745,39 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_h(const AttnBwdArgs a, c
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   {
-    TileRegs rk = tile_fetch(a.k, a.ks, kbeg, klen, 0, hoff);
-    TileRegs rv = tile_fetch(a.v, a.vs, kbeg, klen, 0, hoff);
-    tile_store_split(rk, sk, KRh(0), KRl(0), KCh(0), KCl(0));
-    tile_store_split(rv, sv, VRh(0), VRl(0), nullptr, nullptr);
+    Stage rk, rv;
+    fetchK(rk, 0, true);
+    fetchV(rv, 0);
+    stage_store<PL>(rk, sk, KRh(0), KRl(0), KCh(0), KCl(0));
+    stage_store<PL>(rv, sv, VRh(0), VRl(0), nullptr, nullptr);
     __syncthreads();
     for (int it = 0; it < ntile; ++it) {
       const int buf = it & 1;
       const bool more = it + 1 < ntile;
       if (more) {
-        rk = tile_fetch(a.k, a.ks, kbeg, klen, (it + 1) * BT, hoff);
-        rv = tile_fetch(a.v, a.vs, kbeg, klen, (it + 1) * BT, hoff);
+        fetchK(rk, (it + 1) * BT, true);
+        fetchV(rv, (it + 1) * BT);
       }
       const f32x16 s = mm_rows_h(KRh(buf), KRl(buf), 32 * kb, l31, h, qh, ql);       // S'^T
       const f32x16 dp = mm_rows_h(VRh(buf), VRl(buf), 32 * kb, l31, h, doh, dol);    // dP'^T = V dO^T
       f32x16 ds;
+      if (more) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = it * BT + 32 * kb + crow(r, h);
-        const float p = key < klen ? __builtin_amdgcn_exp2f(s[r] * c - lse) : 0.f;
-        ds[r] = p * (dp[r] - dq_row);
+        for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(s[r] * c - lse) * (dp[r] - dq_row);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = it * BT + 32 * kb + crow(r, h);
+          const float p = key < klen ? __builtin_amdgcn_exp2f(s[r] * c - lse) : 0.f;
+          ds[r] = p * (dp[r] - dq_row);
+        }
       }
       h16x8 bh[2], bl[2];
       acc_planes(ds, DS_MUL, bh, bl);
       mm_cols_acc_h(acc, KCh(buf), KCl(buf), kb, l31, h, bh, bl);
       if (more) {
-        tile_store_split(rk, sk, KRh(buf ^ 1), KRl(buf ^ 1), KCh(buf ^ 1), KCl(buf ^ 1));
-        tile_store_split(rv, sv, VRh(buf ^ 1), VRl(buf ^ 1), nullptr, nullptr);
+        stage_store<PL>(rk, sk, KRh(buf ^ 1), KRl(buf ^ 1), KCh(buf ^ 1), KCl(buf ^ 1));
+        stage_store<PL>(rv, sv, VRh(buf ^ 1), VRl(buf ^ 1), nullptr, nullptr);
       }
       __syncthreads();
     }
@@ -652,7 +805,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_h(const AttnBwdArgs a, c
 }
 
 // grid (key tile, head, key segment); dynamic LDS: 2 x DKV_BUF_HALVES halves + 4 x 64 floats
-__global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_h(const AttnBwdArgs a, const float* __restrict__ scales) {
+template <bool PL>
+__global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_h(const AttnBwdArgs a, const float* __restrict__ scales,
+                                                           const BwdPlanes pl) {
   extern __shared__ __align__(16) unsigned char dkv_smem[];
   _Float16* tiles = reinterpret_cast<_Float16*>(dkv_smem);
   float* Lt = reinterpret_cast<float*>(dkv_smem + (size_t)2 * DKV_BUF_HALVES * 2);     // [2][BT]
@@ -683,8 +838,15 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_h(const AttnBwdArgs a, 
   const bool kvalid = ki < klen;
   const int kic = kvalid ? ki : klen - 1;
   h16x8 kh[2], kl[2], vh[2], vl[2];
-  row_planes(a.k + (size_t)(kbeg + kic) * a.ks + hoff, h, sk, kh, kl);
-  row_planes(a.v + (size_t)(kbeg + kic) * a.vs + hoff, h, sv, vh, vl);
+  row_operand<PL>(a.k, (size_t)(kbeg + kic) * a.ks + hoff, sk, pl.rk, (size_t)head * pl.t + kbeg + kic, h, kh, kl);
+  row_operand<PL>(a.v, (size_t)(kbeg + kic) * a.vs + hoff, sv, pl.rv, (size_t)head * pl.t + kbeg + kic, h, vh, vl);
+  const int qc0 = PL ? pl.cst[seg] : 0;
+  auto fetchQ = [&](Stage& st, int row0) __attribute__((always_inline)) {
+    stage_fetch<PL>(st, a.q, a.qs, hoff, pl.rq, pl.cq, true, pl.t, pl.tc, head, qbeg, qlen, row0, qc0 + row0);
+  };
+  auto fetchO = [&](Stage& st, int row0) __attribute__((always_inline)) {
+    stage_fetch<PL>(st, a.dout, a.dos, hoff, pl.ro, pl.co, true, pl.t, pl.tc, head, qbeg, qlen, row0, qc0 + row0);
+  };
   f32x16 acc_v, acc_k;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc_v[r] = acc_k[r] = 0.f;
@@ -703,19 +865,20 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_h(const AttnBwdArgs a, 
       Dt[buf * BT + tid] = rd;
     }
   };
-  TileRegs rq = tile_fetch(a.q, a.qs, qbeg, qlen, 0, hoff);
-  TileRegs ro = tile_fetch(a.dout, a.dos, qbeg, qlen, 0, hoff);
+  Stage rq, ro;
+  fetchQ(rq, 0);
+  fetchO(ro, 0);
   fetch_stats(0);
-  tile_store_split(rq, sq, QRh(0), QRl(0), QCh(0), QCl(0));
-  tile_store_split(ro, sdo, ORh(0), ORl(0), OCh(0), OCl(0));
+  stage_store<PL>(rq, sq, QRh(0), QRl(0), QCh(0), QCl(0));
+  stage_store<PL>(ro, sdo, ORh(0), ORl(0), OCh(0), OCl(0));
   store_stats(0);
   __syncthreads();
   for (int it = 0; it < ntile; ++it) {
     const int buf = it & 1;
     const bool more = it + 1 < ntile;
     if (more) {
-      rq = tile_fetch(a.q, a.qs, qbeg, qlen, (it + 1) * BT, hoff);
-      ro = tile_fetch(a.dout, a.dos, qbeg, qlen, (it + 1) * BT, hoff);
+      fetchQ(rq, (it + 1) * BT);
+      fetchO(ro, (it + 1) * BT);
       fetch_stats((it + 1) * BT);
     }
     const f32x16 s = mm_rows_h(QRh(buf), QRl(buf), 32 * qb, l31, h, kh, kl);      // S'[query][key]
@@ -726,13 +889,24 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_h(const AttnBwdArgs a, 
       const float4 l4 = *reinterpret_cast<const float4*>(&Lt[buf * BT + 32 * qb + 8 * g + 4 * h]);
       const float4 d4 = *reinterpret_cast<const float4*>(&Dt[buf * BT + 32 * qb + 8 * g + 4 * h]);
       const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+      // (rows past the segment's end exist in the last tile only; an invalid key lane is never stored)
+      if (more) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int r = 4 * g + b;
-        const int qrow = it * BT + 32 * qb + 8 * g + 4 * h + b;
-        const float pv = (qrow < qlen && kvalid) ? __builtin_amdgcn_exp2f(s[r] * c - lv[b]) : 0.f;
-        p[r] = pv;
-        ds[r] = pv * (dp[r] - dv[b]);
+        for (int b = 0; b < 4; ++b) {
+          const int r = 4 * g + b;
+          const float pv = __builtin_amdgcn_exp2f(s[r] * c - lv[b]);
+          p[r] = pv;
+          ds[r] = pv * (dp[r] - dv[b]);
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int r = 4 * g + b;
+          const int qrow = it * BT + 32 * qb + 8 * g + 4 * h + b;
+          const float pv = qrow < qlen ? __builtin_amdgcn_exp2f(s[r] * c - lv[b]) : 0.f;
+          p[r] = pv;
+          ds[r] = pv * (dp[r] - dv[b]);
+        }
       }
     }
     {
@@ -743,8 +917,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_h(const AttnBwdArgs a, 
       mm_cols_acc_h(acc_k, QCh(buf), QCl(buf), qb, l31, h, bh, bl);      // dK^T[d][key] += Q^T dS
     }
     if (more) {
-      tile_store_split(rq, sq, QRh(buf ^ 1), QRl(buf ^ 1), QCh(buf ^ 1), QCl(buf ^ 1));
-      tile_store_split(ro, sdo, ORh(buf ^ 1), ORl(buf ^ 1), OCh(buf ^ 1), OCl(buf ^ 1));
+      stage_store<PL>(rq, sq, QRh(buf ^ 1), QRl(buf ^ 1), QCh(buf ^ 1), QCl(buf ^ 1));
+      stage_store<PL>(ro, sdo, ORh(buf ^ 1), ORl(buf ^ 1), OCh(buf ^ 1), OCl(buf ^ 1));
       store_stats(buf ^ 1);
     }
     __syncthreads();
@@ -785,10 +959,22 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_h(const AttnBwdArgs a, 
 
 using namespace spr;
 
-extern "C" size_t spr_attn_bwd_workspace_bytes(int t, int nhead) {
+static size_t attn_bwd_base_bytes(int t, int nhead) {
   // lse, dsum [t, nhead]; four max-|x| partial arrays and the four operand scales of the split-fp16 form
   return 2 * align_up((size_t)(t > 0 ? t : 1) * (size_t)(nhead > 0 ? nhead : 1) * sizeof(float), 256) +
          align_up((size_t)4 * kAmaxParts * sizeof(float), 256) + 256;
+}
+static int attn_bwd_tc(int t, int nseg) { return (t + BT - 1) / BT * BT + BT * (nseg > 0 ? nseg : 1); }
+static size_t attn_bwd_plane_bytes(int t, int nseg, int nhead) {
+  const size_t d = (size_t)(nhead > 0 ? nhead : 1) * BHD;
+  return 8 * align_up((size_t)(t > 0 ? t : 1) * d * 2, 256) + 6 * align_up(d * (size_t)attn_bwd_tc(t, nseg) * 2, 256) +
+         align_up((size_t)(nseg + 2) * sizeof(int), 256);
+}
+extern "C" size_t spr_attn_bwd_workspace_bytes(int t, int nhead) { return attn_bwd_base_bytes(t, nhead); }
+// with room for the operand planes of the split-fp16 form (k_attn_bwd_pack); a workspace of only
+// spr_attn_bwd_workspace_bytes still works -- the kernels then convert the fp32 tiles they stage themselves
+extern "C" size_t spr_attn_bwd_workspace_bytes2(int t, int nseg, int nhead) {
+  return attn_bwd_base_bytes(t, nhead) + attn_bwd_plane_bytes(t, nseg, nhead);
 }
 
 // q, k, v, out (the forward's output), dout: [t, nhead * 32] with unit inner stride and the given row strides;
@@ -830,13 +1016,38 @@ extern "C" int spr_attn_varlen_bwd(const float* q, int q_stride, const float* k,
                                 stream))
       return rc;
     hipLaunchKernelGGL(k_attn_bwd_scales, dim3(1), dim3(256), 0, stream, parts, scales);
-    hipLaunchKernelGGL(k_attn_bwd_dq_h, grid, dim3(256), 0, stream, a, scales);
     constexpr size_t dkv_lds = (size_t)2 * DKV_BUF_HALVES * 2 + 4 * BT * sizeof(float);
     static_assert(dkv_lds >= sizeof(float) * 2 * 2 * 16 * 64, "the final reduction reuses the tile buffers");
-    static const int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv_h),
+    static const bool no_planes = getenv("SPR_ATTN_BWD_PLANES") != nullptr && getenv("SPR_ATTN_BWD_PLANES")[0] == '0';
+    BwdPlanes pl{};
+    if (!no_planes && ws_bytes >= spr_attn_bwd_workspace_bytes2(t, nseg, nhead)) {
+      // operand planes written once (k_attn_bwd_pack), staged by 16-byte copies
+      const int tc = attn_bwd_tc(t, nseg);
+      _Float16** r[4] = {pl.rq, pl.rk, pl.rv, pl.ro};
+      for (auto& rp : r)
+        for (int i = 0; i < 2; ++i) rp[i] = w.take<_Float16>((size_t)t * d);
+      _Float16** cpl[3] = {pl.cq, pl.ck, pl.co};
+      for (auto& cp : cpl)
+        for (int i = 0; i < 2; ++i) cp[i] = w.take<_Float16>((size_t)d * tc);
+      pl.cst = w.take<int>(nseg + 1);
+      pl.t = t;
+      pl.tc = tc;
+      SPR_REQUIRE(pl.cst != nullptr, "attn_bwd: workspace carve failed");
+      hipLaunchKernelGGL(k_attn_bwd_cst, dim3(1), dim3(64), 0, stream, cu, nseg, pl.cst);
+      hipLaunchKernelGGL(k_attn_bwd_pack, dim3(cdiv(max_len_host, BT), nhead, 4 * nseg), dim3(256), 0, stream, a, pl, scales);
+      hipLaunchKernelGGL(k_attn_bwd_dq_h<true>, grid, dim3(256), 0, stream, a, scales, pl);
+      static const int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv_h<true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dkv_lds);
+      SPR_REQUIRE(attr_rc == 0, "attn_bwd: cannot reserve %zu bytes of LDS", dkv_lds);
+      hipLaunchKernelGGL(k_attn_bwd_dkv_h<true>, grid, dim3(256), dkv_lds, stream, a, scales, pl);
+      SPR_LAUNCH_CHECK();
+      return 0;
+    }
+    hipLaunchKernelGGL(k_attn_bwd_dq_h<false>, grid, dim3(256), 0, stream, a, scales, pl);
+    static const int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv_h<false>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)dkv_lds);
     SPR_REQUIRE(attr_rc == 0, "attn_bwd: cannot reserve %zu bytes of LDS", dkv_lds);
-    hipLaunchKernelGGL(k_attn_bwd_dkv_h, grid, dim3(256), dkv_lds, stream, a, scales);
+    hipLaunchKernelGGL(k_attn_bwd_dkv_h<false>, grid, dim3(256), dkv_lds, stream, a, scales, pl);
     SPR_LAUNCH_CHECK();
     return 0;
   }

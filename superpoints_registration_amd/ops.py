@@ -705,7 +705,8 @@ def _segment_perms(kv_seg_host, device):
 
 
 def attention_bwd(q, k, v, out, dout, cu, kv_seg_host, max_len: int, nhead: int):
-    """Gradients (dq, dk, dv) of attention_raw (spr_attn_varlen_bwd: flash-style, exact f32 MFMA)."""
+    """Gradients (dq, dk, dv) of attention_raw (spr_attn_varlen_bwd: flash-style; the arithmetic follows
+    set_attn_mode: split-fp16 like the forward, or exact f32 MFMA in mode 0)."""
     for t, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout")):
         if not t.is_cuda or t.dtype != torch.float32 or t.stride(1) != 1:
             raise RuntimeError(f"attention_bwd: {nm} must be a float32 device tensor with unit inner stride")
@@ -718,7 +719,7 @@ def attention_bwd(q, k, v, out, dout, cu, kv_seg_host, max_len: int, nhead: int)
     dk = torch.empty_like(dq)
     dv = torch.empty_like(dq)
     L = _lib.lib()
-    ws = _workspace(L.spr_attn_bwd_workspace_bytes(T, nhead), q.device)
+    ws = _workspace(L.spr_attn_bwd_workspace_bytes2(T, nseg, nhead), q.device)      # with room for the operand planes
     _lib.check(L.spr_attn_varlen_bwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(out),
                                      out.stride(0), _ptr(dout), dout.stride(0), _ptr(cu), _ptr(kv), _ptr(inv), T, nseg,
                                      int(max_len), nhead, hd, 1.0 / math.sqrt(hd), _ptr(dq), _ptr(dk), _ptr(dv),
