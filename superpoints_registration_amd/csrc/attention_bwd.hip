@@ -630,14 +630,19 @@ __global__ __launch_bounds__(256) void k_attn_bwd_pack(const AttnBwdArgs a, cons
   *reinterpret_cast<bu32x4*>(cp[1] + o) = *reinterpret_cast<const bu32x4*>(tl + d * CS + 8 * c8);
 }
 
+#ifndef SPR_ATTN_BWD_NB
+#define SPR_ATTN_BWD_NB 1
+#endif
+constexpr int NB = SPR_ATTN_BWD_NB;       // tile buffers.  1 (default): two barriers per iteration, half the LDS, THREE
+                                          // workgroups per CU (measured 127.7 vs 131.0 ms per training step against 2)
 constexpr int DQ_BUF_HALVES = 4 * R_HALVES + 2 * C_HALVES;     // K: R + C planes, V: R planes
 constexpr int DKV_BUF_HALVES = 4 * R_HALVES + 4 * C_HALVES;    // Q and dO: R + C planes
 
 // grid (query tile, head, query segment)
 template <bool PL>
-__global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_h(const AttnBwdArgs a, const float* __restrict__ scales,
+__global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void k_attn_bwd_dq_h(const AttnBwdArgs a, const float* __restrict__ scales,
                                                           const BwdPlanes pl) {
-  __shared__ __align__(16) _Float16 tiles[2 * DQ_BUF_HALVES];
+  __shared__ __align__(16) _Float16 tiles[NB * DQ_BUF_HALVES];
   __shared__ float red_m[2][BT], red_l[2][BT];
   const int head = blockIdx.y, seg = blockIdx.z;
   const int qbeg = a.cu[seg], qlen = a.cu[seg + 1] - qbeg;
@@ -682,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_h(const AttnBwdArgs a, c
     stage_store<PL>(rk, sk, KRh(0), KRl(0), nullptr, nullptr);
     __syncthreads();
     for (int it = 0; it < ntile; ++it) {
-      const int buf = it & 1;
+      const int buf = it & (NB - 1), nbuf = (it + 1) & (NB - 1);
       const bool more = it + 1 < ntile;
       if (more) fetchK(rk, (it + 1) * BT, false);
       const f32x16 s = mm_rows_h(KRh(buf), KRl(buf), 32 * kb, l31, h, qh, ql);       // S'^T[key][query]
@@ -709,7 +714,8 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_h(const AttnBwdArgs a, c
         l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_new) + sum;
         m_run = m_new;
       }
-      if (more) stage_store<PL>(rk, sk, KRh(buf ^ 1), KRl(buf ^ 1), nullptr, nullptr);
+      if (NB == 1) __syncthreads();
+      if (more) stage_store<PL>(rk, sk, KRh(nbuf), KRl(nbuf), nullptr, nullptr);
       __syncthreads();
     }
   }
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_h(const AttnBwdArgs a, c
     stage_store<PL>(rv, sv, VRh(0), VRl(0), nullptr, nullptr);
     __syncthreads();
     for (int it = 0; it < ntile; ++it) {
-      const int buf = it & 1;
+      const int buf = it & (NB - 1), nbuf = (it + 1) & (NB - 1);
       const bool more = it + 1 < ntile;
       if (more) {
         fetchK(rk, (it + 1) * BT, true);
@@ -775,9 +781,10 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_h(const AttnBwdArgs a, c
       h16x8 bh[2], bl[2];
       acc_planes(ds, DS_MUL, bh, bl);
       mm_cols_acc_h(acc, KCh(buf), KCl(buf), kb, l31, h, bh, bl);
+      if (NB == 1) __syncthreads();
       if (more) {
-        stage_store<PL>(rk, sk, KRh(buf ^ 1), KRl(buf ^ 1), KCh(buf ^ 1), KCl(buf ^ 1));
-        stage_store<PL>(rv, sv, VRh(buf ^ 1), VRl(buf ^ 1), nullptr, nullptr);
+        stage_store<PL>(rk, sk, KRh(nbuf), KRl(nbuf), KCh(nbuf), KCl(nbuf));
+        stage_store<PL>(rv, sv, VRh(nbuf), VRl(nbuf), nullptr, nullptr);
       }
       __syncthreads();
     }
@@ -806,11 +813,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dq_h(const AttnBwdArgs a, c
 
 // grid (key tile, head, key segment); dynamic LDS: 2 x DKV_BUF_HALVES halves + 4 x 64 floats
 template <bool PL>
-__global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_h(const AttnBwdArgs a, const float* __restrict__ scales,
+__global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void k_attn_bwd_dkv_h(const AttnBwdArgs a, const float* __restrict__ scales,
                                                            const BwdPlanes pl) {
   extern __shared__ __align__(16) unsigned char dkv_smem[];
   _Float16* tiles = reinterpret_cast<_Float16*>(dkv_smem);
-  float* Lt = reinterpret_cast<float*>(dkv_smem + (size_t)2 * DKV_BUF_HALVES * 2);     // [2][BT]
+  float* Lt = reinterpret_cast<float*>(dkv_smem + (size_t)NB * DKV_BUF_HALVES * 2);     // [2][BT]
   float* Dt = Lt + 2 * BT;                                                               // [2][BT]
   const int head = blockIdx.y, ksg = blockIdx.z;
   const int kbeg = a.cu[ksg], klen = a.cu[ksg + 1] - kbeg;
@@ -874,7 +881,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_h(const AttnBwdArgs a, 
   store_stats(0);
   __syncthreads();
   for (int it = 0; it < ntile; ++it) {
-    const int buf = it & 1;
+    const int buf = it & (NB - 1), nbuf = (it + 1) & (NB - 1);
     const bool more = it + 1 < ntile;
     if (more) {
       fetchQ(rq, (it + 1) * BT);
@@ -916,10 +923,11 @@ __global__ __launch_bounds__(256, 2) void k_attn_bwd_dkv_h(const AttnBwdArgs a, 
       acc_planes(ds, DS_MUL, bh, bl);
       mm_cols_acc_h(acc_k, QCh(buf), QCl(buf), qb, l31, h, bh, bl);      // dK^T[d][key] += Q^T dS
     }
+    if (NB == 1) __syncthreads();
     if (more) {
-      stage_store<PL>(rq, sq, QRh(buf ^ 1), QRl(buf ^ 1), QCh(buf ^ 1), QCl(buf ^ 1));
-      stage_store<PL>(ro, sdo, ORh(buf ^ 1), ORl(buf ^ 1), OCh(buf ^ 1), OCl(buf ^ 1));
-      store_stats(buf ^ 1);
+      stage_store<PL>(rq, sq, QRh(nbuf), QRl(nbuf), QCh(nbuf), QCl(nbuf));
+      stage_store<PL>(ro, sdo, ORh(nbuf), ORl(nbuf), OCh(nbuf), OCl(nbuf));
+      store_stats(nbuf);
     }
     __syncthreads();
   }
@@ -1016,7 +1024,7 @@ extern "C" int spr_attn_varlen_bwd(const float* q, int q_stride, const float* k,
                                 stream))
       return rc;
     hipLaunchKernelGGL(k_attn_bwd_scales, dim3(1), dim3(256), 0, stream, parts, scales);
-    constexpr size_t dkv_lds = (size_t)2 * DKV_BUF_HALVES * 2 + 4 * BT * sizeof(float);
+    constexpr size_t dkv_lds = (size_t)NB * DKV_BUF_HALVES * 2 + 4 * BT * sizeof(float);
     static_assert(dkv_lds >= sizeof(float) * 2 * 2 * 16 * 64, "the final reduction reuses the tile buffers");
     static const bool no_planes = getenv("SPR_ATTN_BWD_PLANES") != nullptr && getenv("SPR_ATTN_BWD_PLANES")[0] == '0';
     BwdPlanes pl{};
