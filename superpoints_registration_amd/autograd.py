@@ -141,6 +141,8 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, act):
         with torch.no_grad():
+            if _ops._modes["gemm"] == 1 and weight.requires_grad:
+                _ops.ensure_range(x)          # published once: the forward product and dW in the backward both scale x
             y = _ops.linear_raw(x, weight, bias, residual, act)
         ctx.act = act
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
@@ -170,7 +172,11 @@ class LinearFn(torch.autograd.Function):
                 dx = torch.empty((m, k), dtype=torch.float32, device=x.device)
                 bgemm(g, w.detach().contiguous(), dx, [(0, 0, 0, m, k, n)], (n, 1), (k, 1), (k, 1))
         if ctx.needs_input_grad[1]:
-            dw = _tn_product(g, x.detach().contiguous(), m, n, k)
+            xd = x.detach().contiguous()
+            r = getattr(x, '_spr_range', None)
+            if r is not None and xd is not x:
+                xd._spr_range = r             # same storage and version counter: the forward's measurement still holds
+            dw = _tn_product(g, xd, m, n, k)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(g)
         dres = g if (ctx.has_res and ctx.needs_input_grad[3]) else None
