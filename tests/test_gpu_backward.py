@@ -186,6 +186,42 @@ def test_attention_backward_split_operand_ranges(device, qs, ks, vs, gs):
         assert _rel(got, ref) <= 2e-5, f"attention d{nm} at scales {(qs, ks, vs, gs)}: {_rel(got, ref):.2e}"
 
 
+def test_attention_backward_operand_planes_and_small_workspace_agree(device, monkeypatch):
+    """spr_attn_varlen_bwd writes the split operand planes once per call when the workspace has room for them
+    (spr_attn_bwd_workspace_bytes2) and lets its kernels convert the fp32 tiles themselves when it has not
+    (spr_attn_bwd_workspace_bytes): the same values reach the same LDS tiles, so the gradients agree bit for bit."""
+    from superpoints_registration_amd import _lib
+    lens, kv_seg = [130, 64, 1, 257], [1, 0, 3, 2]
+    tot = sum(lens)
+    q0, k0, v0 = (synthetic.rand((tot, 256), s, -1.5, 1.5) for s in (41, 42, 43))
+    go = synthetic.rand((tot, 256), 44)
+    cu = ops.lengths_to_cu(lens, device)
+    seg = torch.tensor(kv_seg, dtype=torch.int32, device=device)
+
+    def grads():
+        lq, lk, lv = _leaf(q0, device), _leaf(k0, device), _leaf(v0, device)
+        ops.attention(lq, lk, lv, cu, seg, max(lens), 8, lens_host=lens, kv_seg_host=kv_seg).backward(go.to(device))
+        return lq.grad.clone(), lk.grad.clone(), lv.grad.clone()
+
+    with_planes = grads()
+    L = _lib.lib()
+    small = L.spr_attn_bwd_workspace_bytes
+
+    class Patched:
+        def __getattr__(self, name):
+            if name == "spr_attn_bwd_workspace_bytes2":
+                return lambda t, nseg, nhead: small(t, nhead)
+            return getattr(L, name)
+
+    monkeypatch.setattr(ops, "_workspace", lambda n, dev: torch.empty(max(int(n), 1), dtype=torch.uint8, device=dev))
+    monkeypatch.setattr(_lib, "lib", lambda: Patched())
+    without = grads()
+    for a, b, nm in zip(with_planes, without, "qkv"):
+        assert torch.equal(a, b), f"d{nm}"
+    for got, ref, nm in zip(with_planes, _attention_f64(q0, k0, v0, go, lens, kv_seg), "qkv"):
+        assert _rel(got, ref) <= 2e-5, f"attention d{nm} {_rel(got, ref):.2e}"
+
+
 def test_attention_backward_many_tiles_and_reproducible(device, attn_mode):
     """Several 64-row tiles per segment on both sides, self and cross segments of different lengths; two runs
     must agree bit for bit (fixed summation order: no atomics in spr_attn_varlen_bwd)."""
