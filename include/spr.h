@@ -313,6 +313,13 @@ int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k,
                         int max_len_host, int nhead, int head_dim, float scale,
                         float* out, int o_stride, void* ws, size_t ws_bytes,
                         void* stream);
+/* The same, additionally handing out lse [t, nhead] = log2 sum_j 2^(log2(e) scale q_i.k_j) per query and head
+ * for spr_attn_varlen_bwd_lse (training: what torch's SDPA backward keeps as `logsumexp`).  *lse_written = 0 when
+ * the configured core does not produce it (exact-f32 mode, the eager-softmax experiment): lse is then untouched. */
+int spr_attn_varlen_fwd_lse(const float* q, int q_stride, const float* k, int k_stride, const float* v,
+                            int v_stride, const int* cu, const int* kv_seg, int t, int nseg, int max_len_host,
+                            int nhead, int head_dim, float scale, float* out, int o_stride, float* lse,
+                            int* lse_written, void* ws, size_t ws_bytes, void* stream);
 
 /* In-projection + attention core in one call: replaces
  * F.multi_head_attention_forward's packed in-projection (q, k from x_qk,
@@ -376,6 +383,13 @@ int spr_attn_varlen_bwd(const float* q, int q_stride, const float* k, int k_stri
                         int do_stride, const int* cu, const int* kv_seg, const int* q_seg, int t,
                         int nseg, int max_len_host, int nhead, int head_dim, float scale,
                         float* dq, float* dk, float* dv, void* ws, size_t ws_bytes, void* stream);
+/* lse: what spr_attn_varlen_fwd_lse handed out for the same q, k (the backward then skips its own pass over the
+ * keys); NULL = spr_attn_varlen_bwd */
+int spr_attn_varlen_bwd_lse(const float* q, int q_stride, const float* k, int k_stride, const float* v,
+                            int v_stride, const float* out, int o_stride, const float* dout, int do_stride,
+                            const float* lse, const int* cu, const int* kv_seg, const int* q_seg, int t, int nseg,
+                            int max_len_host, int nhead, int head_dim, float scale, float* dq, float* dk,
+                            float* dv, void* ws, size_t ws_bytes, void* stream);
 
 /* Arithmetic of the attention core:
  *   1 (default) = split-fp16 MFMA (Q, K, V and the probabilities carried as fp16

@@ -72,6 +72,10 @@ SIGNATURES = {
     "spr_attn_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "spr_attn_varlen_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i,
                                  _vp, _sz, _vp]),
+    "spr_attn_varlen_fwd_lse": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp,
+                                     _vp, _sz, _vp]),
+    "spr_attn_varlen_bwd_lse": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
+                                     _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "spr_attn_bwd_workspace_bytes": (_sz, [_i, _i]),
     "spr_attn_bwd_workspace_bytes2": (_sz, [_i, _i, _i]),
     "spr_attn_varlen_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f,

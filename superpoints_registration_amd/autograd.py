@@ -15,6 +15,7 @@ and nothing below is touched.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -348,6 +349,9 @@ class GatherRowsFn(torch.autograd.Function):
         return dx, None
 
 
+_LSE_HANDOVER = os.environ.get("SPR_NO_LSE_HANDOVER", "0") != "1"   # experiment switch (A/B timing)
+
+
 class AttentionFn(torch.autograd.Function):
     """Varlen multi-head attention core (spr_attn_varlen_fwd).  Backward = spr_attn_varlen_bwd: the
     probabilities are recomputed tile by tile inside two kernels (dQ; dK and dV) -- nothing of size
@@ -356,11 +360,15 @@ class AttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, cu, kv_seg, max_len, nhead, lens_host, kv_seg_host):
         with torch.no_grad():
-            out = _ops.attention_raw(q, k, v, cu, kv_seg, max_len, nhead)
+            if _LSE_HANDOVER:
+                out, lse = _ops.attention_raw(q, k, v, cu, kv_seg, max_len, nhead, want_lse=True)
+            else:
+                out, lse = _ops.attention_raw(q, k, v, cu, kv_seg, max_len, nhead), None
         kvs = [int(x) for x in kv_seg_host]
         if sorted(kvs) != list(range(len(kvs))):
             raise NotImplementedError("attention backward needs kv_seg to be a permutation of the segments")
         ctx.meta = (int(nhead), int(max_len), kvs)
+        ctx.lse = lse                       # [T, nhead] log2-sum-exp of the forward (or None): no grad, not an output
         ctx.save_for_backward(q, k, v, out, cu)
         return out
 
@@ -369,7 +377,7 @@ class AttentionFn(torch.autograd.Function):
         q, k, v, out, cu = ctx.saved_tensors
         nhead, max_len, kvs = ctx.meta
         dq, dk, dv = _ops.attention_bwd(q.detach(), k.detach(), v.detach(), out.detach(), dout.contiguous(), cu, kvs,
-                                        max_len, nhead)
+                                        max_len, nhead, lse=ctx.lse)
         return dq, dk, dv, None, None, None, None, None, None
 
 

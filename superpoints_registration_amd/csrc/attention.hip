@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256, WPS) void k_attn_h3(
     const _Float16* __restrict__ kh_g, const _Float16* __restrict__ kl_g,
     const _Float16* __restrict__ vth_g, const _Float16* __restrict__ vtl_g, int t_total, int tp,
     const int* __restrict__ cu, const int* __restrict__ kv_seg, int nseg, int nhead,
-    const float* __restrict__ scales, float* __restrict__ out, int o_stride) {
+    const float* __restrict__ scales, float* __restrict__ out, int o_stride, float* __restrict__ lse_out) {
   __shared__ __align__(16) _Float16 Kh[2][KT2 * KH], Kl[2][KT2 * KH];
   __shared__ __align__(16) _Float16 Vth[2][HD * VH], Vtl[2][HD * VH];
   // 1-D grid: all query tiles of one (segment, head) -- which stream the same
@@ -822,6 +822,12 @@ __global__ __launch_bounds__(256, WPS) void k_attn_h3(
     float l_run = LAZY ? psum_a[h] + psum_b[h] : psum2[h][0] + psum2[h][1];
     l_run += __shfl_xor(l_run, 32, 64);
     const int qi = q0 + wave * QWN + 32 * h + l31;
+    if constexpr (LAZY) {
+      // log2 sum_j 2^(s_ij) of the query's scores (s in the kernel's base-2 units = log2(e) q.k / sqrt(d)): the
+      // probabilities above are 2^(s - m_ref + off) with negm = off - m_ref.  Handed to the backward (training).
+      if (lse_out != nullptr && qi < qlen && lh == 0)
+        lse_out[(size_t)(qbeg + qi) * nhead + head] = __builtin_amdgcn_logf(l_run) - negm[h][0];
+    }
     if (qi < qlen) {
       const float inv = (l_run > 0.f ? 1.0f / l_run : 0.f) * scales[3];   // 2^-ev undoes the V multiplier
       float* op = out + (size_t)(qbeg + qi) * o_stride + hoff;
@@ -951,14 +957,26 @@ int carve(void* ws, size_t ws_bytes, int t, int nseg, int d, size_t tp, AttnPlan
   return 0;
 }
 
+int env_attn_nq() {
+  static const int nq = [] { const char* e = getenv("SPR_ATTN_NQ"); return (e != nullptr && e[0] == '2') ? 2 : 1; }();
+  return nq;
+}
+bool env_attn_lazy() {   // lazy softmax reference (k_attn_h3<*, true>) unless SPR_ATTN_LAZY=0 (A/B against the eager form)
+  static const bool lazy = [] { const char* e = getenv("SPR_ATTN_LAZY"); return e == nullptr || e[0] != '0'; }();
+  return lazy;
+}
+// does the core launched for `mode` write the per-query log-sum-exp (lse_out)?  Every lazy-softmax form does.
+bool attn_core_writes_lse(int mode) { return mode != 0 && (env_attn_nq() == 1 || env_attn_lazy()); }
+
 int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int* kv_seg, int nseg,
-                int max_len_host, int nhead, float* out, int o_stride, int mode, hipStream_t stream) {
+                int max_len_host, int nhead, float* out, int o_stride, int mode, hipStream_t stream,
+                float* lse_out = nullptr) {
   ProfScope prof(stream, -1, t);
   // Default since round 4: 32 queries per wave with a 168-register budget, three waves per SIMD (147 VGPRs in split
   // mode): 927 vs 956 us per call at the bench shape, 452 vs 458 us in mode 2.  SPR_ATTN_NQ=2 selects the 64-query /
   // two-wave form.  (Four waves per SIMD -- 118 VGPRs in mode 2, 128 with 42 spilled registers in split mode --
   // measured 452 and 1 171 us: occupancy is not what this kernel waits for)
-  static const int nq = [] { const char* e = getenv("SPR_ATTN_NQ"); return (e != nullptr && e[0] == '2') ? 2 : 1; }();
+  const int nq = env_attn_nq();
   if (nq == 1) {
     dim3 grid1(cdiv(max_len_host, QB2 / 2) * nhead * nseg);
     // experiment switch (profiles/r04_attn_counters.txt): the same kernel compiled for FOUR waves per SIMD
@@ -966,10 +984,10 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
     if (wps4) {
       if (mode == 2)
         hipLaunchKernelGGL((k_attn_h3<false, true, 1, 4>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
-                           pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+                           pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
       else
         hipLaunchKernelGGL((k_attn_h3<true, true, 1, 4>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
-                           pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+                           pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
       SPR_LAUNCH_CHECK();
       return 0;
     }
@@ -977,61 +995,61 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
     if (pipe == 1) {        // experiment: the two key halves of a tile staggered inside the wave (tile_pipe)
       if (mode == 2)
         hipLaunchKernelGGL((k_attn_h3<false, true, 1, 3, true>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl,
-                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
       else
         hipLaunchKernelGGL((k_attn_h3<true, true, 1, 3, true>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl,
-                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
       SPR_LAUNCH_CHECK();
       return 0;
     }
     if (pipe == 2) {        // the same at two waves per SIMD (256 registers)
       if (mode == 2)
         hipLaunchKernelGGL((k_attn_h3<false, true, 1, 2, true>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl,
-                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
       else
         hipLaunchKernelGGL((k_attn_h3<true, true, 1, 2, true>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl,
-                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
       SPR_LAUNCH_CHECK();
       return 0;
     }
     if (mode == 2)
       hipLaunchKernelGGL((k_attn_h3<false, true, 1, 3>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
-                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
     else
       hipLaunchKernelGGL((k_attn_h3<true, true, 1, 3>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
-                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
     SPR_LAUNCH_CHECK();
     return 0;
   }
   dim3 grid(cdiv(max_len_host, QB2) * nhead * nseg);
   // lazy softmax reference (k_attn_h3<*, true>) unless SPR_ATTN_LAZY=0 (A/B timing against the eager form)
-  static const bool lazy = [] { const char* e = getenv("SPR_ATTN_LAZY"); return e == nullptr || e[0] != '0'; }();
+  const bool lazy = env_attn_lazy();
   if (lazy) {
     if (mode == 2)
       hipLaunchKernelGGL((k_attn_h3<false, true>), grid, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
-                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
     else
       hipLaunchKernelGGL((k_attn_h3<true, true>), grid, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
-                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
     SPR_LAUNCH_CHECK();
     return 0;
   }
   if (mode == 2)
     hipLaunchKernelGGL(k_attn_h3<false>, grid, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth, pl.vtl,
-                       t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+                       t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
   else
     hipLaunchKernelGGL(k_attn_h3<true>, grid, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth, pl.vtl,
-                       t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride);
+                       t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
   SPR_LAUNCH_CHECK();
   return 0;
 }
 }  // namespace
 
-extern "C" int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k, int k_stride,
-                                   const float* v, int v_stride, const int* cu,
-                                   const int* kv_seg, int t, int nseg, int max_len_host, int nhead,
-                                   int head_dim, float scale, float* out, int o_stride, void* ws,
-                                   size_t ws_bytes, void* stream_) {
+static int attn_varlen_fwd_impl(const float* q, int q_stride, const float* k, int k_stride,
+                               const float* v, int v_stride, const int* cu,
+                               const int* kv_seg, int t, int nseg, int max_len_host, int nhead,
+                               int head_dim, float scale, float* out, int o_stride, float* lse_out, void* ws,
+                               size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(head_dim == HD, "attention: head_dim must be %d (got %d)", HD, head_dim);
   SPR_REQUIRE(t >= 1 && nseg >= 1 && nhead >= 1 && max_len_host >= 1, "attention: bad sizes");
@@ -1063,7 +1081,30 @@ extern "C" int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k,
                      v, v_stride, cu, nseg, d_model, t, (int)tp, sm.scales, pl.qh, pl.ql, pl.kh, pl.kl,
                      pl.vth, pl.vtl);
   SPR_LAUNCH_CHECK();
-  return launch_core(pl, t, tp, cu, kv_seg, nseg, max_len_host, nhead, out, o_stride, mode, stream);
+  return launch_core(pl, t, tp, cu, kv_seg, nseg, max_len_host, nhead, out, o_stride, mode, stream, lse_out);
+}
+
+extern "C" int spr_attn_varlen_fwd(const float* q, int q_stride, const float* k, int k_stride,
+                                   const float* v, int v_stride, const int* cu,
+                                   const int* kv_seg, int t, int nseg, int max_len_host, int nhead,
+                                   int head_dim, float scale, float* out, int o_stride, void* ws,
+                                   size_t ws_bytes, void* stream_) {
+  return attn_varlen_fwd_impl(q, q_stride, k, k_stride, v, v_stride, cu, kv_seg, t, nseg, max_len_host, nhead, head_dim,
+                              scale, out, o_stride, nullptr, ws, ws_bytes, stream_);
+}
+
+// The same, additionally handing out lse [t, nhead] = log2 sum_j 2^(log2(e) q_i.k_j scale) per query and head for
+// spr_attn_varlen_bwd_lse (the backward then skips its own pass over the keys).  *lse_written = 0 when the
+// configured core does not produce it (exact-f32 mode, the eager-softmax experiment): lse is then untouched.
+extern "C" int spr_attn_varlen_fwd_lse(const float* q, int q_stride, const float* k, int k_stride, const float* v,
+                                       int v_stride, const int* cu, const int* kv_seg, int t, int nseg,
+                                       int max_len_host, int nhead, int head_dim, float scale, float* out, int o_stride,
+                                       float* lse, int* lse_written, void* ws, size_t ws_bytes, void* stream_) {
+  SPR_REQUIRE(lse != nullptr && lse_written != nullptr, "attention: lse / lse_written must not be null");
+  const bool can = attn_core_writes_lse(spr::g_attn_mode.load(std::memory_order_relaxed));
+  *lse_written = can ? 1 : 0;
+  return attn_varlen_fwd_impl(q, q_stride, k, k_stride, v, v_stride, cu, kv_seg, t, nseg, max_len_host, nhead, head_dim,
+                              scale, out, o_stride, can ? lse : nullptr, ws, ws_bytes, stream_);
 }
 
 extern "C" size_t spr_attn_inproj_workspace_bytes(int t, int nseg, int nhead, int head_dim) {

@@ -639,7 +639,8 @@ constexpr int DQ_BUF_HALVES = 4 * R_HALVES + 2 * C_HALVES;     // K: R + C plane
 constexpr int DKV_BUF_HALVES = 4 * R_HALVES + 4 * C_HALVES;    // Q and dO: R + C planes
 
 // grid (query tile, head, query segment)
-template <bool PL>
+// HL: the per-query log-sum-exp comes from the forward (a.lse, spr_attn_varlen_fwd_lse): no sweep 1
+template <bool PL, bool HL>
 __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void k_attn_bwd_dq_h(const AttnBwdArgs a, const float* __restrict__ scales,
                                                           const BwdPlanes pl) {
   __shared__ __align__(16) _Float16 tiles[NB * DQ_BUF_HALVES];
@@ -679,6 +680,10 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void k_attn_bwd_dq_h(const At
   const float dq_row = a.dsum[(size_t)(qbeg + qic) * a.nhead + head] * (sv * sdo);
   const int ntile = (klen + BT - 1) / BT;
 
+  float lse;
+  if constexpr (HL) {
+    lse = a.lse[(size_t)(qbeg + qic) * a.nhead + head];
+  } else {
   // ---- sweep 1: L = log2 sum_j exp2(c s_j) per query ----
   float m_run = -INFINITY, l_run = 0.f;
   {
@@ -733,7 +738,6 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void k_attn_bwd_dq_h(const At
     red_l[kb][32 * qb + l31] = l_run;
   }
   __syncthreads();
-  float lse;
   {
     const float m0 = red_m[0][32 * qb + l31], m1 = red_m[1][32 * qb + l31];
     const float l0 = red_l[0][32 * qb + l31], l1 = red_l[1][32 * qb + l31];
@@ -746,6 +750,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void k_attn_bwd_dq_h(const At
   if (kb == 0 && h == 0 && qvalid) a.lse[(size_t)(qbeg + qi) * a.nhead + head] = lse;
   __syncthreads();
 
+  }
   // ---- sweep 2: dQ^T[d][query] = sum_keys K^T dS^T ----
   f32x16 acc;
 #pragma unroll
@@ -988,11 +993,11 @@ extern "C" size_t spr_attn_bwd_workspace_bytes2(int t, int nseg, int nhead) {
 // q, k, v, out (the forward's output), dout: [t, nhead * 32] with unit inner stride and the given row strides;
 // kv_seg: key segment of every query segment -- must be a permutation; q_seg: its inverse.
 // dq, dk, dv: [t, nhead * 32] contiguous, fully written.
-extern "C" int spr_attn_varlen_bwd(const float* q, int q_stride, const float* k, int k_stride, const float* v,
-                                   int v_stride, const float* out, int o_stride, const float* dout, int do_stride,
-                                   const int* cu, const int* kv_seg, const int* q_seg, int t, int nseg,
-                                   int max_len_host, int nhead, int head_dim, float scale, float* dq, float* dk,
-                                   float* dv, void* ws, size_t ws_bytes, void* stream_) {
+static int attn_varlen_bwd_impl(const float* q, int q_stride, const float* k, int k_stride, const float* v,
+                               int v_stride, const float* out, int o_stride, const float* dout, int do_stride,
+                               const float* lse_in, const int* cu, const int* kv_seg, const int* q_seg, int t, int nseg,
+                               int max_len_host, int nhead, int head_dim, float scale, float* dq, float* dk,
+                               float* dv, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(head_dim == BHD, "attn_bwd: head_dim must be 32 (got %d)", head_dim);
   SPR_REQUIRE(q && k && v && out && dout && cu && kv_seg && q_seg && dq && dk && dv, "attn_bwd: null operand");
@@ -1007,6 +1012,9 @@ extern "C" int spr_attn_varlen_bwd(const float* q, int q_stride, const float* k,
   a.lse = w.take<float>((size_t)t * nhead);
   a.dsum = w.take<float>((size_t)t * nhead);
   SPR_REQUIRE(a.dsum != nullptr, "attn_bwd: workspace carve failed");
+  // the forward's log-sum-exp (split-fp16 forms only: the exact-f32 kernels keep their own sweep)
+  const bool have_lse = lse_in != nullptr && attn_mode() != 0;
+  if (have_lse) a.lse = const_cast<float*>(lse_in);
   a.q = q; a.k = k; a.v = v; a.out = out; a.dout = dout;
   a.qs = q_stride; a.ks = k_stride; a.vs = v_stride; a.os = o_stride; a.dos = do_stride;
   a.cu = cu; a.kv_seg = kv_seg; a.q_seg = q_seg; a.nseg = nseg; a.nhead = nhead; a.scale = scale;
@@ -1043,7 +1051,10 @@ extern "C" int spr_attn_varlen_bwd(const float* q, int q_stride, const float* k,
       SPR_REQUIRE(pl.cst != nullptr, "attn_bwd: workspace carve failed");
       hipLaunchKernelGGL(k_attn_bwd_cst, dim3(1), dim3(64), 0, stream, cu, nseg, pl.cst);
       hipLaunchKernelGGL(k_attn_bwd_pack, dim3(cdiv(max_len_host, BT), nhead, 4 * nseg), dim3(256), 0, stream, a, pl, scales);
-      hipLaunchKernelGGL(k_attn_bwd_dq_h<true>, grid, dim3(256), 0, stream, a, scales, pl);
+      if (have_lse)
+        hipLaunchKernelGGL((k_attn_bwd_dq_h<true, true>), grid, dim3(256), 0, stream, a, scales, pl);
+      else
+        hipLaunchKernelGGL((k_attn_bwd_dq_h<true, false>), grid, dim3(256), 0, stream, a, scales, pl);
       static const int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv_h<true>),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dkv_lds);
       SPR_REQUIRE(attr_rc == 0, "attn_bwd: cannot reserve %zu bytes of LDS", dkv_lds);
@@ -1051,7 +1062,10 @@ extern "C" int spr_attn_varlen_bwd(const float* q, int q_stride, const float* k,
       SPR_LAUNCH_CHECK();
       return 0;
     }
-    hipLaunchKernelGGL(k_attn_bwd_dq_h<false>, grid, dim3(256), 0, stream, a, scales, pl);
+    if (have_lse)
+      hipLaunchKernelGGL((k_attn_bwd_dq_h<false, true>), grid, dim3(256), 0, stream, a, scales, pl);
+    else
+      hipLaunchKernelGGL((k_attn_bwd_dq_h<false, false>), grid, dim3(256), 0, stream, a, scales, pl);
     static const int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k_attn_bwd_dkv_h<false>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)dkv_lds);
     SPR_REQUIRE(attr_rc == 0, "attn_bwd: cannot reserve %zu bytes of LDS", dkv_lds);
@@ -1063,4 +1077,23 @@ extern "C" int spr_attn_varlen_bwd(const float* q, int q_stride, const float* k,
   hipLaunchKernelGGL(k_attn_bwd_dkv, grid, dim3(256), 0, stream, a);
   SPR_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int spr_attn_varlen_bwd(const float* q, int q_stride, const float* k, int k_stride, const float* v,
+                                   int v_stride, const float* out, int o_stride, const float* dout, int do_stride,
+                                   const int* cu, const int* kv_seg, const int* q_seg, int t, int nseg,
+                                   int max_len_host, int nhead, int head_dim, float scale, float* dq, float* dk,
+                                   float* dv, void* ws, size_t ws_bytes, void* stream_) {
+  return attn_varlen_bwd_impl(q, q_stride, k, k_stride, v, v_stride, out, o_stride, dout, do_stride, nullptr, cu, kv_seg,
+                              q_seg, t, nseg, max_len_host, nhead, head_dim, scale, dq, dk, dv, ws, ws_bytes, stream_);
+}
+
+// lse [t, nhead]: what spr_attn_varlen_fwd_lse handed out for the same q, k (NULL: computed here)
+extern "C" int spr_attn_varlen_bwd_lse(const float* q, int q_stride, const float* k, int k_stride, const float* v,
+                                       int v_stride, const float* out, int o_stride, const float* dout, int do_stride,
+                                       const float* lse, const int* cu, const int* kv_seg, const int* q_seg, int t,
+                                       int nseg, int max_len_host, int nhead, int head_dim, float scale, float* dq,
+                                       float* dk, float* dv, void* ws, size_t ws_bytes, void* stream_) {
+  return attn_varlen_bwd_impl(q, q_stride, k, k_stride, v, v_stride, out, o_stride, dout, do_stride, lse, cu, kv_seg,
+                              q_seg, t, nseg, max_len_host, nhead, head_dim, scale, dq, dk, dv, ws, ws_bytes, stream_);
 }

@@ -667,7 +667,9 @@ def attention(q, k, v, cu, kv_seg, max_len: int, nhead: int, out=None, lens_host
     return attention_raw(q, k, v, cu, kv_seg, max_len, nhead, out)
 
 
-def attention_raw(q, k, v, cu, kv_seg, max_len: int, nhead: int, out=None) -> torch.Tensor:
+def attention_raw(q, k, v, cu, kv_seg, max_len: int, nhead: int, out=None, want_lse: bool = False):
+    """want_lse: returns (out, lse) with lse [T, nhead] = the per-query log2-sum-exp the backward can reuse
+    (spr_attn_varlen_fwd_lse), or (out, None) when the configured core does not produce it."""
     for t, nm in ((q, "q"), (k, "k"), (v, "v")):
         if not t.is_cuda or t.dtype != torch.float32 or t.stride(1) != 1:
             raise RuntimeError(f"attention: {nm} must be a float32 device tensor with unit inner stride")
@@ -680,6 +682,15 @@ def attention_raw(q, k, v, cu, kv_seg, max_len: int, nhead: int, out=None) -> to
         out = torch.empty((T, d), dtype=torch.float32, device=q.device)
     L = _lib.lib()
     ws = _workspace(L.spr_attn_workspace_bytes(T, nseg, nhead, hd), q.device)
+    if want_lse:
+        lse = torch.empty((T, nhead), dtype=torch.float32, device=q.device)
+        written = ctypes.c_int(0)
+        _lib.check(L.spr_attn_varlen_fwd_lse(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0),
+                                             _ptr(cu), _ptr(kv_seg), T, nseg, int(max_len), nhead, hd,
+                                             1.0 / math.sqrt(hd), _ptr(out), out.stride(0), _ptr(lse),
+                                             ctypes.byref(written), _ptr(ws), ws.numel(), _stream(q)),
+                   "spr_attn_varlen_fwd_lse")
+        return out, (lse if written.value else None)
     _lib.check(L.spr_attn_varlen_fwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0),
                                      _ptr(cu), _ptr(kv_seg), T, nseg, int(max_len), nhead, hd,
                                      1.0 / math.sqrt(hd), _ptr(out), out.stride(0), _ptr(ws), ws.numel(),
@@ -704,7 +715,7 @@ def _segment_perms(kv_seg_host, device):
     return c
 
 
-def attention_bwd(q, k, v, out, dout, cu, kv_seg_host, max_len: int, nhead: int):
+def attention_bwd(q, k, v, out, dout, cu, kv_seg_host, max_len: int, nhead: int, lse=None):
     """Gradients (dq, dk, dv) of attention_raw (spr_attn_varlen_bwd: flash-style; the arithmetic follows
     set_attn_mode: split-fp16 like the forward, or exact f32 MFMA in mode 0)."""
     for t, nm in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout")):
@@ -720,10 +731,10 @@ def attention_bwd(q, k, v, out, dout, cu, kv_seg_host, max_len: int, nhead: int)
     dv = torch.empty_like(dq)
     L = _lib.lib()
     ws = _workspace(L.spr_attn_bwd_workspace_bytes2(T, nseg, nhead), q.device)      # with room for the operand planes
-    _lib.check(L.spr_attn_varlen_bwd(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(out),
-                                     out.stride(0), _ptr(dout), dout.stride(0), _ptr(cu), _ptr(kv), _ptr(inv), T, nseg,
-                                     int(max_len), nhead, hd, 1.0 / math.sqrt(hd), _ptr(dq), _ptr(dk), _ptr(dv),
-                                     _ptr(ws), ws.numel(), _stream(q)), "spr_attn_varlen_bwd")
+    _lib.check(L.spr_attn_varlen_bwd_lse(_ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(out),
+                                         out.stride(0), _ptr(dout), dout.stride(0), _ptr(lse), _ptr(cu), _ptr(kv),
+                                         _ptr(inv), T, nseg, int(max_len), nhead, hd, 1.0 / math.sqrt(hd), _ptr(dq),
+                                         _ptr(dk), _ptr(dv), _ptr(ws), ws.numel(), _stream(q)), "spr_attn_varlen_bwd_lse")
     return dq, dk, dv
 
 
