@@ -285,6 +285,38 @@ __global__ void k_in_bwd_apply(const float* __restrict__ x, const float* __restr
   dx[gid] = rstd[s] * (float)(((double)g - m1[s]) - (double)xh * m2[s]);
 }
 
+// the same, four channels per thread (c % 4 == 0, 16-byte aligned tensors): one segment search and one index
+// division per float4 instead of per element; element arithmetic unchanged (bit for bit the results above)
+__global__ void k_in_bwd_apply4(const float* __restrict__ x, const float* __restrict__ out,
+                                const float* __restrict__ dout, const int* __restrict__ cu, int n, int nb, int c,
+                                int norm, float slope, const float* __restrict__ mean,
+                                const float* __restrict__ rstd, const double* __restrict__ m1,
+                                const double* __restrict__ m2, float* __restrict__ dx, float* __restrict__ dadd) {
+  const int c4 = c >> 2;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)n * c4) return;
+  const int row = (int)(gid / c4), ch = 4 * (int)(gid % c4);
+  const float4 d4 = reinterpret_cast<const float4*>(dout)[gid], o4 = reinterpret_cast<const float4*>(out)[gid];
+  float g[4] = {d4.x * (o4.x > 0.f ? 1.f : slope), d4.y * (o4.y > 0.f ? 1.f : slope),
+                d4.z * (o4.z > 0.f ? 1.f : slope), d4.w * (o4.w > 0.f ? 1.f : slope)};
+  if (dadd) reinterpret_cast<float4*>(dadd)[gid] = make_float4(g[0], g[1], g[2], g[3]);
+  if (!norm) {
+    reinterpret_cast<float4*>(dx)[gid] = make_float4(g[0], g[1], g[2], g[3]);
+    return;
+  }
+  const int cloud = find_segment(cu, nb, row);
+  const size_t s = (size_t)cloud * c + ch;
+  const float4 x4 = reinterpret_cast<const float4*>(x)[gid];
+  const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+  float r[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float xh = (xv[e] - mean[s + e]) * rstd[s + e];
+    r[e] = rstd[s + e] * (float)(((double)g[e] - m1[s + e]) - (double)xh * m2[s + e]);
+  }
+  reinterpret_cast<float4*>(dx)[gid] = make_float4(r[0], r[1], r[2], r[3]);
+}
+
 __global__ void k_maxpool(const float* __restrict__ x, int ns, int c, const int* __restrict__ idx,
                           int nq, int idx_stride, int k, float* __restrict__ out, float* __restrict__ out_range,
                           int nslots) {
@@ -424,8 +456,12 @@ extern "C" int spr_instnorm_bwd(const float* x, const float* out, const float* d
                        m1, m2);
     SPR_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_in_bwd_apply, dim3(cdiv((long)n * c, 256)), dim3(256), 0, stream, x, out, dout, cu, n, nb, c,
-                     norm, slope, mean, rstd, m1, m2, dx, dadd);
+  if (c % 4 == 0 && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)dx | (uintptr_t)dadd) & 15) == 0)
+    hipLaunchKernelGGL(k_in_bwd_apply4, dim3(cdiv((long)n * (c / 4), 256)), dim3(256), 0, stream, x, out, dout, cu, n, nb,
+                       c, norm, slope, mean, rstd, m1, m2, dx, dadd);
+  else
+    hipLaunchKernelGGL(k_in_bwd_apply, dim3(cdiv((long)n * c, 256)), dim3(256), 0, stream, x, out, dout, cu, n, nb, c,
+                       norm, slope, mean, rstd, m1, m2, dx, dadd);
   SPR_LAUNCH_CHECK();
   return 0;
 }
