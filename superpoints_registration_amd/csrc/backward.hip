@@ -21,6 +21,19 @@ __global__ void k_act_bwd(const float* __restrict__ y, const float* __restrict__
   out[i] = act == SPR_ACT_RELU ? (v > 0.f ? dy[i] : 0.f) : act == SPR_ACT_SIGMOID ? dy[i] * v * (1.f - v) : dy[i];
 }
 
+__global__ void k_act_bwd4(const float4* __restrict__ y, const float4* __restrict__ dy, int act, long n4,
+                           float4* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = y[i], d = dy[i];
+  float4 r = d;
+  if (act == SPR_ACT_RELU)
+    r = make_float4(v.x > 0.f ? d.x : 0.f, v.y > 0.f ? d.y : 0.f, v.z > 0.f ? d.z : 0.f, v.w > 0.f ? d.w : 0.f);
+  else if (act == SPR_ACT_SIGMOID)
+    r = make_float4(d.x * v.x * (1.f - v.x), d.y * v.y * (1.f - v.y), d.z * v.z * (1.f - v.z), d.w * v.w * (1.f - v.w));
+  out[i] = r;
+}
+
 // column sums of x [m, n] over a fixed number of row chunks: parts [nchunk][n]
 constexpr int kColChunks = 512;
 __global__ __launch_bounds__(256) void k_colsum_parts(const float* __restrict__ x, long m, int n,
@@ -254,6 +267,57 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd(const float* __restrict__ x
   if (bi >= 0) fx_add(acc + (size_t)bi * c + ch, dy[gid], fx);
 }
 
+// the same with four channels per thread: the neighbour ids are read once per float4 and the gathered rows arrive as
+// 16-byte loads, four in flight (the scalar form above walked k dependent 4-byte loads per element)
+__global__ __launch_bounds__(256) void k_maxpool_bwd4(const float* __restrict__ x, int ns, int c, const int* __restrict__ idx,
+                                                      int nq, int idx_stride, int k, const float* __restrict__ dy,
+                                                      const float* __restrict__ parts, unsigned long long* __restrict__ acc) {
+  __shared__ float sh[17];
+  const int fx = fx_exp(parts, sh, 1.0f);
+  const int c4 = c >> 2;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)nq * c4) return;
+  const int row = (int)(gid / c4), q = (int)(gid % c4);
+  const int* ir = idx + (size_t)row * idx_stride;
+  float best[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+  int bi[4] = {-1, -1, -1, -1};
+  auto take = [&](int id, const float4& v) {
+    const bool ok = id >= 0 && id < ns;
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (e[u] > best[u]) {         // first maximum wins (torch.max's index on ties), shadow rows read as 0
+        best[u] = e[u];
+        bi[u] = ok ? id : -1;
+      }
+  };
+  int j = 0;
+  for (; j + 4 <= k; j += 4) {
+    int id[4];
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) id[u] = ir[j + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (id[u] >= 0 && id[u] < ns) v[u] = reinterpret_cast<const float4*>(x + (size_t)id[u] * c)[q];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) take(id[u], v[u]);
+  }
+  for (; j < k; ++j) {
+    const int id = ir[j];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (id >= 0 && id < ns) v = reinterpret_cast<const float4*>(x + (size_t)id * c)[q];
+    take(id, v);
+  }
+  const float4 g = reinterpret_cast<const float4*>(dy)[gid];
+  const float ge[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (bi[u] >= 0) fx_add(acc + (size_t)bi[u] * c + 4 * q + u, ge[u], fx);
+}
+
 // rows gathered forward (spr_gather_rows) -> scatter-add backward
 __global__ __launch_bounds__(256) void k_scatter_rows_add(const float* __restrict__ dy, const int* __restrict__ idx, int n,
                                                           int c, int n_src, const float* __restrict__ parts,
@@ -469,7 +533,11 @@ using namespace spr;
 extern "C" int spr_act_bwd(const float* y, const float* dy, int act, long n, float* out, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(y && dy && out && n >= 1 && act >= 0 && act <= 2, "act_bwd: bad arguments");
-  hipLaunchKernelGGL(k_act_bwd, dim3(cdiv(n, 256)), dim3(256), 0, stream, y, dy, act, n, out);
+  if (n % 4 == 0 && (((uintptr_t)y | (uintptr_t)dy | (uintptr_t)out) & 15) == 0)
+    hipLaunchKernelGGL(k_act_bwd4, dim3(cdiv(n / 4, 256)), dim3(256), 0, stream, (const float4*)y, (const float4*)dy, act,
+                       n / 4, (float4*)out);
+  else
+    hipLaunchKernelGGL(k_act_bwd, dim3(cdiv(n, 256)), dim3(256), 0, stream, y, dy, act, n, out);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -547,8 +615,12 @@ extern "C" int spr_maxpool_bwd(const float* x, int ns, int c, const int* idx, in
   FxScratch f;
   if (int rc = fx_scratch(ws, ws_bytes, ns, c, stream, &f)) return rc;
   if (int rc = launch_absmax(dy, nq, c, c, f.parts, stream)) return rc;
-  hipLaunchKernelGGL(k_maxpool_bwd, dim3(cdiv((long)nq * c, 256)), dim3(256), 0, stream, x, ns, c, idx, nq,
-                     idx_stride, k, dy, f.parts, f.acc);
+  if (c % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0)
+    hipLaunchKernelGGL(k_maxpool_bwd4, dim3(cdiv((long)nq * (c / 4), 256)), dim3(256), 0, stream, x, ns, c, idx, nq,
+                       idx_stride, k, dy, f.parts, f.acc);
+  else
+    hipLaunchKernelGGL(k_maxpool_bwd, dim3(cdiv((long)nq * c, 256)), dim3(256), 0, stream, x, ns, c, idx, nq,
+                       idx_stride, k, dy, f.parts, f.acc);
   hipLaunchKernelGGL(k_fx_to_float, dim3(cdiv((long)ns * c, 256)), dim3(256), 0, stream, f.acc, (long)ns * c, f.parts,
                      1.0f, dx);
   SPR_LAUNCH_CHECK();
