@@ -140,6 +140,11 @@ def weight_transposed(w: torch.Tensor) -> torch.Tensor:
         c[4].acquire()
         return c[0]
     wt = w.detach().t().contiguous()
+    # max |W^T| = max |W|: the transposed copy shares the weight's measured range instead of being scanned itself
+    r, n = _static_range(w)
+    if r is not None:
+        rw = getattr(w, '_spr_range', None)
+        _set_range(wt, r, n, rw[5] if rw is not None else None)
     w._spr_wt = (wt, w._version, w.data_ptr(), _range_epoch[0], _StreamGuard(wt))
     return wt
 
