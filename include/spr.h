@@ -213,6 +213,10 @@ int spr_linear(const float* x, int m, int k, const float* w, int n,
  * (out_range_n zeroed slots, a power of two chosen by the caller); spr_kpconv_fwd_r accepts x_range / w_range. */
 int spr_range_parts(void);
 int spr_absmax(const float* x, long rows, int cols, long stride, float* parts, void* stream);
+/* max |x| of many contiguous tensors in ONE launch (all weights of a model at the start of a training step).
+ * jobs_dev: njobs device records {const float* x; long long n_elements;}; parts_out [njobs][parts_per_job]:
+ * row j is a range (parts_per_job partials) of tensor j, usable wherever spr_absmax partials are. */
+int spr_absmax_multi(const void* jobs_dev, int njobs, int parts_per_job, float* parts_out, void* stream);
 int spr_linear_r(const float* x, int m, int k, const float* w, int n, const float* bias,
                  const float* residual, int act, float* out, const float* x_range,
                  int x_range_n, const float* w_range, int w_range_n, float* out_range,

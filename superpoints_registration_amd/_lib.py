@@ -44,6 +44,7 @@ SIGNATURES = {
     "spr_linear": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "spr_linear_r": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _sz, _vp]),
     "spr_range_parts": (_i, []),
+    "spr_absmax_multi": (_i, [_vp, _i, _i, _vp, _vp]),
     "spr_absmax": (_i, [_vp, _l, _i, _l, _vp, _vp]),
     "spr_kpconv_fwd_r": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp,
                               _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),

@@ -184,6 +184,37 @@ int spr::launch_absmax2(const float* x0, long rows0, int cols0, long stride0, fl
   return 0;
 }
 
+// max |x| of MANY contiguous tensors in one launch (the weights of a model at the start of a training step: ~150
+// tensors of 10^2 .. 10^6 elements, each of which used to cost its own 512-workgroup launch).  jobs_dev: njobs records
+// {pointer, element count}; parts_out [njobs][parts_per_job].
+struct AbsmaxMultiJob {
+  const float* x;
+  long long n;
+};
+namespace {
+__global__ __launch_bounds__(256) void k_absmax_multi(const AbsmaxMultiJob* __restrict__ jobs, int parts_per_job,
+                                                      float* __restrict__ parts_out) {
+  const AbsmaxMultiJob j = jobs[blockIdx.y];
+  __shared__ float sh[4];
+  const long chunk = (j.n + parts_per_job - 1) / parts_per_job;
+  const long i0 = (long)blockIdx.x * chunk, i1 = i0 + chunk < j.n ? i0 + chunk : j.n;
+  float m = 0.f;
+  for (long i = i0 + threadIdx.x; i < i1; i += 256) m = fmaxf(m, amag(j.x[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) parts_out[(size_t)blockIdx.y * parts_per_job + blockIdx.x] = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+}  // namespace
+extern "C" int spr_absmax_multi(const void* jobs_dev, int njobs, int parts_per_job, float* parts_out, void* stream_) {
+  SPR_REQUIRE(jobs_dev != nullptr && parts_out != nullptr && njobs >= 1 && njobs <= 65535 && parts_per_job >= 1 &&
+                  parts_per_job <= 1024, "absmax_multi: bad arguments");
+  hipLaunchKernelGGL(k_absmax_multi, dim3(parts_per_job, njobs), dim3(256), 0, (hipStream_t)stream_,
+                     (const AbsmaxMultiJob*)jobs_dev, parts_per_job, parts_out);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
 // Range of a tensor that does not change between calls (weights): measured once by the caller
 // and handed to spr_linear_r / spr_kpconv_fwd_r as w_range (spr_range_parts() floats).
 extern "C" int spr_range_parts(void) { return spr::kAmaxParts; }

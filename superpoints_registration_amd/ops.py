@@ -132,6 +132,36 @@ def _static_range(w: torch.Tensor):
     return parts, n
 
 
+_PRIME_PARTS = 16
+
+
+def prime_weight_ranges(params) -> int:
+    """Measures the ranges of all (float32, contiguous, device) parameters whose cached range is stale in ONE launch
+    (spr_absmax_multi) and attaches them like _static_range would: after an optimizer step every weight's version
+    counter has moved, and ~150 separate measuring launches (16 us each) opened every training forward.  Returns the
+    number of tensors measured."""
+    if not _HANDOVER:
+        return 0
+    todo = [p for p in params if isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == torch.float32
+            and p.dim() >= 2 and p.is_contiguous() and p.numel() > 0 and _get_range(p)[0] is None]
+    if not todo:
+        return 0
+    dev = todo[0].device
+    todo = [p for p in todo if p.device == dev]
+    rec = np.zeros((len(todo), 2), dtype=np.int64)
+    for i, p in enumerate(todo):
+        rec[i, 0] = p.data_ptr()
+        rec[i, 1] = p.numel()
+    jobs = torch.from_numpy(rec).to(dev)
+    parts = torch.empty((len(todo), _PRIME_PARTS), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().spr_absmax_multi(_ptr(jobs), len(todo), _PRIME_PARTS, _ptr(parts), _stream(parts)),
+               "spr_absmax_multi")
+    guard = _StreamGuard(parts)
+    for i, p in enumerate(todo):
+        _set_range(p, parts[i], _PRIME_PARTS, guard)
+    return len(todo)
+
+
 def weight_transposed(w: torch.Tensor) -> torch.Tensor:
     """Contiguous W^T of a [n, k] weight, kept on the tensor per (storage, version) like its range (the
     backward's dX = g W runs as the forward's NT product on it); guarded for readers on other streams."""

@@ -104,6 +104,8 @@ class RegTR(nn.Module):
         if not self.training and torch.is_grad_enabled():
             with torch.no_grad():
                 return self._forward(batch)
+        if self.training and torch.is_grad_enabled():
+            ops.prime_weight_ranges(self.parameters())      # one measuring launch for every weight the step moved
         return self._forward(batch)
 
     def _forward(self, batch):
