@@ -360,3 +360,25 @@ def test_weight_ranges_are_cached_per_version_and_follow_in_place_updates(device
     ops.invalidate_ranges()
     ops.linear(x, w)
     assert w._spr_range[4] == ops._range_epoch[0]
+
+
+def test_prime_weight_ranges_measures_all_stale_weights_in_one_launch(device):
+    """ops.prime_weight_ranges (spr_absmax_multi): the ranges attached in one launch are upper bounds equal to the
+    true maxima, are picked up by _static_range without another measurement, and go stale with the version counter."""
+    g = torch.Generator().manual_seed(2)
+    ws = [torch.randn(shape, generator=g).mul(scale).to(device).requires_grad_(True)
+          for shape, scale in (((256, 256), 1.0), ((1024, 256), 1e-3), ((15, 32, 32), 40.0), ((3, 5), 7.0), ((768, 256), 1e4))]
+    bias = torch.randn(256, generator=g).to(device)                     # 1-D: not a product operand, skipped
+    assert ops.prime_weight_ranges(ws + [bias]) == len(ws)
+    for w in ws:
+        parts, n = ops._get_range(w)
+        assert parts is not None and n == 16
+        assert float(parts[:n].max()) == float(w.detach().abs().max())
+        again, n2 = ops._static_range(w)
+        assert again.data_ptr() == parts.data_ptr() and n2 == n            # no second measurement
+    assert ops.prime_weight_ranges(ws) == 0                             # nothing stale
+    with torch.no_grad():
+        ws[1].mul_(3.0)                                                  # an optimizer step bumps the version
+    assert ops._get_range(ws[1])[0] is None
+    assert ops.prime_weight_ranges(ws) == 1
+    assert float(ops._get_range(ws[1])[0].max()) == float(ws[1].detach().abs().max())
