@@ -370,3 +370,45 @@ def test_match_and_sinkhorn_is_the_two_operators_bit_for_bit(device):
         assert torch.equal(a, b), nm
     v2, none, i2, w2, t2 = ops.match_and_sinkhorn(feat, xyz, cu, cu_host, B, alpha, beta, 3)
     assert none is None and torch.equal(v2, v0) and torch.equal(i2, i0) and torch.equal(w2, w0)
+
+
+def test_matching_heads_in_small_groups_of_pairs(device):
+    """The matching head processes the score matrices in groups that fit a byte budget (SPR_MATCH_GROUP_MB, read once
+    per process): a child process with a 1 MB budget -- one pair per group, five groups -- must reproduce this
+    process's one-group results bit for bit, through the separate operators and through spr_match_sinkhorn."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np, torch
+from superpoints_registration_amd import ops
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(3)
+n_l, m_l = [60, 333, 1, 129, 257], [47, 290, 5, 130, 64]
+cu_host = [0]
+for n in n_l + m_l:
+    cu_host.append(cu_host[-1] + n)
+T, B = cu_host[-1], len(n_l)
+feat = (torch.randn(T, 256, generator=g) * 0.7).to(dev)
+xyz = torch.randn(T, 3, generator=g).to(dev)
+cu = torch.tensor(cu_host, dtype=torch.int32, device=dev)
+alpha, beta = torch.tensor(0.8, device=dev), torch.tensor(-0.4, device=dev)
+w0, t0 = ops.sinkhorn_correspondences(feat, xyz, cu, cu_host, B, alpha, beta, 3)
+v0, v20, i0 = ops.match_dualsoftmax_top2(feat, cu, cu_host, B)
+v1, v21, i1, w1, t1 = ops.match_and_sinkhorn(feat, xyz, cu, cu_host, B, alpha, beta, 3, top2=True)
+for a, b in ((v0, v1), (v20, v21), (i0, i1), (w0, w1), (t0, t1)):
+    assert torch.equal(a, b)
+np.savez(sys.argv[1], v=v0.cpu().numpy(), v2=v20.cpu().numpy(), i=i0.cpu().numpy(), w=w0.cpu().numpy(), t=t0.cpu().numpy())
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, mb in (("one_group", "250"), ("per_pair", "1")):
+            env = dict(os.environ, SPR_MATCH_GROUP_MB=mb, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            path = os.path.join(tmp, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr[-2000:]
+            outs.append(dict(np.load(path)))
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
