@@ -586,6 +586,11 @@ int spr_kpconv_bwd_dx(const float* q_xyz, int nq, const float* s_xyz, int ns, co
                       int nbr_stride, int kmax, int cin, const float* kernel_points, int n_kp,
                       float kp_extent, const float* dwf, float* dx, void* ws, size_t ws_bytes,
                       void* stream);
+/* dwf_range: the max |dwf| partials published by the product that wrote dwf (spr_linear_r out_range); NULL = measured */
+int spr_kpconv_bwd_dx_r(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
+                        int nbr_stride, int kmax, int cin, const float* kernel_points, int n_kp,
+                        float kp_extent, const float* dwf, const float* dwf_range, int dwf_range_n, float* dx,
+                        void* ws, size_t ws_bytes, void* stream);
 int spr_softmax_rows(float* mat, const void* desc_dev, int nbatch, int max_m, void* stream);
 int spr_softmax_bwd_rows(const float* p, float* dp, const void* desc_dev, int nbatch, int max_m,
                          void* stream);

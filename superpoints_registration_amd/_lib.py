@@ -125,6 +125,7 @@ SIGNATURES = {
     "spr_scatter_rows_add": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "spr_kpconv_weighted_features": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp]),
     "spr_kpconv_bwd_dx": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "spr_kpconv_bwd_dx_r": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     "spr_softmax_rows": (_i, [_vp, _vp, _i, _i, _vp]),
     "spr_softmax_bwd_rows": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "spr_bce_logits_mean_bwd": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),

@@ -215,6 +215,11 @@ class KPConvFn(torch.autograd.Function):
                                                   ctx.kp_extent, _ops._ptr(wf), _ops._ptr(cnt), _ops._stream(x)),
                    "spr_kpconv_weighted_features")
         g = (dout / cnt.unsqueeze(1)).contiguous()
+        # |wf| <= kmax max|x| (every influence weight is <= 1): a bound within 2^3..2^5 of the true maximum, well
+        # inside what the split arithmetic absorbs -- the 1 GB tensor is not scanned for its range
+        xr, xr_n = _ops._get_range(x)
+        if xr is not None:
+            _ops._set_range(wf, xr[:xr_n] * float(kmax), int(xr_n))
         wflat = w.detach().contiguous().view(n_kp * cin, cout)
         dx = dw = None
         if ctx.needs_input_grad[3]:
@@ -228,10 +233,11 @@ class KPConvFn(torch.autograd.Function):
                 bgemm(g, wflat, dwf, [(0, 0, 0, nq, n_kp * cin, cout)], (cout, 1), (1, cout), (n_kp * cin, 1))
             dx = torch.empty((ns, cin), dtype=torch.float32, device=x.device)
             ws = _ops._workspace(L.spr_scatter_workspace_bytes(ns, cin), x.device)
-            _lib.check(L.spr_kpconv_bwd_dx(_ops._ptr(q_pts), nq, _ops._ptr(s_pts), ns, _ops._ptr(nbr32), int(stride), kmax,
-                                           cin, _ops._ptr(kp.detach().contiguous()), n_kp, ctx.kp_extent,
-                                           _ops._ptr(dwf), _ops._ptr(dx), _ops._ptr(ws), ws.numel(), _ops._stream(x)),
-                       "spr_kpconv_bwd_dx")
+            dr, dr_n = _ops._get_range(dwf)          # published by the product that wrote dwf: no second scan of it
+            _lib.check(L.spr_kpconv_bwd_dx_r(_ops._ptr(q_pts), nq, _ops._ptr(s_pts), ns, _ops._ptr(nbr32), int(stride), kmax,
+                                             cin, _ops._ptr(kp.detach().contiguous()), n_kp, ctx.kp_extent,
+                                             _ops._ptr(dwf), _ops._ptr(dr), int(dr_n), _ops._ptr(dx), _ops._ptr(ws),
+                                             ws.numel(), _ops._stream(x)), "spr_kpconv_bwd_dx_r")
         if ctx.needs_input_grad[4]:
             # the first layer (cin = 1: constant input) is the ill-conditioned sum: float64 accumulation
             dw = _tn_product(wf, g, nq, n_kp * cin, cout, f64=(cin == 1)).view(n_kp, cin, cout)

@@ -662,17 +662,53 @@ extern "C" int spr_kpconv_weighted_features(const float* q_xyz, int nq, const fl
   return 0;
 }
 
+namespace {
+// an externally published range (n partials) as the kAmaxParts partials the fixed-point kernels read
+__global__ __launch_bounds__(256) void k_range_to_parts(const float* __restrict__ range, int n, float* __restrict__ parts) {
+  __shared__ float sh[17];
+  const float m = block_absmax(range, sh, n);
+  for (int i = threadIdx.x; i < kAmaxParts; i += 256) parts[i] = i == 0 ? m : 0.f;
+}
+}  // namespace
+
+static int kpconv_bwd_dx_impl(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
+                              int nbr_stride, int kmax, int cin, const float* kernel_points, int n_kp,
+                              float kp_extent, const float* dwf, const float* dwf_range, int dwf_range_n, float* dx,
+                              void* ws, size_t ws_bytes, void* stream_);
+
 // dx [ns, cin] is fully written (ws: spr_scatter_workspace_bytes(ns, cin)); order-independent sums
 extern "C" int spr_kpconv_bwd_dx(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
                                  int nbr_stride, int kmax, int cin, const float* kernel_points, int n_kp,
                                  float kp_extent, const float* dwf, float* dx, void* ws, size_t ws_bytes,
                                  void* stream_) {
+  return kpconv_bwd_dx_impl(q_xyz, nq, s_xyz, ns, nbr, nbr_stride, kmax, cin, kernel_points, n_kp, kp_extent, dwf,
+                            nullptr, 0, dx, ws, ws_bytes, stream_);
+}
+// dwf_range: max |dwf| partials published by the product that wrote dwf (spr_linear_r's out_range): the 1 GB
+// tensor is then not scanned again for the fixed-point scale
+extern "C" int spr_kpconv_bwd_dx_r(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
+                                   int nbr_stride, int kmax, int cin, const float* kernel_points, int n_kp,
+                                   float kp_extent, const float* dwf, const float* dwf_range, int dwf_range_n, float* dx,
+                                   void* ws, size_t ws_bytes, void* stream_) {
+  SPR_REQUIRE(dwf_range == nullptr || dwf_range_n >= 1, "kpconv_bwd_dx: a range needs a count");
+  return kpconv_bwd_dx_impl(q_xyz, nq, s_xyz, ns, nbr, nbr_stride, kmax, cin, kernel_points, n_kp, kp_extent, dwf,
+                            dwf_range, dwf_range_n, dx, ws, ws_bytes, stream_);
+}
+
+static int kpconv_bwd_dx_impl(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr,
+                              int nbr_stride, int kmax, int cin, const float* kernel_points, int n_kp,
+                              float kp_extent, const float* dwf, const float* dwf_range, int dwf_range_n, float* dx,
+                              void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(nq > 0 && ns > 0 && cin >= 1 && n_kp >= 1 && n_kp <= kKPmax && kp_extent > 0.f && kmax >= 1 &&
                   kmax <= nbr_stride, "kpconv_bwd_dx: bad arguments");
   FxScratch f;
   if (int rc = fx_scratch(ws, ws_bytes, ns, cin, stream, &f)) return rc;
-  if (int rc = launch_absmax(dwf, nq, n_kp * cin, n_kp * cin, f.parts, stream)) return rc;
+  if (dwf_range != nullptr) {
+    hipLaunchKernelGGL(k_range_to_parts, dim3(1), dim3(256), 0, stream, dwf_range, dwf_range_n, f.parts);
+  } else if (int rc = launch_absmax(dwf, nq, n_kp * cin, n_kp * cin, f.parts, stream)) {
+    return rc;
+  }
   if (cin == 32)
     hipLaunchKernelGGL((k_kpconv_aux2<true, true>), dim3(cdiv(nq, 4)), dim3(256), 0, stream, q_xyz, nq, s_xyz, ns, nbr,
                        nbr_stride, kmax, (const float*)nullptr, cin, kernel_points, n_kp, 1.0f / kp_extent, dwf,
