@@ -179,6 +179,7 @@ def train_leg(cfg, args, dev):
     dt = time.perf_counter() - t0
     return dict(value=round(Bt * steps / dt, 3), unit="pairs/s", ms_per_step=round(1e3 * dt / steps, 2), steps=steps,
                 pairs_per_step=Bt, points_per_cloud=args.points,
+                note=f"--train-pairs {Bt}: BENCH_r04 and later use 16 pairs per step, r01-r03 used 4 (not comparable)",
                 stage_ms=dict(forward=round(stage[0] / steps, 2), loss=round(stage[1] / steps, 2),
                               backward=round(stage[2] / steps, 2), clip_adamw=round(stage[3] / steps, 2)),
                 loss_total=round(float(losses["total"].detach()), 5),

@@ -628,8 +628,12 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
           }
         }
       };
-      auto count = [&]() __attribute__((always_inline)) {
-        if (wave_valid) s_cnt += 4;
+      // stores a wave really issued since the last acquire.  Q / K blocks: four (all under the same lane mask).  V
+      // blocks: the second piece of each plane exists only when the wave has more than 16 tokens (its store sits
+      // behind its own execz branch) -- counting it for a ragged wave would let acquire() release a slot with up to
+      // two DMA pieces of the acquired chunk still in flight (an over-count waits for LESS).
+      auto count = [&](bool vblock) __attribute__((always_inline)) {
+        if (wave_valid) s_cnt += (vblock && tok_w + 16 >= seg_end) ? 2 : 4;
       };
       // block 0 (side: bias of block 1 into B)
       chunk_f(std::false_type{}, A, ph, pw, [&](int s) __attribute__((always_inline)) {
@@ -638,10 +642,11 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
       XSTAMP(11);
       // blocks fb (odd, into B) and fb + 1 (into A); which_tag = kind of the blocks whose epilogues run beside them
       auto pair = [&](auto which_tag, auto sw1, auto sw2, int fb) __attribute__((always_inline)) {
+        constexpr bool VB = decltype(which_tag)::value == 2;
         chunk_f(sw1, B, ph, pw, [&](int s) __attribute__((always_inline)) { epi(which_tag, A, fb - 1, fb + 1, s); });
-        count();
+        count(VB);
         chunk_f(sw2, A, ph, pw, [&](int s) __attribute__((always_inline)) { epi(which_tag, B, fb, fb + 2, s); });
-        count();
+        count(VB);
       };
       const std::integral_constant<int, 0> kQ{};
       const std::integral_constant<int, 1> kK{};
@@ -658,10 +663,10 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
 #pragma unroll 1
       for (int fb = 17; fb < 22; fb += 2) pair(kV, sw, sw, fb);        // blocks 17..22, epilogues of blocks 16..21 (V)
       chunk_f(sw, B, ph, pw, [&](int s) __attribute__((always_inline)) { epi(kV, A, 22, 23, s); });
-      count();
+      count(true);
 #pragma unroll
       for (int s = 0; s < 32; ++s) epi(kV, B, 23, 23, s);              // last block: nothing to hide behind
-      count();
+      count(true);
       XSTAMP(14);
     }
     tile = s_tile[(it + 1) & 1];   // written before this tile's first barrier: ordered by the barriers since

@@ -134,7 +134,10 @@ class GradientSync:
         if self._expected is None:
             return
         nxt = len(self._handles)
-        while nxt < len(self.buckets) and self._expected[nxt] and self._fired[nxt] >= self._expected[nxt]:
+        # a bucket whose learned set is empty (only never-firing parameters) is complete by definition: it
+        # leaves in order like the others (all zeros), so it cannot hold back the overlapped launch of its
+        # successors -- the set is agreed across ranks, every rank takes the same decision
+        while nxt < len(self.buckets) and self._fired[nxt] >= self._expected[nxt]:
             self._launch(nxt)
             nxt += 1
 
@@ -194,7 +197,10 @@ class GradientSync:
             t = p.grad if p in local_late else torch.zeros_like(want)
             if self.active:
                 self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
-            want.copy_(t)
+            # ADD to the slot: a rank on which p was on time (its bucket had not left when p fired) carried p's
+            # gradient inside the reduced bucket; on the late ranks the slot was zero when the bucket left.  Bucket
+            # sum + late sum is therefore the full sum on every rank (copy_ here dropped the on-time ranks' share).
+            want.add_(t)
             p.grad = want
             bi, _ = self._slot[p]
             if self._expected is not None:

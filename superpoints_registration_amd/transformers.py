@@ -201,6 +201,10 @@ class TransformerCrossEncoder(nn.Module):
         # (csrc/xenc.hip xenc_lds_bytes: 23 232 bytes for 4 d_ff + 8 (segments + 1))
         if 4 * max(l.linear1.out_features for l in self.layers) + 8 * (nseg + 1) > 23232:
             return False
+        # one plan = at most 16 layers (csrc/xenc.hip kMaxLayers) of ONE feed-forward width (the plan is prepared with
+        # the first layer's): anything else takes the operator route instead of failing in xenc_prepare
+        if len(self.layers) > 16 or len({l.linear1.out_features for l in self.layers}) != 1:
+            return False
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False                                  # training: the differentiable per-operator route
         return all(l.normalize_before and l.sa_val_has_pos_emb and l.ca_val_has_pos_emb and l.nhead == 8

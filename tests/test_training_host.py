@@ -325,3 +325,58 @@ def test_gradient_sync_refuses_a_second_backward_into_a_launched_bucket():
         assert raised
     finally:
         dist.destroy_process_group()
+
+
+def _late_on_one_rank_worker(rank, world, port, q):
+    """Drives the hooks by hand so that `unused` is LATE on rank 0 (its bucket has left when it fires) and ON TIME
+    on rank 1 (it fires before any bucket has left)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = Toy()
+    sync = GradientSync(model, None, bucket_bytes=256)
+    params = dict(model.named_parameters())
+    order = ['b.bias', 'b.weight', 'a.bias', 'a.weight']
+
+    def fire(name, value):
+        p = params[name]
+        p.grad = torch.full_like(p, value)            # a fresh tensor outside the buckets, as after zero_grad(None)
+        sync._on_grad(p)
+
+    # step 0: learns the buckets without `unused`
+    for n in order:
+        fire(n, 1.0 + rank)
+    sync.finish()
+    bi = sync._slot[params['unused']][0]
+    assert not sync._expected[bi]                     # `unused` sits alone in the last bucket, learnt as empty
+    # step 1: `unused` joins -- on rank 0 behind everything else (its empty bucket left in order right behind its
+    # predecessors: already on the wire), on rank 1 in front of everything (nothing has left yet)
+    for p in params.values():
+        p.grad = None
+    seq = order + ['unused'] if rank == 0 else ['unused'] + order
+    for n in seq:
+        fire(n, (10.0 if n == 'unused' else 1.0) * (1 + rank))
+    assert (params['unused'] in sync._late) == (rank == 0)
+    sync.finish()
+    q.put((rank, {n: p.grad.detach().numpy().copy() for n, p in params.items() if p.grad is not None}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_parameter_late_on_one_rank_and_on_time_on_the_other_keeps_both_contributions():
+    """the per-parameter reduction of a late parameter must ADD to the bucket-reduced slot -- the
+    on-time rank's share travelled inside the bucket."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_late_on_one_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(2):
+        assert np.allclose(res[rank]['unused'], 0.5 * (10.0 + 20.0)), res[rank]['unused']
+        for n in ('a.weight', 'a.bias', 'b.weight', 'b.bias'):
+            assert np.allclose(res[rank][n], 1.5), n
