@@ -844,7 +844,286 @@ __global__ __launch_bounds__(256, WPS) void k_attn_h3(
   }
 }
 
-static std::atomic<int> g_attn_mode{1};   // 1 = split-fp16 (default), 0 = exact f32 MFMA, 2 = single-pass fp16
+// ---------------------------------------------------------------------------------------------------
+// Round 5 core ("s" = sum-checked).  Same contract, operand planes, LDS images and staging as
+// k_attn_h3<H3, /*LAZY*/ true, /*NQ*/ 1>, with two changes that take vector instructions off the per-score path
+// (the kernel is bound by vector-instruction issue: profiles/r04_attn_counters.txt):
+//  * no row-maximum pass in the steady state.  The lazy reference is set from the true maximum on the first tile;
+//    afterwards a tile is exponentiated optimistically and the row sums the softmax needs anyway are the check: a
+//    lane's 32 probabilities of the tile are all below their sum, so "sum < 2^15" proves that nothing left fp16's
+//    range.  Otherwise (rare: a score more than ~10 octaves above the reference) the tile is recomputed after
+//    recentring on its true maximum -- the loop below runs its body a second time, nothing of the tile has been
+//    accumulated yet.  24 v_max + swap + compare per tile become one add and one compare.
+//  * PLO = false ("single probability plane", attention mode 3): P is carried as ONE fp16 plane (round toward
+//    zero) instead of hi + lo, O^T = (V_hi + V_lo)^T P_hi: 8 instead of 12 MFMAs for the second product and no
+//    v_fma_mix pair per probability.  The row sum is formed from the ROUNDED plane (v_dot2c_f32_f16 with a ones
+//    vector), so numerator and denominator use the same weights: the output is an exact convex combination of the
+//    value rows with weights perturbed by < 2^-10 relative each; the systematic part of the rounding cancels in
+//    1 / l, what is left is sum_j w_j delta_j (v_j - o), delta uniform over one fp16 ulp.
+//    Q K^T keeps the three-product split in every H3 mode: score errors are amplified by the exponential.
+// PRIO > 0: s_setprio PRIO around the score MFMAs (A/B switch SPR_ATTN_PRIO).
+// ABL (diagnostic builds only, -DSPR_ATTN_ABLATE; results are garbage): 1 = no fragment reads from LDS (the Q registers
+// stand in), 2 = no K / V staging (no global loads, no LDS writes), 4 = no per-tile barrier.
+template <bool H3, bool PLO, int WPS, int PRIO, int ABL = 0>
+__global__ __launch_bounds__(256, WPS) void k_attn_s(
+    const _Float16* __restrict__ qh_g, const _Float16* __restrict__ ql_g,
+    const _Float16* __restrict__ kh_g, const _Float16* __restrict__ kl_g,
+    const _Float16* __restrict__ vth_g, const _Float16* __restrict__ vtl_g, int t_total, int tp,
+    const int* __restrict__ cu, const int* __restrict__ kv_seg, int nseg, int nhead,
+    const float* __restrict__ scales, float* __restrict__ out, int o_stride, float* __restrict__ lse_out) {
+  static_assert(H3 || !PLO, "a lo plane of P only with split operands");
+  __shared__ __align__(16) _Float16 Kh[2][KT2 * KH], Kl[2][KT2 * KH];
+  __shared__ __align__(16) _Float16 Vth[2][HD * VH], Vtl[2][HD * VH];
+  int seg, head, qt;
+  {
+    const int nqt = gridDim.x / (nhead * nseg);
+    const int ngrp = nhead * nseg;
+    const int b = blockIdx.x;
+    if ((ngrp & 7) == 0) {      // all query tiles of one (segment, head) on one XCD (ids b and b + 8 share an L2)
+      const int xcd = b & 7, idx = b >> 3;
+      const int g = xcd + 8 * (idx / nqt);
+      qt = idx % nqt;
+      head = g % nhead;
+      seg = g / nhead;
+    } else {
+      qt = b % nqt;
+      head = (b / nqt) % nhead;
+      seg = b / (nqt * nhead);
+    }
+  }
+  const int qbeg = cu[seg], qlen = cu[seg + 1] - qbeg;
+  const int q0 = qt * 128;
+  if (q0 >= qlen) return;
+  const int ks = kv_seg[seg];
+  const int kbeg = cu[ks], klen = cu[ks + 1] - kbeg;
+  const int vbeg = vstart(cu, ks);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int hoff = head * HD;
+
+  h16x8 qh[2], ql[2];
+  {
+    const int qi = min(q0 + wave * 32 + l31, qlen - 1);
+    const size_t row = ((size_t)head * t_total + qbeg + qi) * HD + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      qh[s] = *reinterpret_cast<const h16x8*>(qh_g + row + 16 * s);
+      if constexpr (H3) ql[s] = *reinterpret_cast<const h16x8*>(ql_g + row + 16 * s);
+    }
+  }
+  // The Q fragments are first USED inside the tile loop: without this the compiler's own wait for their loads
+  // lands in the loop (s_waitcnt vmcnt(0) in front of the score MFMAs) and drains the asm-issued prefetch of the
+  // next K / V tile on every iteration.
+  if constexpr (H3) asm volatile("" ::"v"(qh[0]), "v"(qh[1]), "v"(ql[0]), "v"(ql[1]));
+  else asm volatile("" ::"v"(qh[0]), "v"(qh[1]));
+  f32x16 o, negm;      // negm: all registers = off - m_ref, the C operand of the score MFMAs
+  float psum = 0.f;    // per-lane partial row sum (the two half-waves are joined at the end)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    o[r] = 0.f;
+    negm[r] = 0.f;
+  }
+
+  const int skr = tid >> 2, skc = (tid & 3) * 8;
+  const int svr = tid >> 3, svc = (tid & 7) * 8;
+  u32x4 rkh, rkl, rvh, rvl;
+  auto fetch = [&](int kt) {
+    if constexpr (ABL & 2) return;
+    const size_t krow = ((size_t)head * t_total + kbeg + min(kt + skr, klen - 1)) * HD + skc;
+    const size_t vrow = (size_t)(hoff + svr) * tp + vbeg + kt + svc;
+    const _Float16 *a = kh_g + krow, *b = kl_g + krow, *c = vth_g + vrow, *d = vtl_g + vrow;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rkh) : "v"(a));
+    if constexpr (H3) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rkl) : "v"(b));
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rvh) : "v"(c));
+    if constexpr (H3) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rvl) : "v"(d));
+  };
+  auto stash = [&](int buf) {
+    if constexpr (ABL & 2) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    *reinterpret_cast<u32x4*>(Kh[buf] + skr * KH + skc) = rkh;
+    if constexpr (H3) *reinterpret_cast<u32x4*>(Kl[buf] + skr * KH + skc) = rkl;
+    // V^T: the keys of every 16-key group in the order [0-3, 8-11, 4-7, 12-15], so that the eight keys a lane
+    // contracts in one k-step (16 s + 8 (j >> 2) + 4 lh + (j & 3)) are 16 contiguous bytes: ONE ds_read_b128 per
+    // fragment (256 B/clk) where the straight image needs a ds_read2_b64 (128 B/clk: MI355X_MICROARCH.md, LDS).
+    // The 16-byte chunk of a staging lane (keys 8 c .. 8 c + 7) lands as two 8-byte pieces.
+    {
+      const int vpos = svr * VH + 16 * ((tid & 7) >> 1) + ((tid & 1) ? 4 : 0);
+      *reinterpret_cast<u32x2*>(Vth[buf] + vpos) = (u32x2){rvh[0], rvh[1]};
+      *reinterpret_cast<u32x2*>(Vth[buf] + vpos + 8) = (u32x2){rvh[2], rvh[3]};
+      if constexpr (H3) {
+        *reinterpret_cast<u32x2*>(Vtl[buf] + vpos) = (u32x2){rvl[0], rvl[1]};
+        *reinterpret_cast<u32x2*>(Vtl[buf] + vpos + 8) = (u32x2){rvl[2], rvl[3]};
+      }
+    }
+  };
+
+  constexpr float kOff = 4.0f;        // a fresh reference puts the row maximum at 2^kOff
+  constexpr float kSumMax = 32768.f;  // a lane's tile sum below this: every probability inside fp16's range
+
+  auto tile = [&](int kt, int buf, auto tail_tag) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    f32x16 sc[2];
+    unsigned int ph_u[2][8], pl_u[2][8];
+    float ts = 0.f;
+    bool redo = false;
+    for (;;) {
+      // ---- S^T = K Q^T + (off - m_ref)   (rows = keys, cols = queries) ----
+      if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        h16x8 kfh[2], kfl[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if constexpr (ABL & 1) {
+            kfh[s] = qh[s];
+            if constexpr (H3) kfl[s] = ql[s];
+            continue;
+          }
+          kfh[s] = *reinterpret_cast<const h16x8*>(Kh[buf] + (32 * kk + l31) * KH + 16 * s + 8 * lh);
+          if constexpr (H3) kfl[s] = *reinterpret_cast<const h16x8*>(Kl[buf] + (32 * kk + l31) * KH + 16 * s + 8 * lh);
+        }
+        sc[kk] = negm;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if constexpr (H3) {
+            sc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], ql[s], sc[kk], 0, 0, 0);
+            sc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[s], qh[s], sc[kk], 0, 0, 0);
+          }
+          sc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], qh[s], sc[kk], 0, 0, 0);
+        }
+        if (kk == 0) __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(0);
+      if (TAIL) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int j = kt + 32 * kk + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (j >= klen) sc[kk][r] = -INFINITY;
+          }
+      }
+      const bool first = kt == 0;
+      if (first || redo) {
+        // recentre on the tile's true maximum (first tile: o and psum are still zero)
+        float mx = fmaxf(sc[0][0], sc[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(sc[0][r], sc[1][r]));
+        mx = half_swap_max(mx);
+        const float delta = first ? mx - kOff : fmaxf(mx - kOff, 0.f);
+        const float corr = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+        psum *= corr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          o[r] *= corr;
+          negm[r] -= delta;
+          sc[0][r] -= delta;
+          sc[1][r] -= delta;
+        }
+      }
+      // ---- probabilities, their planes and the lane's tile sum ----
+      float ta = 0.f, tb = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(sc[kk][r]);
+          const float p1 = __builtin_amdgcn_exp2f(sc[kk][r + 1]);
+          const auto hi_h = __builtin_amdgcn_cvt_pkrtz(p0, p1);
+          const unsigned int hi_u = __builtin_bit_cast(unsigned int, hi_h);
+          ph_u[kk][r >> 1] = hi_u;
+          if constexpr (PLO) {
+            ta += p0;      // two plain adds (-fno-slp-vectorize): v_pk_add_f32 issues slower than the pair
+            tb += p1;
+            unsigned int lo_u;
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+                "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                : "=&v"(lo_u)
+                : "v"(hi_u), "v"(p0), "v"(p1));
+            pl_u[kk][r >> 1] = lo_u;
+          } else {
+            // the sum of the ROUNDED pair: acc += float(half) exactly, one v_fma_mix_f32 per half (a v_dot2c_f32_f16
+            // per pair costs 2.7 ns beside an MFMA, these 0.4 each: scripts/abl/issue_probe.hip, round 5)
+            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(ta) : "v"(hi_u));
+            asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(tb) : "v"(hi_u));
+          }
+        }
+      ts = ta + tb;
+      if (redo || __builtin_amdgcn_ballot_w64(!(ts < kSumMax)) == 0) break;
+      redo = true;   // some probability may have left fp16's range: once more, recentred (rare)
+    }
+    psum += ts;
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if (kk == 1) __builtin_amdgcn_sched_barrier(0);
+      h16x8 vfh[2], vfl[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if constexpr (ABL & 1) {
+          vfh[s] = qh[s];
+          if constexpr (H3) vfl[s] = ql[s];
+          continue;
+        }
+        vfh[s] = *reinterpret_cast<const h16x8*>(Vth[buf] + l31 * VH + 32 * kk + 16 * s + 8 * lh);
+        if constexpr (H3) vfl[s] = *reinterpret_cast<const h16x8*>(Vtl[buf] + l31 * VH + 32 * kk + 16 * s + 8 * lh);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const u32x4 pa = {ph_u[kk][4 * s], ph_u[kk][4 * s + 1], ph_u[kk][4 * s + 2], ph_u[kk][4 * s + 3]};
+        const h16x8 pbh = __builtin_bit_cast(h16x8, pa);
+        if constexpr (PLO) {
+          const u32x4 pb = {pl_u[kk][4 * s], pl_u[kk][4 * s + 1], pl_u[kk][4 * s + 2], pl_u[kk][4 * s + 3]};
+          const h16x8 pbl = __builtin_bit_cast(h16x8, pb);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbl, o, 0, 0, 0);
+        }
+        if constexpr (H3) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[s], pbh, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbh, o, 0, 0, 0);
+      }
+    }
+  };
+
+  if (klen > 0) {
+    fetch(0);
+    stash(0);
+  }
+  __syncthreads();
+  int buf = 0, kt = 0;
+  for (; kt + KT2 <= klen; kt += KT2, buf ^= 1) {
+    const bool more = kt + KT2 < klen;
+    if (more) fetch(kt + KT2);
+    __builtin_amdgcn_sched_barrier(0);
+    tile(kt, buf, std::false_type{});
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) stash(buf ^ 1);
+    if constexpr (!(ABL & 4)) __syncthreads();
+  }
+  if (kt < klen) tile(kt, buf, std::true_type{});
+
+  float l_run = psum;
+  l_run += __shfl_xor(l_run, 32, 64);
+  const int qi = q0 + wave * 32 + l31;
+  // log2 sum_j 2^(s_ij): handed to the backward (training), as k_attn_h3's lazy form does
+  if (lse_out != nullptr && qi < qlen && lh == 0)
+    lse_out[(size_t)(qbeg + qi) * nhead + head] = __builtin_amdgcn_logf(l_run) - negm[0];
+  if (qi < qlen) {
+    const float inv = (l_run > 0.f ? 1.0f / l_run : 0.f) * scales[3];   // 2^-ev undoes the V multiplier
+    float* op = out + (size_t)(qbeg + qi) * o_stride + hoff;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 w4;
+      w4.x = o[4 * g + 0] * inv;
+      w4.y = o[4 * g + 1] * inv;
+      w4.z = o[4 * g + 2] * inv;
+      w4.w = o[4 * g + 3] * inv;
+      *reinterpret_cast<float4*>(op + 8 * g + 4 * lh) = w4;
+    }
+  }
+}
+
+static std::atomic<int> g_attn_mode{1};   // 1 = split-fp16 (default), 0 = exact f32 MFMA, 2 = single-pass fp16,
+                                          // 3 = split-fp16 scores, ONE probability plane (k_attn_s<true, false>)
 
 // L1 norm of every row of w [rows, cols]: one wave per row.
 __global__ void k_row_l1(const float* __restrict__ w, int rows, int cols, float* __restrict__ out) {
@@ -977,6 +1256,48 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
   // two-wave form.  (Four waves per SIMD -- 118 VGPRs in mode 2, 128 with 42 spilled registers in split mode --
   // measured 452 and 1 171 us: occupancy is not what this kernel waits for)
   const int nq = env_attn_nq();
+  // Round 5 default: the sum-checked core k_attn_s (no row-maximum pass; mode 3 = one probability plane).
+  // SPR_ATTN_CORE=h3 selects the round-4 kernel for A/B (modes 1 and 2 only); s_setprio 2 around the score MFMAs
+  // (-1.5 % in every mode) unless SPR_ATTN_PRIO=0.
+  static const bool core_h3 = [] { const char* e = getenv("SPR_ATTN_CORE"); return e != nullptr && e[0] == 'h'; }();
+  static const int prio = [] { const char* e = getenv("SPR_ATTN_PRIO"); return e != nullptr ? atoi(e) : 2; }();
+  if (mode == 3 || (nq == 1 && !core_h3)) {
+    dim3 grid1(cdiv(max_len_host, QB2 / 2) * nhead * nseg);
+#define SPR_ATTN_S(H3_, PLO_, PR_)                                                                                   \
+    hipLaunchKernelGGL((k_attn_s<H3_, PLO_, 3, PR_>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth, \
+                       pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out)
+#ifdef SPR_ATTN_ABLATE
+    static const int abl = [] { const char* e = getenv("SPR_ATTN_ABL"); return e != nullptr ? atoi(e) : 0; }();
+#define SPR_ATTN_SA(A_)                                                                                               \
+    hipLaunchKernelGGL((k_attn_s<true, true, 3, 2, A_>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth, \
+                       pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out)
+    if (abl != 0 && mode == 1) {
+      switch (abl) {
+        case 1: SPR_ATTN_SA(1); break;
+        case 2: SPR_ATTN_SA(2); break;
+        case 3: SPR_ATTN_SA(3); break;
+        case 4: SPR_ATTN_SA(4); break;
+        case 6: SPR_ATTN_SA(6); break;
+        default: SPR_ATTN_SA(7); break;
+      }
+      SPR_LAUNCH_CHECK();
+      return 0;
+    }
+#undef SPR_ATTN_SA
+#endif
+    if (prio > 0) {
+      if (mode == 2) SPR_ATTN_S(false, false, 2);
+      else if (mode == 3) SPR_ATTN_S(true, false, 2);
+      else SPR_ATTN_S(true, true, 2);
+    } else {
+      if (mode == 2) SPR_ATTN_S(false, false, 0);
+      else if (mode == 3) SPR_ATTN_S(true, false, 0);
+      else SPR_ATTN_S(true, true, 0);
+    }
+#undef SPR_ATTN_S
+    SPR_LAUNCH_CHECK();
+    return 0;
+  }
   if (nq == 1) {
     dim3 grid1(cdiv(max_len_host, QB2 / 2) * nhead * nseg);
     // experiment switch (profiles/r04_attn_counters.txt): the same kernel compiled for FOUR waves per SIMD
@@ -1257,15 +1578,16 @@ int spr::attn_zero_gaps(const AttnPlanes& pl, int d, hipStream_t stream) {
 }
 int spr::attn_core_on_planes(const AttnPlanes& pl, const int* kv_seg, int max_len_host, int nhead, float* out,
                              int o_stride, int mode, hipStream_t stream) {
-  SPR_REQUIRE(mode == 1 || mode == 2, "attention core on planes: mode must be 1 or 2 (got %d)", mode);
+  SPR_REQUIRE(mode >= 1 && mode <= 3, "attention core on planes: mode must be 1, 2 or 3 (got %d)", mode);
   SPR_REQUIRE((long)cdiv(max_len_host, QB2 / 2) * nhead * pl.nseg < (1l << 31), "attention: grid too large");
   return launch_core(pl, pl.t_total, (size_t)pl.tp, pl.cu, kv_seg, pl.nseg, max_len_host, nhead, out, o_stride, mode,
                      stream);
 }
 
 extern "C" int spr_set_attn_mode(int mode) {
-  SPR_REQUIRE(mode >= 0 && mode <= 2,
-              "attention mode must be 0 (exact f32 MFMA), 1 (split-fp16) or 2 (single-pass fp16)");
+  SPR_REQUIRE(mode >= 0 && mode <= 3,
+              "attention mode must be 0 (exact f32 MFMA), 1 (split-fp16), 2 (single-pass fp16) or 3 (split-fp16 "
+              "scores, one probability plane)");
   spr::g_attn_mode.store(mode);
   return 0;
 }

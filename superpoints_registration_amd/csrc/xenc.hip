@@ -1071,7 +1071,7 @@ extern "C" int spr_xenc_forward(const void* plan_host, const float* x, const flo
   SPR_REQUIRE((size_t)t * XD * 4 < (1ull << 32), "xenc_forward: too many tokens");
   SPR_REQUIRE(ws != nullptr && ws_bytes >= spr_xenc_workspace_bytes(t, nseg), "xenc_forward: workspace too small");
   const int mode = attn_mode();
-  SPR_REQUIRE(gemm_mode() == 1 && (mode == 1 || mode == 2),
+  SPR_REQUIRE(gemm_mode() == 1 && (mode >= 1 && mode <= 3),
               "xenc_forward: needs the split-fp16 arithmetic (gemm mode 1, attention mode 1 or 2)");
   const size_t planes_bytes = spr_attn_workspace_bytes(t, nseg, 8, 32);
   AttnPlanes pl{};
