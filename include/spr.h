@@ -403,7 +403,15 @@ int spr_attn_varlen_bwd_lse(const float* q, int q_stride, const float* k, int k_
  *   0 = exact f32 MFMA;
  *   2 = single-pass fp16 MFMA (hi planes only: 11-bit operands, fp32 softmax and
  *     accumulators; 1/3 of the matrix-core work -- the throughput mode BASELINE
- *     configs[4] names; ~1e-3 relative on the attention output). */
+ *     configs[4] names; ~1e-3 relative on the attention output);
+ *   3 = split-fp16 scores, the probabilities as ONE fp16 plane (rounded toward
+ *     zero) whose rounded values also form the row sum: exact convex combination
+ *     of the value rows with weights perturbed by < 2^-10 each (5e-6 of the
+ *     output scale on flat rows of ~2 000 keys, up to ~3e-4 on rows carried by a
+ *     few keys); 20 instead of 24 MFMAs per 64-key tile;
+ *   4 = as 1, the lo plane of the probabilities only on the key tiles that hold
+ *     a weight of at least 2^-7 of the running row sum (dominant keys exact, the
+ *     rest as mode 3: <= 3e-5 of the output scale on every tested distribution). */
 int spr_set_attn_mode(int mode);
 
 /* ---- a11: dual-softmax matching ---------------------------------------------

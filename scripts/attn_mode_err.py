@@ -22,12 +22,12 @@ for sharpen in (1.0, 3.0, 8.0):
     model = model.to(dev).eval()
     outs = {}
     with torch.no_grad():
-        for gm, am in ((0, 0), (1, 1), (1, 3), (1, 2)):
+        for gm, am in ((0, 0), (1, 1), (1, 4), (1, 3), (1, 2)):
             ops.set_gemm_mode(gm); ops.set_attn_mode(am)
             outs[(gm, am)] = model(batch())
     ops.set_gemm_mode(1); ops.set_attn_mode(1)
     ex = outs[(0, 0)]
-    for key in ((1, 1), (1, 3), (1, 2)):
+    for key in ((1, 1), (1, 4), (1, 3), (1, 2)):
         o = outs[key]
         fe = max(float((o["src_feat"][b][0] - ex["src_feat"][b][0]).abs().max()) / float(ex["src_feat"][b][0].abs().max())
                  for b in range(2))

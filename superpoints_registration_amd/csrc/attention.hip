@@ -255,8 +255,8 @@ __global__ __launch_bounds__(256) void k_attn_zero_gaps(const int* __restrict__ 
     const int beg = vstart(cu, s) + cu[s + 1] - cu[s];
     const int end = s + 1 < nseg ? vstart(cu, s + 1) : tp;
     for (int c = beg + threadIdx.x; c < end; c += 256) {
-      vth[row + c] = (_Float16)0.f;
-      vtl[row + c] = (_Float16)0.f;
+      vth[row + attn_vperm(c)] = (_Float16)0.f;     // (a bijection inside every aligned 16-column group)
+      vtl[row + attn_vperm(c)] = (_Float16)0.f;
     }
   }
 }
@@ -325,14 +325,17 @@ __global__ __launch_bounds__(256) void k_attn_pack(
     }
     __syncthreads();
     const int ch = (tid & 7) * 8, d0 = tid >> 3;   // 16-byte chunk, 32 feature rows per pass
+    // plane order inside a 16-column group: [0-3, 8-11, 4-7, 12-15] (attn_vperm): the chunk at plane columns ch .. ch + 7
+    // holds the tile columns c0 .. c0 + 3 and c0 + 8 .. c0 + 11, c0 = 16 (ch / 16) + 4 * ((ch / 8) & 1)
+    const int c0 = (ch & ~15) + ((ch & 8) >> 1);
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int d = it * 32 + d0;
       if (half + d < d_model) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(Lh + d * PS + ch);
-        const u32x4 b = *reinterpret_cast<const u32x4*>(Ll + d * PS + ch);
-        *reinterpret_cast<u32x4*>(vth + (size_t)(half + d) * tp + col0 + ch) = a;
-        *reinterpret_cast<u32x4*>(vtl + (size_t)(half + d) * tp + col0 + ch) = b;
+        const u32x2 a0 = *reinterpret_cast<const u32x2*>(Lh + d * PS + c0), a1 = *reinterpret_cast<const u32x2*>(Lh + d * PS + c0 + 8);
+        const u32x2 b0 = *reinterpret_cast<const u32x2*>(Ll + d * PS + c0), b1 = *reinterpret_cast<const u32x2*>(Ll + d * PS + c0 + 8);
+        *reinterpret_cast<u32x4*>(vth + (size_t)(half + d) * tp + col0 + ch) = (u32x4){a0[0], a0[1], a1[0], a1[1]};
+        *reinterpret_cast<u32x4*>(vtl + (size_t)(half + d) * tp + col0 + ch) = (u32x4){b0[0], b0[1], b1[0], b1[1]};
       }
     }
   }
@@ -500,16 +503,9 @@ __global__ __launch_bounds__(256, WPS) void k_attn_h3(
     auto load_vf = [&](int kk) __attribute__((always_inline)) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const _Float16* ph_ = Vth[buf] + l31 * VH + 32 * kk + 16 * s + 4 * lh;
-        const _Float16* pl_ = Vtl[buf] + l31 * VH + 32 * kk + 16 * s + 4 * lh;
-        const h16x4 a0 = *reinterpret_cast<const h16x4*>(ph_);
-        const h16x4 a1 = *reinterpret_cast<const h16x4*>(ph_ + 8);
-        vfh[kk][s] = (h16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        if constexpr (H3) {
-          const h16x4 b0 = *reinterpret_cast<const h16x4*>(pl_);
-          const h16x4 b1 = *reinterpret_cast<const h16x4*>(pl_ + 8);
-          vfl[kk][s] = (h16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-        }
+        // (round 5: the planes hold every 16-key group in fragment order, attn_vperm: one 16-byte read)
+        vfh[kk][s] = *reinterpret_cast<const h16x8*>(Vth[buf] + l31 * VH + 32 * kk + 16 * s + 8 * lh);
+        if constexpr (H3) vfl[kk][s] = *reinterpret_cast<const h16x8*>(Vtl[buf] + l31 * VH + 32 * kk + 16 * s + 8 * lh);
       }
     };
     if constexpr (NQ == 2) {
@@ -675,16 +671,8 @@ __global__ __launch_bounds__(256, WPS) void k_attn_h3(
     auto load_vf = [&](int kk) __attribute__((always_inline)) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const _Float16* ph_ = Vth[buf] + l31 * VH + 32 * kk + 16 * s + 4 * lh;
-        const _Float16* pl_ = Vtl[buf] + l31 * VH + 32 * kk + 16 * s + 4 * lh;
-        const h16x4 a0 = *reinterpret_cast<const h16x4*>(ph_);
-        const h16x4 a1 = *reinterpret_cast<const h16x4*>(ph_ + 8);
-        vfh[s] = (h16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        if constexpr (H3) {
-          const h16x4 b0 = *reinterpret_cast<const h16x4*>(pl_);
-          const h16x4 b1 = *reinterpret_cast<const h16x4*>(pl_ + 8);
-          vfl[s] = (h16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-        }
+        vfh[s] = *reinterpret_cast<const h16x8*>(Vth[buf] + l31 * VH + 32 * kk + 16 * s + 8 * lh);
+        if constexpr (H3) vfl[s] = *reinterpret_cast<const h16x8*>(Vtl[buf] + l31 * VH + 32 * kk + 16 * s + 8 * lh);
       }
     };
     auto scores = [&](f32x16& acc) __attribute__((always_inline)) {
@@ -864,7 +852,15 @@ __global__ __launch_bounds__(256, WPS) void k_attn_h3(
 // PRIO > 0: s_setprio PRIO around the score MFMAs (A/B switch SPR_ATTN_PRIO).
 // ABL (diagnostic builds only, -DSPR_ATTN_ABLATE; results are garbage): 1 = no fragment reads from LDS (the Q registers
 // stand in), 2 = no K / V staging (no global loads, no LDS writes), 4 = no per-tile barrier.
-template <bool H3, bool PLO, int WPS, int PRIO, int ABL = 0>
+// ADAPT (attention mode 4, needs H3 && PLO): the lo plane of the probabilities only where it matters.  A tile is
+// "significant" for a wave when some lane holds a probability of at least 2^-7 of that lane's running row sum (the
+// maximum of the tile's hi plane: 15 v_pk_max_f16); only such tiles pay for the lo plane (32 quarter-rate
+// v_fma_mix*_f16), the f32 sums and the third MFMA of every k-step.  The other tiles run as mode 3 (row sum from the
+// rounded plane).  Every key with weight w_j >= 2^-7 is then carried with full accuracy; what the rest can contribute is
+// bounded by 2^-10 sqrt(sum w_j^2) <= 2^-10 sqrt(2^-7) = 8.6e-5 of the value spread in the worst case (128 keys
+// of exactly that weight) and is ~5e-6 for flat rows of 2 000 keys -- the peaked rows mode 3 is inaccurate on
+// (few keys with large weights) are exact here.
+template <bool H3, bool PLO, int WPS, int PRIO, int ABL = 0, bool ADAPT = false>
 __global__ __launch_bounds__(256, WPS) void k_attn_s(
     const _Float16* __restrict__ qh_g, const _Float16* __restrict__ ql_g,
     const _Float16* __restrict__ kh_g, const _Float16* __restrict__ kl_g,
@@ -872,8 +868,15 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
     const int* __restrict__ cu, const int* __restrict__ kv_seg, int nseg, int nhead,
     const float* __restrict__ scales, float* __restrict__ out, int o_stride, float* __restrict__ lse_out) {
   static_assert(H3 || !PLO, "a lo plane of P only with split operands");
-  __shared__ __align__(16) _Float16 Kh[2][KT2 * KH], Kl[2][KT2 * KH];
-  __shared__ __align__(16) _Float16 Vth[2][HD * VH], Vtl[2][HD * VH];
+  static_assert(!ADAPT || (H3 && PLO), "the adaptive form is a refinement of the split form");
+  // K tiles arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write): the image is lane-linear,
+  // 64 key rows of 64 bytes; the 16-byte chunk c of row r sits at position c ^ ((r >> 2) & 3) (the DMA lane fetches the
+  // SOURCE chunk of its position: linear destination + swizzled source + the same XOR on the read), which makes the
+  // fragment reads (16 lanes = 16 rows, one chunk) conflict-free without row padding.
+  // V^T tiles the same way: 32 feature rows of 128 bytes (64 keys in the planes' fragment order, attn_vperm); chunk c of
+  // row d at position c ^ ((d >> 1) & 7).
+  __shared__ __align__(16) _Float16 Kh[2][KT2 * HD], Kl[2][KT2 * HD];
+  __shared__ __align__(16) _Float16 Vth[2][HD * KT2], Vtl[2][HD * KT2];
   int seg, head, qt;
   {
     const int nqt = gridDim.x / (nhead * nseg);
@@ -924,42 +927,34 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
     negm[r] = 0.f;
   }
 
-  const int skr = tid >> 2, skc = (tid & 3) * 8;
-  const int svr = tid >> 3, svc = (tid & 7) * 8;
-  u32x4 rkh, rkl, rvh, rvl;
-  auto fetch = [&](int kt) {
-    if constexpr (ABL & 2) return;
-    const size_t krow = ((size_t)head * t_total + kbeg + min(kt + skr, klen - 1)) * HD + skc;
-    const size_t vrow = (size_t)(hoff + svr) * tp + vbeg + kt + svc;
-    const _Float16 *a = kh_g + krow, *b = kl_g + krow, *c = vth_g + vrow, *d = vtl_g + vrow;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rkh) : "v"(a));
-    if constexpr (H3) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rkl) : "v"(b));
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rvh) : "v"(c));
-    if constexpr (H3) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rvl) : "v"(d));
+  const int skr = tid >> 2, skc = ((tid & 3) ^ ((tid >> 4) & 3)) * 8;   // K: row, SOURCE chunk of this lane's position
+  const int svr = tid >> 3, svc = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;   // V^T: row, SOURCE chunk of this lane's position
+  const unsigned kdst_h = (unsigned)(uintptr_t)(&Kh[0][0]) + (unsigned)wave * 1024u;   // + buf * 4096
+  const unsigned kdst_l = (unsigned)(uintptr_t)(&Kl[0][0]) + (unsigned)wave * 1024u;
+  const unsigned vdst_h = (unsigned)(uintptr_t)(&Vth[0][0]) + (unsigned)wave * 1024u;
+  const unsigned vdst_l = (unsigned)(uintptr_t)(&Vtl[0][0]) + (unsigned)wave * 1024u;
+  auto dma16 = [&](const void* base, unsigned off, unsigned dst) __attribute__((always_inline)) {
+    const unsigned d = __builtin_amdgcn_readfirstlane(dst);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(d)
+                 : "memory", "m0");
   };
-  auto stash = [&](int buf) {
+  auto fetch = [&](int kt, int nbuf) {     // nbuf: the buffer tile kt will be read from
     if constexpr (ABL & 2) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    *reinterpret_cast<u32x4*>(Kh[buf] + skr * KH + skc) = rkh;
-    if constexpr (H3) *reinterpret_cast<u32x4*>(Kl[buf] + skr * KH + skc) = rkl;
-    // V^T: the keys of every 16-key group in the order [0-3, 8-11, 4-7, 12-15], so that the eight keys a lane
-    // contracts in one k-step (16 s + 8 (j >> 2) + 4 lh + (j & 3)) are 16 contiguous bytes: ONE ds_read_b128 per
-    // fragment (256 B/clk) where the straight image needs a ds_read2_b64 (128 B/clk: MI355X_MICROARCH.md, LDS).
-    // The 16-byte chunk of a staging lane (keys 8 c .. 8 c + 7) lands as two 8-byte pieces.
-    {
-      const int vpos = svr * VH + 16 * ((tid & 7) >> 1) + ((tid & 1) ? 4 : 0);
-      *reinterpret_cast<u32x2*>(Vth[buf] + vpos) = (u32x2){rvh[0], rvh[1]};
-      *reinterpret_cast<u32x2*>(Vth[buf] + vpos + 8) = (u32x2){rvh[2], rvh[3]};
-      if constexpr (H3) {
-        *reinterpret_cast<u32x2*>(Vtl[buf] + vpos) = (u32x2){rvl[0], rvl[1]};
-        *reinterpret_cast<u32x2*>(Vtl[buf] + vpos + 8) = (u32x2){rvl[2], rvl[3]};
-      }
-    }
+    const unsigned koff = (unsigned)((((size_t)head * t_total + kbeg + min(kt + skr, klen - 1)) * HD + skc) * 2);
+    const unsigned voff = (unsigned)(((size_t)(hoff + svr) * tp + vbeg + kt + svc) * 2);
+    dma16(kh_g, koff, kdst_h + (unsigned)nbuf * 4096u);
+    if constexpr (H3) dma16(kl_g, koff, kdst_l + (unsigned)nbuf * 4096u);
+    dma16(vth_g, voff, vdst_h + (unsigned)nbuf * 4096u);
+    if constexpr (H3) dma16(vtl_g, voff, vdst_l + (unsigned)nbuf * 4096u);
+  };
+  auto stash = [&](int) {
+    if constexpr (ABL & 2) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next tile have landed
   };
 
   constexpr float kOff = 4.0f;        // a fresh reference puts the row maximum at 2^kOff
   constexpr float kSumMax = 32768.f;  // a lane's tile sum below this: every probability inside fp16's range
+  constexpr float kSig = 1.0f / 128;  // ADAPT: a probability below kSig x the lane's running sum needs no lo plane
 
   auto tile = [&](int kt, int buf, auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
@@ -967,6 +962,7 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
     unsigned int ph_u[2][8], pl_u[2][8];
     float ts = 0.f;
     bool redo = false;
+    bool sig = PLO;      // does this tile carry a lo plane (ADAPT: decided per tile)
     for (;;) {
       // ---- S^T = K Q^T + (off - m_ref)   (rows = keys, cols = queries) ----
       if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
@@ -980,8 +976,9 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
             if constexpr (H3) kfl[s] = ql[s];
             continue;
           }
-          kfh[s] = *reinterpret_cast<const h16x8*>(Kh[buf] + (32 * kk + l31) * KH + 16 * s + 8 * lh);
-          if constexpr (H3) kfl[s] = *reinterpret_cast<const h16x8*>(Kl[buf] + (32 * kk + l31) * KH + 16 * s + 8 * lh);
+          const int kpos = (32 * kk + l31) * HD + 8 * ((2 * s + lh) ^ ((l31 >> 2) & 3));
+          kfh[s] = *reinterpret_cast<const h16x8*>(Kh[buf] + kpos);
+          if constexpr (H3) kfl[s] = *reinterpret_cast<const h16x8*>(Kl[buf] + kpos);
         }
         sc[kk] = negm;
 #pragma unroll
@@ -1024,6 +1021,47 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
       }
       // ---- probabilities, their planes and the lane's tile sum ----
       float ta = 0.f, tb = 0.f;
+      if constexpr (ADAPT) {
+        typedef _Float16 h16x2_ __attribute__((ext_vector_type(2)));
+        h16x2_ m2 = {(_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(sc[kk][r]);
+            const float p1 = __builtin_amdgcn_exp2f(sc[kk][r + 1]);
+            sc[kk][r] = p0;
+            sc[kk][r + 1] = p1;
+            const auto hi_h = __builtin_amdgcn_cvt_pkrtz(p0, p1);
+            ph_u[kk][r >> 1] = __builtin_bit_cast(unsigned int, hi_h);
+            m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(h16x2_, hi_h));
+          }
+        const float mxp = (float)(m2[0] > m2[1] ? m2[0] : m2[1]);
+        sig = __builtin_amdgcn_ballot_w64(!(mxp < kSig * psum)) != 0;     // (first tile: psum = 0 -> significant)
+        if (sig) {
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              ta += sc[kk][r];
+              tb += sc[kk][r + 1];
+              unsigned int lo_u;
+              asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+                  "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                  : "=&v"(lo_u)
+                  : "v"(ph_u[kk][r >> 1]), "v"(sc[kk][r]), "v"(sc[kk][r + 1]));
+              pl_u[kk][r >> 1] = lo_u;
+            }
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(ta) : "v"(ph_u[kk][i]));
+              asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(tb) : "v"(ph_u[kk][i]));
+            }
+        }
+      } else {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -1049,50 +1087,62 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
             asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(tb) : "v"(hi_u));
           }
         }
+      }
       ts = ta + tb;
       if (redo || __builtin_amdgcn_ballot_w64(!(ts < kSumMax)) == 0) break;
       redo = true;   // some probability may have left fp16's range: once more, recentred (rare)
     }
     psum += ts;
     // ---- O^T += V^T P^T ----
+    auto pv = [&](auto lo_tag) __attribute__((always_inline)) {
+      constexpr bool LO = decltype(lo_tag)::value;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      if (kk == 1) __builtin_amdgcn_sched_barrier(0);
-      h16x8 vfh[2], vfl[2];
+      for (int kk = 0; kk < 2; ++kk) {
+        if (kk == 1) __builtin_amdgcn_sched_barrier(0);
+        h16x8 vfh[2], vfl[2];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if constexpr (ABL & 1) {
-          vfh[s] = qh[s];
-          if constexpr (H3) vfl[s] = ql[s];
-          continue;
+        for (int s = 0; s < 2; ++s) {
+          if constexpr (ABL & 1) {
+            vfh[s] = qh[s];
+            if constexpr (H3) vfl[s] = ql[s];
+            continue;
+          }
+          const int vpos = l31 * KT2 + 8 * ((4 * kk + 2 * s + lh) ^ ((l31 >> 1) & 7));
+          vfh[s] = *reinterpret_cast<const h16x8*>(Vth[buf] + vpos);
+          if constexpr (H3) vfl[s] = *reinterpret_cast<const h16x8*>(Vtl[buf] + vpos);
         }
-        vfh[s] = *reinterpret_cast<const h16x8*>(Vth[buf] + l31 * VH + 32 * kk + 16 * s + 8 * lh);
-        if constexpr (H3) vfl[s] = *reinterpret_cast<const h16x8*>(Vtl[buf] + l31 * VH + 32 * kk + 16 * s + 8 * lh);
-      }
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const u32x4 pa = {ph_u[kk][4 * s], ph_u[kk][4 * s + 1], ph_u[kk][4 * s + 2], ph_u[kk][4 * s + 3]};
-        const h16x8 pbh = __builtin_bit_cast(h16x8, pa);
-        if constexpr (PLO) {
-          const u32x4 pb = {pl_u[kk][4 * s], pl_u[kk][4 * s + 1], pl_u[kk][4 * s + 2], pl_u[kk][4 * s + 3]};
-          const h16x8 pbl = __builtin_bit_cast(h16x8, pb);
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbl, o, 0, 0, 0);
+        for (int s = 0; s < 2; ++s) {
+          const u32x4 pa = {ph_u[kk][4 * s], ph_u[kk][4 * s + 1], ph_u[kk][4 * s + 2], ph_u[kk][4 * s + 3]};
+          const h16x8 pbh = __builtin_bit_cast(h16x8, pa);
+          if constexpr (LO) {
+            const u32x4 pb = {pl_u[kk][4 * s], pl_u[kk][4 * s + 1], pl_u[kk][4 * s + 2], pl_u[kk][4 * s + 3]};
+            const h16x8 pbl = __builtin_bit_cast(h16x8, pb);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbl, o, 0, 0, 0);
+          }
+          if constexpr (H3) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[s], pbh, o, 0, 0, 0);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbh, o, 0, 0, 0);
         }
-        if constexpr (H3) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[s], pbh, o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbh, o, 0, 0, 0);
       }
+    };
+    if constexpr (ADAPT) {
+      if (sig) pv(std::true_type{});
+      else pv(std::false_type{});
+    } else {
+      pv(std::integral_constant<bool, PLO>{});
     }
   };
 
   if (klen > 0) {
-    fetch(0);
+    fetch(0, 0);
     stash(0);
   }
   __syncthreads();
   int buf = 0, kt = 0;
   for (; kt + KT2 <= klen; kt += KT2, buf ^= 1) {
     const bool more = kt + KT2 < klen;
-    if (more) fetch(kt + KT2);
+    // (the barrier at the end of the previous iteration: every wave has finished reading buffer buf ^ 1)
+    if (more) fetch(kt + KT2, buf ^ 1);
     __builtin_amdgcn_sched_barrier(0);
     tile(kt, buf, std::false_type{});
     __builtin_amdgcn_sched_barrier(0);
@@ -1123,7 +1173,7 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
 }
 
 static std::atomic<int> g_attn_mode{1};   // 1 = split-fp16 (default), 0 = exact f32 MFMA, 2 = single-pass fp16,
-                                          // 3 = split-fp16 scores, ONE probability plane (k_attn_s<true, false>)
+                                          // 3 = split-fp16 scores, ONE probability plane (k_attn_s<true, false>), 4 = adaptive lo plane
 
 // L1 norm of every row of w [rows, cols]: one wave per row.
 __global__ void k_row_l1(const float* __restrict__ w, int rows, int cols, float* __restrict__ out) {
@@ -1202,7 +1252,7 @@ __global__ __launch_bounds__(256) void k_plane_scales(const float* __restrict__ 
 
 using namespace spr;
 
-static size_t attn_tp_(int t, int nseg) { return align_up((size_t)t + 8 * (size_t)nseg + KT2, PT); }
+static size_t attn_tp_(int t, int nseg) { return align_up((size_t)t + 16 * (size_t)nseg + KT2, PT); }
 // small scratch behind the planes: 3 absmax partial arrays, 3*256 row norms, 4 scales
 static constexpr size_t kAttnSmall = 3 * 2048 + 4096 + 256;
 
@@ -1261,7 +1311,7 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
   // (-1.5 % in every mode) unless SPR_ATTN_PRIO=0.
   static const bool core_h3 = [] { const char* e = getenv("SPR_ATTN_CORE"); return e != nullptr && e[0] == 'h'; }();
   static const int prio = [] { const char* e = getenv("SPR_ATTN_PRIO"); return e != nullptr ? atoi(e) : 2; }();
-  if (mode == 3 || (nq == 1 && !core_h3)) {
+  if (mode >= 3 || (nq == 1 && !core_h3)) {
     dim3 grid1(cdiv(max_len_host, QB2 / 2) * nhead * nseg);
 #define SPR_ATTN_S(H3_, PLO_, PR_)                                                                                   \
     hipLaunchKernelGGL((k_attn_s<H3_, PLO_, 3, PR_>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth, \
@@ -1285,7 +1335,10 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
     }
 #undef SPR_ATTN_SA
 #endif
-    if (prio > 0) {
+    if (mode == 4) {
+      hipLaunchKernelGGL((k_attn_s<true, true, 3, 2, 0, true>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
+                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
+    } else if (prio > 0) {
       if (mode == 2) SPR_ATTN_S(false, false, 2);
       else if (mode == 3) SPR_ATTN_S(true, false, 2);
       else SPR_ATTN_S(true, true, 2);
@@ -1578,16 +1631,16 @@ int spr::attn_zero_gaps(const AttnPlanes& pl, int d, hipStream_t stream) {
 }
 int spr::attn_core_on_planes(const AttnPlanes& pl, const int* kv_seg, int max_len_host, int nhead, float* out,
                              int o_stride, int mode, hipStream_t stream) {
-  SPR_REQUIRE(mode >= 1 && mode <= 3, "attention core on planes: mode must be 1, 2 or 3 (got %d)", mode);
+  SPR_REQUIRE(mode >= 1 && mode <= 4, "attention core on planes: mode must be 1 .. 4 (got %d)", mode);
   SPR_REQUIRE((long)cdiv(max_len_host, QB2 / 2) * nhead * pl.nseg < (1l << 31), "attention: grid too large");
   return launch_core(pl, pl.t_total, (size_t)pl.tp, pl.cu, kv_seg, pl.nseg, max_len_host, nhead, out, o_stride, mode,
                      stream);
 }
 
 extern "C" int spr_set_attn_mode(int mode) {
-  SPR_REQUIRE(mode >= 0 && mode <= 3,
-              "attention mode must be 0 (exact f32 MFMA), 1 (split-fp16), 2 (single-pass fp16) or 3 (split-fp16 "
-              "scores, one probability plane)");
+  SPR_REQUIRE(mode >= 0 && mode <= 4,
+              "attention mode must be 0 (exact f32 MFMA), 1 (split-fp16), 2 (single-pass fp16), 3 (split-fp16 "
+              "scores, one probability plane) or 4 (as 1, the lo plane of the probabilities only on significant tiles)");
   spr::g_attn_mode.store(mode);
   return 0;
 }

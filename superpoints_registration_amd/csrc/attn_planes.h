@@ -5,9 +5,15 @@
 
 namespace spr {
 
-// Token columns of segment s in the transposed V planes start at a 16-byte
+// Token columns of segment s in the transposed V planes start at a 32-byte
 // aligned column; gaps and the tail hold zeros.
-__host__ __device__ inline int attn_vstart_of(int cu_s, int s) { return (cu_s + 8 * s) & ~7; }
+__host__ __device__ inline int attn_vstart_of(int cu_s, int s) { return (cu_s + 16 * s) & ~15; }
+// Round 5: inside every aligned group of 16 columns the tokens are stored in the order [0-3, 8-11, 4-7, 12-15].
+// The B fragment of O^T = V^T P^T holds, per k-step, the keys 16 s + 8 (j >> 2) + 4 h + (j & 3) (the 32x32
+// accumulator layout of the scores): with this order they are 16 CONTIGUOUS bytes of a plane row, so the attention
+// core stages V^T tiles by LDS-DMA (16-byte pieces cannot be permuted on the way) and reads a fragment with one
+// ds_read_b128.  attn_vperm(column) = where a token column lives.
+__host__ __device__ inline int attn_vperm(int col) { return (col & ~15) | (col & 3) | ((col & 4) << 1) | ((col & 8) >> 1); }
 
 struct AttnPlanes {
   _Float16 *qh, *ql, *kh, *kl;   // [nhead][T][32] head-major, Q pre-scaled by log2(e)/sqrt(d)

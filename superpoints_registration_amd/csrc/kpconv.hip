@@ -1059,25 +1059,12 @@ __global__ __launch_bounds__(512, (RingShape<CC, COUT, NS>::MINW)) void k_kpconv
       else wait_vm_any(DPI * max(younger, 0));
     };
     KStep R0, R1;
-    // Round 5: the influence of k-step 0 is computed ONE k-step ahead (w0c: beside the previous item's second group
-    // of MFMAs; for a tile's first item here), and the influence of k-step 1 beside the first group.  A wave's
-    // stream is then "4 MFMAs with the next influence's dependent chain (12 VALU + sqrt) in their shadows" instead
-    // of "chain, then 4 back-to-back MFMAs that block the in-order wave for 128 cycles": the two waves of a SIMD
-    // run the same program and fall into lockstep (both in their chains, then both queueing for the matrix pipe;
-    // MI355X_MICROARCH.md "Two waves per SIMD", item 9), which the old order paid in full.  Same float operations
-    // in the same order per element: outputs bitwise unchanged.
-    auto influence = [&](const float4& rec, float qx, float qy, float qz) -> float {
-      const float dx = (rec.x - qx) - kx, dy = (rec.y - qy) - ky, dz = (rec.z - qz) - kz;
-      return fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
-    };
-    float w0c = 0.f;
     if (n_items == 0) {
       wait_vm_any(0);
     } else {
       wait_item(0);
       R0 = ld_kstep(0, 0);
       R1 = ld_kstep(0, 1);
-      w0c = d.z > 0 ? influence(R0.rec, qax, qay, qaz) : influence(R0.rec, qbx, qby, qbz);
     }
     Ids ids_next = load_ids(par, NS);
     int i = 0;
@@ -1119,45 +1106,35 @@ __global__ __launch_bounds__(512, (RingShape<CC, COUT, NS>::MINW)) void k_kpconv
     // One item = two k-steps.  `between` runs after the first k-step's MFMAs have been issued: the
     // place where the previous query's flush goes, so that its conversions and LDS writes execute
     // under the matrix pipe's work instead of behind its drain.
-    // (nqx, nqy, nqz): the query of the NEXT item of the wave's stream (k-step 0 of that item is prepared here)
-    auto item = [&](f32x4 (&acc)[NTC], int& cnt, float qx, float qy, float qz, float nqx, float nqy, float nqz,
-                    auto&& between) {
+    auto item = [&](f32x4 (&acc)[NTC], int& cnt, float qx, float qy, float qz, auto&& between) {
       KP_STAMP(2);
       const unsigned nslot = slot_off + SLOT == NS * SLOT ? 0u : slot_off + SLOT;
-      {   // k-step 0: its influence was computed a k-step ago; k-step 1's chain runs beside these MFMAs
+      {   // k-step 0
+        const float dx = (R0.rec.x - qx) - kx, dy = (R0.rec.y - qy) - ky, dz = (R0.rec.z - qz) - kz;
+        const float w = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
         cnt += __float_as_int(R0.rec.w);
-        const float w1 = influence(R1.rec, qx, qy, qz);
 #ifndef SPR_KP_ABL_NOMFMA1
 #pragma unroll
-        for (int t = 0; t < NTC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0c, R0.xv[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < NTC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, R0.xv[t], acc[t], 0, 0, 0);
 #else
 #pragma unroll
-        for (int t = 0; t < NTC; ++t) acc[t][0] += w0c * R0.xv[t];
+        for (int t = 0; t < NTC; ++t) acc[t][0] += w * R0.xv[t];
 #endif
-        w0c = w1;          // (k-step 1's influence until the reload below)
-        // pin the chain INTO this block (the compiler otherwise sinks it behind the waits below, in front of its
-        // first use) and spread it over the MFMAs' shadows
-        asm volatile("" : "+v"(w0c));
-#pragma unroll
-        for (int t = 0; t < NTC; ++t) {
-          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);    // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);    // four vector instructions
-        }
       }
       wait_item(i + 1);                   // (the last item of the tile: everything has landed)
       R0 = ld_kstep(nslot, 0);
       if (i + NS < n_items) issue_ids(slot_off, ids_next);   // refill the slot item i lived in
       between();
-      {   // k-step 1, with the next item's first influence beside its MFMAs
+      {   // k-step 1
+        const float dx = (R1.rec.x - qx) - kx, dy = (R1.rec.y - qy) - ky, dz = (R1.rec.z - qz) - kz;
+        const float w = fmaxf(0.f, 1.f - __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * inv_extent);
         cnt += __float_as_int(R1.rec.w);
-        const float w1 = w0c;
-        w0c = influence(R0.rec, nqx, nqy, nqz);   // (past the tile's last item: stale slot contents, never used)
 #ifndef SPR_KP_ABL_NOMFMA1
 #pragma unroll
-        for (int t = 0; t < NTC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1, R1.xv[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < NTC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, R1.xv[t], acc[t], 0, 0, 0);
 #else
 #pragma unroll
-        for (int t = 0; t < NTC; ++t) acc[t][0] += w1 * R1.xv[t];
+        for (int t = 0; t < NTC; ++t) acc[t][0] += w * R1.xv[t];
 #endif
       }
       R1 = ld_kstep(nslot, 1);
@@ -1171,13 +1148,12 @@ __global__ __launch_bounds__(512, (RingShape<CC, COUT, NS>::MINW)) void k_kpconv
     for (int t = 0; t < NTC; ++t) accA[t] = accB[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int cntA = 0, cntB = 0;
 #pragma unroll 1
-    for (int b = 0; b + 1 < d.z; ++b) item(accA, cntA, qax, qay, qaz, qax, qay, qaz, nothing);
-    if (d.z > 0) item(accA, cntA, qax, qay, qaz, qbx, qby, qbz, nothing);   // the item behind it belongs to B (if any)
+    for (int b = 0; b < d.z; ++b) item(accA, cntA, qax, qay, qaz, nothing);
     if (d.w > 0) {
       // query B's first item carries query A's flush (query A exists whenever B does)
-      item(accB, cntB, qbx, qby, qbz, qbx, qby, qbz, [&] { flush(accA, cntA, wave, d.x); });
+      item(accB, cntB, qbx, qby, qbz, [&] { flush(accA, cntA, wave, d.x); });
 #pragma unroll 1
-      for (int b = 1; b < d.w; ++b) item(accB, cntB, qbx, qby, qbz, qbx, qby, qbz, nothing);
+      for (int b = 1; b < d.w; ++b) item(accB, cntB, qbx, qby, qbz, nothing);
       flush(accB, cntB, 15 - wave, d.y);
     } else if (d.z > 0) {
       flush(accA, cntA, wave, d.x);

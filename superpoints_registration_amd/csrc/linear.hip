@@ -367,7 +367,7 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
       int vcol = 0;
       if (which == 2) {
         const int sg = find_segment(pl.cu, pl.nseg, tok);
-        vcol = attn_vstart_of(pl.cu[sg], sg) + tok - pl.cu[sg];
+        vcol = attn_vperm(attn_vstart_of(pl.cu[sg], sg) + tok - pl.cu[sg]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {

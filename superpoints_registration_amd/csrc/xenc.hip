@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
   for (int it = 0; tile < ntiles; ++it) {
     if (tid == 0) s_tile[(it + 1) & 1] = atomicAdd(tile_ctr, 1);       // the next tile (read at the end of this one)
     // Tiles never straddle a segment (cloud): tile = (segment, 128-token slice of it).  A wave's 32 tokens then sit in
-    // 32 consecutive, 16-byte aligned columns of the transposed V planes (one segment, vstart is a multiple of 8).
+    // 32 consecutive, 32-byte aligned columns of the transposed V planes (one segment, vstart is a multiple of 16).
     int sg;
     {
       int lo = 0, hi = pl.nseg;                        // largest s with tf[s] <= tile (skips empty segments)
@@ -587,22 +587,10 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
         } else if (s < 12) {
           bias_next(P, fbn, s - 8);
         } else if (s < 16) {
-          if constexpr (WHICH == 2) {
-            // The lane (feature l & 31, half h) holds tokens {0..3, 8..11, 16..19, 24..27} + 4 h as packed pairs;
-            // exchanging pairs with the partner half gives the h = 0 lane tokens 0..7 and 16..23 and the h = 1
-            // lane tokens 8..15 and 24..31: two contiguous 16-byte pieces per plane.
-            const int i0 = (s - 12) < 2 ? (s - 12) : (s - 12) + 2;       // pairs (0,2) (1,3) (4,6) (5,7)
-            {
-              const auto t = __builtin_amdgcn_permlane32_swap(hu[i0], hu[i0 + 2], false, false);
-              hu[i0] = t[0];
-              hu[i0 + 2] = t[1];
-            }
-            {
-              const auto t = __builtin_amdgcn_permlane32_swap(lu[i0], lu[i0 + 2], false, false);
-              lu[i0] = t[0];
-              lu[i0 + 2] = t[1];
-            }
-          }
+          // (round 5: the V planes keep every 16-token group in the order [0-3, 8-11, 4-7, 12-15] -- attn_planes.h,
+          // attn_vperm -- which is exactly what a lane holds: (feature l & 31, half h) has tokens {0..3, 8..11} + 4 h of
+          // the wave's first 16 and {16..19, 24..27} + 4 h of its second 16 as packed pairs.  The four
+          // v_permlane32_swaps per plane that used to gather 8 consecutive tokens are gone.)
         } else if (s >= 18 && s < 22) {            // stores behind the acquire of step 8 (slice 16): counted there
           const unsigned int* src = s < 20 ? hu : lu;
           const int o4 = 4 * (s & 1);
@@ -616,10 +604,11 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
               store16(pb + row, (u32x4){src[o4], src[o4 + 1], src[o4 + 2], src[o4 + 3]});
             }
           } else {
-            // transposed planes [feature][token column]: piece (s & 1) = tokens 16 (s & 1) + 8 h .. + 7 of feature
-            // row head * 32 + (l & 31); written when the group's first token exists (the rest of a partly valid
-            // group are finite values of the clamped last token, inside the gap in front of the next segment)
-            const int t0 = tok_w + 16 * (s & 1) + 8 * h;
+            // transposed planes [feature][token column]: piece (s & 1) = the lane's eight tokens {0..3, 8..11} + 4 h of
+            // the 16-token group (s & 1) = one 16-byte chunk of the permuted row head * 32 + (l & 31); written when the
+            // chunk's first token exists (the rest of a partly valid chunk are finite values of the clamped last token,
+            // inside the gap in front of the next segment)
+            const int t0 = tok_w + 16 * (s & 1) + 4 * h;
             if (t0 < seg_end) {
               _Float16* pb = s < 20 ? pl.vth : pl.vtl;
               const size_t o0 = (size_t)(head * 32 + r) * pl.tp + vcol_w + 16 * (s & 1) + 8 * h;
@@ -1071,7 +1060,7 @@ extern "C" int spr_xenc_forward(const void* plan_host, const float* x, const flo
   SPR_REQUIRE((size_t)t * XD * 4 < (1ull << 32), "xenc_forward: too many tokens");
   SPR_REQUIRE(ws != nullptr && ws_bytes >= spr_xenc_workspace_bytes(t, nseg), "xenc_forward: workspace too small");
   const int mode = attn_mode();
-  SPR_REQUIRE(gemm_mode() == 1 && (mode >= 1 && mode <= 3),
+  SPR_REQUIRE(gemm_mode() == 1 && (mode >= 1 && mode <= 4),
               "xenc_forward: needs the split-fp16 arithmetic (gemm mode 1, attention mode 1 or 2)");
   const size_t planes_bytes = spr_attn_workspace_bytes(t, nseg, 8, 32);
   AttnPlanes pl{};

@@ -850,7 +850,7 @@ def _no_plan():
 
 
 def xenc_available() -> bool:
-    return _XENC_ON and _modes["gemm"] == 1 and _modes["attn"] in (1, 2)
+    return _XENC_ON and _modes["gemm"] == 1 and _modes["attn"] in (1, 2, 3, 4)
 
 
 def xenc_prepare(layer_params, layer_eps, final, nhead: int, d_ff: int, pos_bound: float, cached=None) -> XencPlan:
@@ -903,7 +903,10 @@ def xenc_forward(plan: XencPlan, x, pos, cu, seg_self, seg_cross, max_len: int) 
 
 
 def set_attn_mode(mode: int) -> None:
-    """1 = split-fp16 MFMA (default), 0 = exact f32 MFMA, 2 = single-pass fp16 MFMA."""
+    """1 = split-fp16 MFMA (default), 0 = exact f32 MFMA, 2 = single-pass fp16 MFMA, 3 = split-fp16 scores with ONE
+    probability plane (weights rounded to 11 bits, row sum from the rounded plane), 4 = as 1 with the lo plane of the
+    probabilities only on tiles that hold a weight of at least 2^-7 of the running row sum (csrc/attention.hip,
+    k_attn_s; accuracy table in DESIGN.md section 4)."""
     _lib.check(_lib.lib().spr_set_attn_mode(int(mode)), "spr_set_attn_mode")
     _modes["attn"] = int(mode)
 
