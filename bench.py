@@ -283,12 +283,14 @@ def main():
             tfs = avg_flops / (avg_ms_attn * 1e-3) / 1e12
             roofline_attn = dict(bound="mfma", achieved=round(tfs, 2), peak=MFMA_F16_PEAK_TFS, unit="TFLOP/s",
                                  frac=round(tfs / MFMA_F16_PEAK_TFS, 5), traffic=None,
-                                 kernel={1: "k_attn_h3<true> (varlen attention core, split-fp16: 3 MFMA per product)",
-                                         2: "k_attn_h3<false> (varlen attention core, single-pass fp16 operands)",
+                                 kernel={1: "k_attn_s<true, true> (varlen attention core, split-fp16: 3 MFMA per product)",
+                                         2: "k_attn_s<false, false> (varlen attention core, single-pass fp16 operands)",
+                                         3: "k_attn_s<true, false> (split-fp16 scores, one probability plane)",
+                                         4: "k_attn_s<true, true, ADAPT> (split-fp16, lo plane of P on significant tiles only)",
                                          0: "k_attn (exact f32 MFMA)"}[args.attn_mode],
                                  avg_launch_ms=round(avg_ms_attn, 5), launches=len(attn_ms),
                                  alg_flops_per_launch=int(avg_flops),
-                                 mfma_flops_executed_per_launch=int({1: 3, 2: 1, 0: 1}[args.attn_mode] * avg_flops))
+                                 mfma_flops_executed_per_launch=int({1: 3, 2: 1, 0: 1, 3: 2.5, 4: 2.5}[args.attn_mode] * avg_flops))
         best = None
         for code, a in agg.items():
             if code not in fwd_bytes or a['count'] % fwd_launches[code] != 0:
@@ -365,6 +367,10 @@ def main():
         n_leg = max(1, min(args.steps, 4))
         extra["exact_f32"] = leg(0, 0, n_leg)
         extra["fp16_attention"] = leg(args.gemm_mode, 2, n_leg)
+        # round 5: split-fp16 scores with ONE probability plane (spr_set_attn_mode(3)): 5e-6 of the feature scale away
+        # from the exact-f32 forward on this workload, up to ~2e-4 when the softmax rows are carried by a few keys
+        # (scripts/attn_mode_err.py) -- an opt-in mode, never the headline
+        extra["single_plane_attention"] = leg(args.gemm_mode, 3, n_leg)
         ops.set_gemm_mode(args.gemm_mode)
         ops.set_attn_mode(args.attn_mode)
         if roofline is not None:
@@ -459,6 +465,7 @@ def main():
         "roofline_attention": roofline_attn,
         "exact_f32": extra.get("exact_f32"),
         "fp16_attention": extra.get("fp16_attention"),
+        "single_plane_attention": extra.get("single_plane_attention"),
         "two_streams": extra.get("two_streams"),
         "train_step": extra.get("train_step"),
         "ranks": {"world_size_seen": (dist.get_world_size() if dist is not None else 1),

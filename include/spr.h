@@ -171,6 +171,19 @@ int spr_block_tail(const float* xa, int ka, const float* wa, const float* xb, in
                    const float* xa_range, int xa_range_n, const float* wa_range, int wa_range_n,
                    const float* xb_range, int xb_range_n, const float* wb_range, int wb_range_n,
                    float* out_range, int out_range_n, void* ws, size_t ws_bytes, void* stream);
+/* Round 5: the same with xa = the RAW input of a per-cloud InstanceNorm + LeakyReLU(xa_slope) (the KPConv output of a
+ * bottleneck block, kpconv_blocks.py:717-719 of the reference) whose statistics the caller holds (spr_instnorm_stats:
+ * xa_mean, xa_rstd [nb][ka]); the normalisation runs while a tile is staged -- the normalised tensor is never written.
+ * xa_range (required) bounds the NORMALISED values: sqrt(longest cloud) is always valid. */
+int spr_block_tail_n(const float* xa, int ka, const float* wa, const float* xb, int kb, const float* wb,
+                     const float* add, const int* cu, const int* tiles, int n, int nb, int n_out, float eps,
+                     float slope, float* out, const float* xa_range, int xa_range_n, const float* wa_range,
+                     int wa_range_n, const float* xb_range, int xb_range_n, const float* wb_range,
+                     int wb_range_n, float* out_range, int out_range_n, const float* xa_mean,
+                     const float* xa_rstd, float xa_slope, void* ws, size_t ws_bytes, void* stream);
+/* mean / rstd [nb][c] of spr_instnorm's statistics passes alone (workspace: spr_instnorm_workspace_bytes). */
+int spr_instnorm_stats(const float* x, const int* cu, int n, int nb, int max_len_host, int c, float eps,
+                       float* mean, float* rstd, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a5: strided max pooling ----------------------------------------------
  * Replaces max_pool(x, inds) (kpconv_blocks.py:127-143): max over the pooling

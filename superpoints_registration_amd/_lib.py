@@ -61,6 +61,9 @@ SIGNATURES = {
     "spr_block_tail_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "spr_block_tail": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _i, _vp, _i,
                             _vp, _i, _vp, _i, _vp, _i, _vp, _sz, _vp]),
+    "spr_block_tail_n": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _i, _vp, _i,
+                              _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _sz, _vp]),
+    "spr_instnorm_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "spr_maxpool_gather_r": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "spr_layernorm_range_count": (_i, [_i]),
     "spr_layernorm_r": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -962,7 +962,7 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
     unsigned int ph_u[2][8], pl_u[2][8];
     float ts = 0.f;
     bool redo = false;
-    bool sig = PLO;      // does this tile carry a lo plane (ADAPT: decided per tile)
+    bool sigk[2] = {PLO, PLO};      // does the 32-key sub-tile carry a lo plane (ADAPT: decided per sub-tile)
     for (;;) {
       // ---- S^T = K Q^T + (off - m_ref)   (rows = keys, cols = queries) ----
       if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
@@ -1022,25 +1022,32 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
       // ---- probabilities, their planes and the lane's tile sum ----
       float ta = 0.f, tb = 0.f;
       if constexpr (ADAPT) {
+        // per 32-key sub-tile (the decision needs that sub-tile's probabilities only: 16 live registers, not 32)
         typedef _Float16 h16x2_ __attribute__((ext_vector_type(2)));
-        h16x2_ m2 = {(_Float16)0.f, (_Float16)0.f};
+        const float thr = kSig * psum;                                    // (first tile: psum = 0 -> significant)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk) {
+          h16x2_ m2 = {(_Float16)0.f, (_Float16)0.f};
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
             const float p0 = __builtin_amdgcn_exp2f(sc[kk][r]);
             const float p1 = __builtin_amdgcn_exp2f(sc[kk][r + 1]);
             sc[kk][r] = p0;
             sc[kk][r + 1] = p1;
-            const auto hi_h = __builtin_amdgcn_cvt_pkrtz(p0, p1);
-            ph_u[kk][r >> 1] = __builtin_bit_cast(unsigned int, hi_h);
-            m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(h16x2_, hi_h));
+            // round to NEAREST here (v_cvt_pk_f16_f32, gfx950): sub-tiles with and without a lo plane are mixed in
+            // one row, so the systematic part of a round-toward-zero plane (-2^-11.5 on average) would no longer
+            // cancel in 1 / l as it does when EVERY weight carries it (mode 3) -- measured 4e-5 of the output scale
+            // on the late-spike test before this
+            // (through the compiler, not inline asm: a VALU instruction that reads the result of a transcendental needs
+            // a wait state the hazard pass only inserts for instructions it can see -- the asm form produced NaNs in
+            // the lanes the quarter-rate unit finishes last)
+            const unsigned int hi_u = __builtin_bit_cast(unsigned int, __builtin_convertvector((f32x2){p0, p1}, h16x2_));
+            ph_u[kk][r >> 1] = hi_u;
+            m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(h16x2_, hi_u));
           }
-        const float mxp = (float)(m2[0] > m2[1] ? m2[0] : m2[1]);
-        sig = __builtin_amdgcn_ballot_w64(!(mxp < kSig * psum)) != 0;     // (first tile: psum = 0 -> significant)
-        if (sig) {
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk)
+          const float mxp = (float)(m2[0] > m2[1] ? m2[0] : m2[1]);
+          sigk[kk] = __builtin_amdgcn_ballot_w64(!(mxp < thr)) != 0;
+          if (sigk[kk]) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
               ta += sc[kk][r];
@@ -1052,14 +1059,13 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
                   : "v"(ph_u[kk][r >> 1]), "v"(sc[kk][r]), "v"(sc[kk][r + 1]));
               pl_u[kk][r >> 1] = lo_u;
             }
-        } else {
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk)
+          } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel_hi:[1,0,0]" : "+v"(ta) : "v"(ph_u[kk][i]));
               asm("v_fma_mix_f32 %0, %1, 1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(tb) : "v"(ph_u[kk][i]));
             }
+          }
         }
       } else {
 #pragma unroll
@@ -1094,42 +1100,42 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
     }
     psum += ts;
     // ---- O^T += V^T P^T ----
-    auto pv = [&](auto lo_tag) __attribute__((always_inline)) {
+    auto pv = [&](auto lo_tag, int kk) __attribute__((always_inline)) {
       constexpr bool LO = decltype(lo_tag)::value;
+      h16x8 vfh[2], vfl[2];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        if (kk == 1) __builtin_amdgcn_sched_barrier(0);
-        h16x8 vfh[2], vfl[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if constexpr (ABL & 1) {
-            vfh[s] = qh[s];
-            if constexpr (H3) vfl[s] = ql[s];
-            continue;
-          }
-          const int vpos = l31 * KT2 + 8 * ((4 * kk + 2 * s + lh) ^ ((l31 >> 1) & 7));
-          vfh[s] = *reinterpret_cast<const h16x8*>(Vth[buf] + vpos);
-          if constexpr (H3) vfl[s] = *reinterpret_cast<const h16x8*>(Vtl[buf] + vpos);
+      for (int s = 0; s < 2; ++s) {
+        if constexpr (ABL & 1) {
+          vfh[s] = qh[s];
+          if constexpr (H3) vfl[s] = ql[s];
+          continue;
         }
+        const int vpos = l31 * KT2 + 8 * ((4 * kk + 2 * s + lh) ^ ((l31 >> 1) & 7));
+        vfh[s] = *reinterpret_cast<const h16x8*>(Vth[buf] + vpos);
+        if constexpr (H3) vfl[s] = *reinterpret_cast<const h16x8*>(Vtl[buf] + vpos);
+      }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const u32x4 pa = {ph_u[kk][4 * s], ph_u[kk][4 * s + 1], ph_u[kk][4 * s + 2], ph_u[kk][4 * s + 3]};
-          const h16x8 pbh = __builtin_bit_cast(h16x8, pa);
-          if constexpr (LO) {
-            const u32x4 pb = {pl_u[kk][4 * s], pl_u[kk][4 * s + 1], pl_u[kk][4 * s + 2], pl_u[kk][4 * s + 3]};
-            const h16x8 pbl = __builtin_bit_cast(h16x8, pb);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbl, o, 0, 0, 0);
-          }
-          if constexpr (H3) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[s], pbh, o, 0, 0, 0);
-          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbh, o, 0, 0, 0);
+      for (int s = 0; s < 2; ++s) {
+        const u32x4 pa = {ph_u[kk][4 * s], ph_u[kk][4 * s + 1], ph_u[kk][4 * s + 2], ph_u[kk][4 * s + 3]};
+        const h16x8 pbh = __builtin_bit_cast(h16x8, pa);
+        if constexpr (LO) {
+          const u32x4 pb = {pl_u[kk][4 * s], pl_u[kk][4 * s + 1], pl_u[kk][4 * s + 2], pl_u[kk][4 * s + 3]};
+          const h16x8 pbl = __builtin_bit_cast(h16x8, pb);
+          o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbl, o, 0, 0, 0);
         }
+        if constexpr (H3) o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[s], pbh, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[s], pbh, o, 0, 0, 0);
       }
     };
-    if constexpr (ADAPT) {
-      if (sig) pv(std::true_type{});
-      else pv(std::false_type{});
-    } else {
-      pv(std::integral_constant<bool, PLO>{});
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if (kk == 1) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ADAPT) {
+        if (sigk[kk]) pv(std::true_type{}, kk);
+        else pv(std::false_type{}, kk);
+      } else {
+        pv(std::integral_constant<bool, PLO>{}, kk);
+      }
     }
   };
 
@@ -1336,7 +1342,7 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
 #undef SPR_ATTN_SA
 #endif
     if (mode == 4) {
-      hipLaunchKernelGGL((k_attn_s<true, true, 3, 2, 0, true>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
+      hipLaunchKernelGGL((k_attn_s<true, true, 4, 2, 0, true>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
                          pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
     } else if (prio > 0) {
       if (mode == 2) SPR_ATTN_S(false, false, 2);

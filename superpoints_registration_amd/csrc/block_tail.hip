@@ -60,6 +60,12 @@ struct TailArgs {
   float* out;
   float* out_range;
   int nslots;
+  // round 5: xa is the RAW input of a per-cloud InstanceNorm + LeakyReLU (the KPConv output of a bottleneck block):
+  // xa_mean / xa_rstd [nb][ka] (spr_instnorm_stats); the normalisation runs while a tile is staged, so the
+  // normalised tensor is never written or read (kpconv_blocks.py:510-525 followed by :553-561 of the reference)
+  const float* xa_mean;
+  const float* xa_rstd;
+  float xa_slope;
 };
 
 // slot (16 bytes) of the fragment element (row16, kg) inside the 1-KiB image of k-step ks.
@@ -151,12 +157,24 @@ __global__ __launch_bounds__(kTailThreads) void k_block_tail(const TailArgs a) {
   const int ntiles = a.tile_cu[a.nb];
   float4 pa[NPA], pb[NPB], pst = make_float4(0.f, 0.f, 0.f, 0.f);
   float mx = 0.f;
+  // normalise-on-load of xa: every staged element of this thread belongs to the same four channels (the thread
+  // count is a multiple of the float4s per row), so one (mean, rstd) float4 pair per tile -- a tile is one cloud
+  const bool norm_a = a.xa_mean != nullptr;
+  float4 pma = make_float4(0.f, 0.f, 0.f, 0.f), pra = make_float4(1.f, 1.f, 1.f, 1.f);
+  int pvalid = 0;
+  static_assert(kTailThreads % (KA / 4) == 0, "a thread stages one channel quad");
 
   // d = {first row, valid rows, cloud} of the tile (one 16-byte record, read one iteration ahead of its use
   // so that no dependent index chain sits in front of the row loads)
   auto fetch = [&](const int4 d) {
     const int row0 = d.x, valid = d.y, cloud = d.z;
     tail_fetch<KA, NPA>(a.xa, row0, valid, pa);
+    if (norm_a) {
+      const int j = threadIdx.x % (KA / 4);
+      pma = reinterpret_cast<const float4*>(a.xa_mean + (size_t)cloud * KA)[j];
+      pra = reinterpret_cast<const float4*>(a.xa_rstd + (size_t)cloud * KA)[j];
+      pvalid = valid;
+    }
     if constexpr (KB > 0) tail_fetch<KB, NPB>(a.xb, row0, valid, pb);
     if constexpr (PASS == 2) {
       if (threadIdx.x < NSTAT4) {
@@ -168,6 +186,23 @@ __global__ __launch_bounds__(kTailThreads) void k_block_tail(const TailArgs a) {
   auto stage = [&](int buf) {
     char* hi = tile_lds + buf * 2 * PLANE;
     char* lo = hi + PLANE;
+    if (norm_a) {
+      // the float operations of k_in_apply (norm_pool.hip), in its order; rows past the cloud's end stay zero
+#pragma unroll
+      for (int i = 0; i < NPA; ++i) {
+        const int row = (threadIdx.x + kTailThreads * i) / (KA / 4);
+        float4 w = pa[i];
+        w.x = (w.x - pma.x) * pra.x;
+        w.y = (w.y - pma.y) * pra.y;
+        w.z = (w.z - pma.z) * pra.z;
+        w.w = (w.w - pma.w) * pra.w;
+        w.x = w.x >= 0.f ? w.x : w.x * a.xa_slope;
+        w.y = w.y >= 0.f ? w.y : w.y * a.xa_slope;
+        w.z = w.z >= 0.f ? w.z : w.z * a.xa_slope;
+        w.w = w.w >= 0.f ? w.w : w.w * a.xa_slope;
+        pa[i] = row < pvalid ? w : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
     tail_stage<KA, NPA, KS, 0>(pa, sa, hi, lo);
     if constexpr (KB > 0) tail_stage<KB, NPB, KS, KSA>(pb, sb, hi, lo);
     if constexpr (PASS == 2) {
@@ -463,12 +498,12 @@ extern "C" size_t spr_block_tail_workspace_bytes(int n, int nb, int kb, int n_ou
          4 * align_up(kAmaxParts * sizeof(float), 256);
 }
 
-extern "C" int spr_block_tail(const float* xa, int ka, const float* wa, const float* xb, int kb, const float* wb,
-                              const float* add, const int* cu, const int* tiles, int n, int nb, int n_out, float eps,
-                              float slope, float* out, const float* xa_range, int xa_range_n, const float* wa_range,
-                              int wa_range_n, const float* xb_range, int xb_range_n, const float* wb_range,
-                              int wb_range_n, float* out_range, int out_range_n, void* ws, size_t ws_bytes,
-                              void* stream_) {
+static int block_tail_impl(const float* xa, int ka, const float* wa, const float* xb, int kb, const float* wb,
+                           const float* add, const int* cu, const int* tiles, int n, int nb, int n_out, float eps,
+                           float slope, float* out, const float* xa_range, int xa_range_n, const float* wa_range,
+                           int wa_range_n, const float* xb_range, int xb_range_n, const float* wb_range,
+                           int wb_range_n, float* out_range, int out_range_n, const float* xa_mean,
+                           const float* xa_rstd, float xa_slope, void* ws, size_t ws_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SPR_REQUIRE(spr::gemm_mode() == 1, "block_tail: only in the split-fp16 product mode (spr_set_gemm_mode(1))");
   const TailShape sh = tail_shape(ka, kb, n_out);
@@ -491,6 +526,10 @@ extern "C" int spr_block_tail(const float* xa, int ka, const float* wa, const fl
   a.xa = xa; a.xb = xb; a.wa = wa; a.wb = wb; a.add = add; a.cu = cu; a.tile_cu = tiles;
   a.tile_desc = reinterpret_cast<const int4*>(tiles + tiles_desc_offset(nb));
   a.nb = nb; a.n = n; a.n_total = n_out; a.slope = slope; a.out = out; a.out_range = out_range; a.nslots = out_range_n;
+  a.xa_mean = xa_mean; a.xa_rstd = xa_rstd; a.xa_slope = xa_slope;
+  SPR_REQUIRE((xa_mean == nullptr) == (xa_rstd == nullptr), "block_tail: xa_mean and xa_rstd come together");
+  SPR_REQUIRE(xa_mean == nullptr || xa_range != nullptr,
+              "block_tail: a normalised-on-load xa needs the bound of the NORMALISED values as xa_range");
   auto range = [&](const float* x, long rows, int cols, const float* given, int given_n, float* scratch,
                    const float*& parts, int& np) -> int {
     if (given != nullptr) {
@@ -522,4 +561,30 @@ extern "C" int spr_block_tail(const float* xa, int ka, const float* wa, const fl
 #undef SPR_TAIL
   SPR_REQUIRE(false, "block_tail: no kernel for ka=%d kb=%d n_out=%d", ka, kb, n_out);
   return 1;
+}
+
+extern "C" int spr_block_tail(const float* xa, int ka, const float* wa, const float* xb, int kb, const float* wb,
+                              const float* add, const int* cu, const int* tiles, int n, int nb, int n_out, float eps,
+                              float slope, float* out, const float* xa_range, int xa_range_n, const float* wa_range,
+                              int wa_range_n, const float* xb_range, int xb_range_n, const float* wb_range,
+                              int wb_range_n, float* out_range, int out_range_n, void* ws, size_t ws_bytes,
+                              void* stream_) {
+  return block_tail_impl(xa, ka, wa, xb, kb, wb, add, cu, tiles, n, nb, n_out, eps, slope, out, xa_range, xa_range_n,
+                         wa_range, wa_range_n, xb_range, xb_range_n, wb_range, wb_range_n, out_range, out_range_n,
+                         nullptr, nullptr, 1.0f, ws, ws_bytes, stream_);
+}
+
+// The same with xa = the RAW input of a per-cloud InstanceNorm + LeakyReLU(xa_slope) whose statistics the caller
+// has (spr_instnorm_stats: xa_mean, xa_rstd [nb][ka]): lrelu(IN(lrelu(IN(xa)) wa^T) + ...).  xa_range must bound
+// the NORMALISED values (sqrt(longest cloud) is always valid: |x - mean| <= sqrt(n - 1) sigma).
+extern "C" int spr_block_tail_n(const float* xa, int ka, const float* wa, const float* xb, int kb, const float* wb,
+                                const float* add, const int* cu, const int* tiles, int n, int nb, int n_out, float eps,
+                                float slope, float* out, const float* xa_range, int xa_range_n, const float* wa_range,
+                                int wa_range_n, const float* xb_range, int xb_range_n, const float* wb_range,
+                                int wb_range_n, float* out_range, int out_range_n, const float* xa_mean,
+                                const float* xa_rstd, float xa_slope, void* ws, size_t ws_bytes, void* stream_) {
+  SPR_REQUIRE(xa_mean != nullptr && xa_rstd != nullptr, "block_tail_n: statistics missing");
+  return block_tail_impl(xa, ka, wa, xb, kb, wb, add, cu, tiles, n, nb, n_out, eps, slope, out, xa_range, xa_range_n,
+                         wa_range, wa_range_n, xb_range, xb_range_n, wb_range, wb_range_n, out_range, out_range_n,
+                         xa_mean, xa_rstd, xa_slope, ws, ws_bytes, stream_);
 }

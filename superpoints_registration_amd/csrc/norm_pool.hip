@@ -421,6 +421,25 @@ extern "C" int spr_instnorm_r(const float* x, const int* cu, int n, int nb, int 
   return 0;
 }
 
+// Statistics only: mean [nb][c] and rstd [nb][c] of a per-cloud InstanceNorm (the two passes k_in_stats / k_in_final
+// of spr_instnorm, bit for bit), for consumers that normalise on load (spr_block_tail_n).
+extern "C" int spr_instnorm_stats(const float* x, const int* cu, int n, int nb, int max_len_host, int c, float eps,
+                                  float* mean, float* rstd, void* ws, size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(x && cu && mean && rstd && n > 0 && nb >= 1 && c >= 4 && c % 4 == 0, "instnorm_stats: bad arguments (c=%d)", c);
+  SPR_REQUIRE(max_len_host >= 1 && max_len_host <= n, "instnorm_stats: bad max_len_host=%d", max_len_host);
+  SPR_REQUIRE(ws_bytes >= spr_instnorm_workspace_bytes(max_len_host, nb, c), "instnorm_stats: workspace too small");
+  Workspace w(ws, ws_bytes);
+  const int nsplit = in_nsplit(max_len_host);
+  double* part = w.take<double>((size_t)nb * nsplit * 2 * c);
+  SPR_REQUIRE(part != nullptr, "instnorm_stats: workspace carve failed");
+  hipLaunchKernelGGL(k_in_stats, dim3(nb, nsplit, cdiv(c, 64)), dim3(256), 0, stream, x, cu, c, nsplit, part);
+  hipLaunchKernelGGL(k_in_final, dim3(cdiv((long)nb * c, 256)), dim3(256), 0, stream, part, cu, nb, c, nsplit, eps, mean,
+                     rstd);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" size_t spr_instnorm_bwd_workspace_bytes(int max_len, int nb, int c) {
   const size_t B = (size_t)(nb > 0 ? nb : 1), C = (size_t)(c > 0 ? c : 1);
   return spr_instnorm_workspace_bytes(max_len, nb, c) + 2 * align_up(B * C * sizeof(double), 256);

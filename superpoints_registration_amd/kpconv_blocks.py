@@ -15,8 +15,12 @@ import torch.nn as nn
 from torch.nn.init import kaiming_uniform_
 from torch.nn.parameter import Parameter
 
+import os
+
 from . import _concurrency, ops
 from .kernel_points import load_kernels
+
+_NORM_FOLD = os.environ.get("SPR_NO_NORM_FOLD", "0") != "1"   # experiment switch (A/B timing)
 
 
 def _cu_of(batch, layer_ind):
@@ -299,7 +303,15 @@ class ResnetBottleneckBlock(nn.Module):
             if isinstance(self.unary1, UnaryBlock) else features
         self.KPConv.rows_sorted = bool(batch.get('_rows_sorted', False))
         x = self.KPConv(q_pts, s_pts, neighb_inds, x)
-        x = self.batch_norm_conv(x, stack_lengths_post, cu=cu_post, slope=0.1, max_len=ml_post)
+        # Inference with the fused tail: the norm + LeakyReLU behind the KPConv runs while the tail stages its
+        # tiles (ops.block_tail(xa_stats=...)): only the statistics passes remain of it, the normalised tensor is
+        # never written or read back (SPR_NO_NORM_FOLD=1: the separate operator, for A/B).
+        fold = fused and self.use_bn and _NORM_FOLD
+        conv_stats = None
+        if fold:
+            conv_stats = ops.instnorm_stats(x, cu_post, eps=self.batch_norm_conv.eps, max_len=ml_post)
+        else:
+            x = self.batch_norm_conv(x, stack_lengths_post, cu=cu_post, slope=0.1, max_len=ml_post)
 
         if fork:
             main.wait_event(joined)
@@ -309,9 +321,11 @@ class ResnetBottleneckBlock(nn.Module):
         if fused:
             if projected:
                 return ops.block_tail(x, self.unary2.mlp.weight, cu_post, xb=shortcut,
-                                      wb=self.unary_shortcut.mlp.weight, eps=self.unary2.batch_norm.eps, slope=0.1)
+                                      wb=self.unary_shortcut.mlp.weight, eps=self.unary2.batch_norm.eps, slope=0.1,
+                                      xa_stats=conv_stats, xa_slope=0.1, xa_max_len=ml_post)
             return ops.block_tail(x, self.unary2.mlp.weight, cu_post, add=shortcut,
-                                  eps=self.unary2.batch_norm.eps, slope=0.1)
+                                  eps=self.unary2.batch_norm.eps, slope=0.1,
+                                  xa_stats=conv_stats, xa_slope=0.1, xa_max_len=ml_post)
         # unary2 (no relu) + shortcut, then LeakyReLU: fused into unary2's norm pass
         return self.unary2(x, stack_lengths_post, cu=cu_post, add=shortcut, final_slope=0.1,
                            max_len=ml_post)

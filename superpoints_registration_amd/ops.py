@@ -527,9 +527,43 @@ def _tail_tiles(cu: torch.Tensor, n: int, tr: int) -> torch.Tensor:
     return t
 
 
-def block_tail(xa, wa, cu, xb=None, wb=None, add=None, eps: float = 1e-5, slope: float = 0.1) -> torch.Tensor:
+def instnorm_stats(x, cu, eps: float = 1e-5, max_len: Optional[int] = None):
+    """(mean, rstd), each [nb, c]: the statistics passes of `instnorm` alone, for a consumer that normalises on
+    load (block_tail(..., xa_stats=...))."""
+    x = _dev(x, "x", torch.float32)
+    cu = _dev(cu, "cu", torch.int32)
+    n, c = x.shape
+    nb = cu.numel() - 1
+    L = _lib.lib()
+    max_len = n if max_len is None else max(1, min(int(max_len), n))
+    ws = _workspace(L.spr_instnorm_workspace_bytes(max_len, nb, c), x.device)
+    st = torch.empty((2, nb, c), dtype=torch.float32, device=x.device)
+    _lib.check(L.spr_instnorm_stats(_ptr(x), _ptr(cu), n, nb, max_len, c, float(eps), _ptr(st[0]), _ptr(st[1]),
+                                    _ptr(ws), ws.numel(), _stream(x)), "spr_instnorm_stats")
+    return st[0], st[1]
+
+
+_NORM_BOUNDS = {}
+
+
+def _norm_bound(max_len: int, device) -> torch.Tensor:
+    """One-slot operand range holding sqrt(max_len): |x - mean| <= sqrt(n - 1) sigma for any n values, so an
+    instance-normalised (and LeakyReLU'd, slope <= 1) column of a cloud of at most max_len points is bounded by it."""
+    key = (int(max_len), str(device))
+    t = _NORM_BOUNDS.get(key)
+    if t is None:
+        t = torch.full((1,), float(max(1, int(max_len))) ** 0.5, dtype=torch.float32, device=device)
+        _NORM_BOUNDS[key] = t
+    return t
+
+
+def block_tail(xa, wa, cu, xb=None, wb=None, add=None, eps: float = 1e-5, slope: float = 0.1,
+               xa_stats=None, xa_slope: float = 0.1, xa_max_len: Optional[int] = None) -> torch.Tensor:
     """a5, inference: lrelu(IN(xa wa^T) + (IN(xb wb^T) | add), slope) without the un-normalised
-    projections ever being written (spr_block_tail).  The caller checks block_tail_tile_rows first."""
+    projections ever being written (spr_block_tail).  The caller checks block_tail_tile_rows first.
+    xa_stats = (mean, rstd) of instnorm_stats(xa): xa is then the RAW input of a per-cloud InstanceNorm +
+    LeakyReLU(xa_slope) that runs while the tiles are staged (spr_block_tail_n) -- the bottleneck block's norm
+    behind its KPConv costs no pass of its own."""
     xa = _dev(xa, "xa", torch.float32)
     wa = _dev(wa, "wa", torch.float32)
     cu = _dev(cu, "cu", torch.int32)
@@ -553,7 +587,10 @@ def block_tail(xa, wa, cu, xb=None, wb=None, add=None, eps: float = 1e-5, slope:
     tiles = _tail_tiles(cu, n, tr)
     out = torch.empty((n, n_out), dtype=torch.float32, device=xa.device)
     ws = _workspace(L.spr_block_tail_workspace_bytes(n, nb, kb, n_out, tr), xa.device)
-    xar, xar_n = _get_range(xa)
+    if xa_stats is not None:
+        xar, xar_n = _norm_bound(n if xa_max_len is None else xa_max_len, xa.device), 1
+    else:
+        xar, xar_n = _get_range(xa)
     war, war_n = _static_range(wa)
     xbr, xbr_n, wbr, wbr_n = None, 0, None, 0
     if kb > 0:
@@ -561,10 +598,19 @@ def block_tail(xa, wa, cu, xb=None, wb=None, add=None, eps: float = 1e-5, slope:
         wbr, wbr_n = _static_range(wb)
     cnt = _STREAM_SLOTS
     rng = _zero_slots(cnt, xa.device) if _HANDOVER else None
-    _lib.check(L.spr_block_tail(_ptr(xa), ka, _ptr(wa), _ptr(xb), kb, _ptr(wb), _ptr(add), _ptr(cu), _ptr(tiles),
-                                n, nb, n_out, float(eps), float(slope), _ptr(out), _ptr(xar), int(xar_n),
-                                _ptr(war), int(war_n), _ptr(xbr), int(xbr_n), _ptr(wbr), int(wbr_n),
-                                _ptr(rng), cnt, _ptr(ws), ws.numel(), _stream(xa)), "spr_block_tail")
+    if xa_stats is not None:
+        mean, rstd = xa_stats
+        assert mean.shape == (nb, ka) and rstd.shape == (nb, ka) and mean.is_contiguous() and rstd.is_contiguous()
+        _lib.check(L.spr_block_tail_n(_ptr(xa), ka, _ptr(wa), _ptr(xb), kb, _ptr(wb), _ptr(add), _ptr(cu), _ptr(tiles),
+                                      n, nb, n_out, float(eps), float(slope), _ptr(out), _ptr(xar), int(xar_n),
+                                      _ptr(war), int(war_n), _ptr(xbr), int(xbr_n), _ptr(wbr), int(wbr_n),
+                                      _ptr(rng), cnt, _ptr(mean), _ptr(rstd), float(xa_slope), _ptr(ws), ws.numel(),
+                                      _stream(xa)), "spr_block_tail_n")
+    else:
+        _lib.check(L.spr_block_tail(_ptr(xa), ka, _ptr(wa), _ptr(xb), kb, _ptr(wb), _ptr(add), _ptr(cu), _ptr(tiles),
+                                    n, nb, n_out, float(eps), float(slope), _ptr(out), _ptr(xar), int(xar_n),
+                                    _ptr(war), int(war_n), _ptr(xbr), int(xbr_n), _ptr(wbr), int(wbr_n),
+                                    _ptr(rng), cnt, _ptr(ws), ws.numel(), _stream(xa)), "spr_block_tail")
     if rng is not None:
         _set_range(out, rng, cnt)
     return out

@@ -138,3 +138,41 @@ def test_block_tail_rejects_unsupported_shape(device):
     wa = torch.zeros((128, 48), device=device)
     with pytest.raises(RuntimeError):
         ops.block_tail(xa, wa, ops.lengths_to_cu([10], device))
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_block_tail_normalises_its_input_on_load(device, shape):
+    """Round 5 (spr_block_tail_n): xa handed over RAW with the statistics of the per-cloud InstanceNorm +
+    LeakyReLU(0.1) that precedes the tail in a bottleneck block (kpconv_blocks.py:717-719 of the reference).  Against
+    the float64 expression lrelu(IN(lrelu(IN(xa)) wa^T) + ...) at 5e-6 of the output scale, and against the two
+    separate operators (instnorm, then the plain tail) at 2e-6: the only difference between the two GPU routes is
+    the operand scale of the staged tile (the static bound sqrt(longest cloud) instead of the measured maximum)."""
+    ka, kb, n_out = shape
+    lens = LENS
+    xa, wa, xb, wb, ad, cu = _inputs(ka, kb, n_out, lens, device, seed=3)
+    mean, rstd = ops.instnorm_stats(xa, cu, max_len=max(lens))
+    got = ops.block_tail(xa, wa, cu, xb=xb, wb=wb, add=ad, xa_stats=(mean, rstd), xa_slope=0.1, xa_max_len=max(lens))
+    xn = ops.instnorm_raw(xa, cu, slope=0.1, max_len=max(lens))
+    two = ops.block_tail(xn, wa, cu, xb=xb, wb=wb, add=ad)
+
+    def inorm(y):
+        out = torch.empty_like(y)
+        o = 0
+        for l in lens:
+            sl = y[o:o + l]
+            m = sl.mean(0, keepdim=True)
+            v = ((sl - m) ** 2).mean(0, keepdim=True)
+            out[o:o + l] = (sl - m) / torch.sqrt(v + 1e-5)
+            o += l
+        return out
+    x64 = inorm(xa.double().cpu())
+    x64 = torch.where(x64 >= 0, x64, x64 * 0.1)
+    ref = _ref64(x64, wa.cpu(), None if xb is None else xb.cpu(), None if wb is None else wb.cpu(),
+                 None if ad is None else ad.cpu(), lens)
+    scale = float(ref.abs().max())
+    assert torch.isfinite(got).all()
+    assert float((got.double().cpu() - ref).abs().max()) <= 5e-6 * scale
+    assert float((got - two).abs().max()) <= 2e-6 * scale
+    # the statistics entry point is the norm operator's own first two passes
+    m64 = torch.stack([xa.double().cpu()[o:o + l].mean(0) for o, l in zip(np.concatenate([[0], np.cumsum(lens)[:-1]]), lens)])
+    assert float((mean.double().cpu() - m64).abs().max()) <= 1e-6 * float(xa.abs().max())

