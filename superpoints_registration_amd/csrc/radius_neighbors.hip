@@ -30,6 +30,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "spr_common.h"
+#include <type_traits>
 
 namespace spr {
 namespace {
@@ -639,6 +640,69 @@ __global__ __launch_bounds__(BLOCK) void k_sort_rows(const unsigned long long* _
   for (int k = kept; k < limit; ++k) row[k] = ns;
 }
 
+// Round 5: the same rank sort with the row in REGISTERS (rows of at most N entries; the launcher caps the scan's
+// scratch rows at N for limits <= N).  No LDS at all: k_sort_rows needs cap * 8 bytes of LDS per thread (40 KB per
+// 64-thread block at the 3DMatch limit), i.e. four waves per CU at best -- and none while a main-stream kernel that
+// owns the CU's LDS (the KPConv ring: 160 KB) is resident, which is where its 465 us per call in the round-4 bench
+// profile came from (150 us alone).  Every index into the key array is a compile-time constant (the loops are fully
+// unrolled; a wave leaves both loops at its longest row through wave-uniform branches), so the array lives in VGPRs.
+// Results are those of k_sort_rows, entry for entry.
+// f(integral_constant<int, I>) for I = B .. E-1: every index is a compile-time constant in the callee (a plain
+// `#pragma unroll` nest of 64 x 64 iterations is not unrolled by the compiler: the key array then went to scratch)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_sort_rows_reg(const unsigned long long* __restrict__ tmp_key,
+                                                       const int* __restrict__ kept_in, const int* __restrict__ qid_in,
+                                                       const int* __restrict__ err, int nq, int ns, int limit,
+                                                       int* __restrict__ out) {
+  static_assert(N % 8 == 0, "rows in chunks of eight");
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (*err) return;
+  const bool act = i < nq;
+  const int kept = act ? min(kept_in[i], N) : 0;
+  int kmax = kept;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) kmax = max(kmax, __shfl_xor(kmax, o, 64));
+  kmax = __builtin_amdgcn_readfirstlane(kmax);
+  const unsigned long long* src = tmp_key + (act ? i : 0);
+  const size_t rs = (size_t)nq;
+  unsigned long long key[N];
+  static_for<0, N>([&](auto kc) { key[decltype(kc)::value] = ~0ull; });
+  static_for<0, N / 8>([&](auto cc) {
+    constexpr int k0 = 8 * decltype(cc)::value;
+    if (k0 < kmax) {
+      static_for<k0, k0 + 8>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (k < kept) key[k] = src[rs * k];
+      });
+    }
+  });
+  int* row = out + (size_t)(act ? qid_in[i] : 0) * limit;
+  static_for<0, N>([&](auto ac) {
+    constexpr int a = decltype(ac)::value;
+    if (a < kmax) {
+      int r = 0;
+      static_for<0, N / 8>([&](auto cc) {
+        constexpr int b0 = 8 * decltype(cc)::value;
+        if (b0 < kmax) {
+          static_for<b0, b0 + 8>([&](auto bc) { r += key[decltype(bc)::value] < key[a] ? 1 : 0; });   // padding (~0) is never smaller
+        }
+      });
+      // ranks are a permutation of 0..kept-1; the row keeps the `limit` nearest
+      if (a < kept && r < limit) row[r] = (int)(unsigned)key[a];
+    }
+  });
+  if (act)
+    for (int k = kept; k < limit; ++k) row[k] = ns;
+}
+
 __global__ void k_nbr_err2(const int* hdr, int slot, int* max_count) {
   const int err = hdr[kHdrErr];
   if (err & 1) *max_count = -1;       // extent / radius too large
@@ -710,7 +774,12 @@ int table_query(const float* q_xyz, const int* q_cu, int nq, int self, int ns, i
                 hipStream_t stream) {
   const TableView t = table_view(const_cast<void*>(blob), ns, nb);
   Workspace w(ws, ws_bytes);
-  const int rcap = nbr_row_cap(limit);
+  // limits up to kRegRows: the scratch rows are capped there and sorted in registers (k_sort_rows_reg); a query with
+  // more candidates in range than the cap takes the scan's second (histogram-cut) pass, as before beyond 2 * limit
+  constexpr int kRegRows = 64;
+  static const bool reg_sort = [] { const char* e = getenv("SPR_NBR_LDS_SORT"); return e == nullptr || e[0] != '1'; }();
+  const bool use_reg = reg_sort && limit <= kRegRows;
+  const int rcap = use_reg ? min(nbr_row_cap(limit), kRegRows) : nbr_row_cap(limit);
   unsigned long long* tmp_key = w.take<unsigned long long>((size_t)nq * rcap);
   int* kept = w.take<int>((size_t)nq);
   int* qid = w.take<int>((size_t)nq);
@@ -719,6 +788,13 @@ int table_query(const float* q_xyz, const int* q_cu, int nq, int self, int ns, i
   const float inv_cell = 1.0f / (radius * (1.0f + 1.0f / 256.0f));
   hipLaunchKernelGGL(k_scan_table, dim3(cdiv(nq, 256)), dim3(256), 0, stream, q_xyz, q_cu, nq, nb, t.ginfo, t.start,
                      t.rec, t.hdr + kHdrErr, r2, inv_cell, rcap, limit, self, tmp_key, kept, qid, t.hdr + kHdrSlot0 + slot);
+  if (use_reg) {
+    hipLaunchKernelGGL(k_sort_rows_reg<kRegRows>, dim3(cdiv(nq, 256)), dim3(256), 0, stream, tmp_key, kept, qid,
+                       t.hdr + kHdrErr, nq, ns, limit, out_idx);
+    hipLaunchKernelGGL(k_nbr_err2, dim3(1), dim3(1), 0, stream, t.hdr, slot, max_count);
+    SPR_LAUNCH_CHECK();
+    return 0;
+  }
   constexpr int BLOCK = 64;   // cap <= 128 -> at most 64 KB of LDS
   // whole rows in LDS: staging only the first `limit` entries gave 4 % on voxelised clouds (most rows are
   // shorter than `limit`) but 1.9 ms per call on LiDAR-shaped scans, whose rows fill the 2 * limit scratch
