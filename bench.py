@@ -43,9 +43,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs-per-step", type=int, default=32,
-                    help="pairs per forward and rank (round 3: 32 -- 3 % above 16 on the same box, 48 another 2 %: the "
-                         "N = 256 products of the transformer then run two rounds of tiles per CU instead of one)")
+    ap.add_argument("--pairs-per-step", type=int, default=64,
+                    help="pairs per forward and rank.  Round 5: 64 (one box, same build: 32 -> 1 111, 64 -> 1 164, "
+                         "96 -> 1 170, 128 -> 1 180 pairs/s: per-launch tails and the per-forward host work amortise "
+                         "over more pairs; rounds 3-4 used 32, rounds 1-2 16)")
     ap.add_argument("--no-cross-step-overlap", action="store_true",
                     help="make every forward's pyramid wait for the previous forward's tail (default: inputs "
                          "are resident, so consecutive steps pipeline on the GPU)")
