@@ -860,7 +860,11 @@ __global__ __launch_bounds__(256, WPS) void k_attn_h3(
 // bounded by 2^-10 sqrt(sum w_j^2) <= 2^-10 sqrt(2^-7) = 8.6e-5 of the value spread in the worst case (128 keys
 // of exactly that weight) and is ~5e-6 for flat rows of 2 000 keys -- the peaked rows mode 3 is inaccurate on
 // (few keys with large weights) are exact here.
-template <bool H3, bool PLO, int WPS, int PRIO, int ABL = 0, bool ADAPT = false>
+// PF (round 5): fragment prefetch.  The sensitivity builds (profiles/r05_attn_ablate.txt) price the LDS fragment
+// reads at a quarter of the kernel: every group of MFMAs waits for four ds_read_b128 issued right in front of it.
+// PF = 1 issues a tile's V^T fragments (both 32-key halves) at the top of the tile -- they land under the score
+// MFMAs and the exponentials -- and the K fragments of both halves before the first score MFMA.
+template <bool H3, bool PLO, int WPS, int PRIO, int ABL = 0, bool ADAPT = false, int PF = 0>
 __global__ __launch_bounds__(256, WPS) void k_attn_s(
     const _Float16* __restrict__ qh_g, const _Float16* __restrict__ ql_g,
     const _Float16* __restrict__ kh_g, const _Float16* __restrict__ kl_g,
@@ -946,6 +950,12 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
     if constexpr (H3) dma16(kl_g, koff, kdst_l + (unsigned)nbuf * 4096u);
     dma16(vth_g, voff, vdst_h + (unsigned)nbuf * 4096u);
     if constexpr (H3) dma16(vtl_g, voff, vdst_l + (unsigned)nbuf * 4096u);
+    if constexpr (ABL & 16) {   // sensitivity: the same four pieces once more
+      dma16(kh_g, koff, kdst_h + (unsigned)nbuf * 4096u);
+      dma16(kl_g, koff, kdst_l + (unsigned)nbuf * 4096u);
+      dma16(vth_g, voff, vdst_h + (unsigned)nbuf * 4096u);
+      dma16(vtl_g, voff, vdst_l + (unsigned)nbuf * 4096u);
+    }
   };
   auto stash = [&](int) {
     if constexpr (ABL & 2) return;
@@ -962,32 +972,56 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
     unsigned int ph_u[2][8], pl_u[2][8];
     float ts = 0.f;
     bool redo = false;
+    h16x8 pvh[2][2], pvl[2][2];     // PF: V^T fragments of the whole tile
+    if constexpr (PF > 0) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int vpos = l31 * KT2 + 8 * ((4 * kk + 2 * s + lh) ^ ((l31 >> 1) & 7));
+          pvh[kk][s] = *reinterpret_cast<const h16x8*>(Vth[buf] + vpos);
+          if constexpr (H3) pvl[kk][s] = *reinterpret_cast<const h16x8*>(Vtl[buf] + vpos);
+        }
+    }
     bool sigk[2] = {PLO, PLO};      // does the 32-key sub-tile carry a lo plane (ADAPT: decided per sub-tile)
     for (;;) {
       // ---- S^T = K Q^T + (off - m_ref)   (rows = keys, cols = queries) ----
       if constexpr (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        h16x8 kfh[2], kfl[2];
+      h16x8 kfh[2][2], kfl[2][2];
+      auto load_kf = [&](int kk) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           if constexpr (ABL & 1) {
-            kfh[s] = qh[s];
-            if constexpr (H3) kfl[s] = ql[s];
+            kfh[kk][s] = qh[s];
+            if constexpr (H3) kfl[kk][s] = ql[s];
             continue;
           }
           const int kpos = (32 * kk + l31) * HD + 8 * ((2 * s + lh) ^ ((l31 >> 2) & 3));
-          kfh[s] = *reinterpret_cast<const h16x8*>(Kh[buf] + kpos);
-          if constexpr (H3) kfl[s] = *reinterpret_cast<const h16x8*>(Kl[buf] + kpos);
+          kfh[kk][s] = *reinterpret_cast<const h16x8*>(Kh[buf] + kpos);
+          if constexpr (H3) kfl[kk][s] = *reinterpret_cast<const h16x8*>(Kl[buf] + kpos);
+          if constexpr (ABL & 8) {    // sensitivity: the same reads once more (volatile: not merged), data unchanged
+            const h16x8 d0 = *reinterpret_cast<const volatile h16x8*>(Kh[buf ^ 1] + kpos);
+            const h16x8 d1 = *reinterpret_cast<const volatile h16x8*>(Kl[buf ^ 1] + kpos);
+            asm volatile("" ::"v"(d0), "v"(d1));
+          }
         }
+      };
+      if constexpr (PF > 0) {
+        load_kf(0);
+        load_kf(1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        if constexpr (PF == 0) load_kf(kk);
         sc[kk] = negm;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           if constexpr (H3) {
-            sc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], ql[s], sc[kk], 0, 0, 0);
-            sc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[s], qh[s], sc[kk], 0, 0, 0);
+            sc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[kk][s], ql[s], sc[kk], 0, 0, 0);
+            sc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[kk][s], qh[s], sc[kk], 0, 0, 0);
           }
-          sc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[s], qh[s], sc[kk], 0, 0, 0);
+          sc[kk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[kk][s], qh[s], sc[kk], 0, 0, 0);
         }
         if (kk == 0) __builtin_amdgcn_sched_barrier(0);
       }
@@ -1074,6 +1108,11 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
         for (int r = 0; r < 16; r += 2) {
           const float p0 = __builtin_amdgcn_exp2f(sc[kk][r]);
           const float p1 = __builtin_amdgcn_exp2f(sc[kk][r + 1]);
+          if constexpr (ABL & 64) {   // sensitivity: two more exponentials per pair, results discarded
+            float e0, e1;
+            asm volatile("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" : "=v"(e0), "=v"(e1) : "v"(sc[kk][r]), "v"(sc[kk][r + 1]));
+            asm volatile("" ::"v"(e0), "v"(e1));
+          }
           const auto hi_h = __builtin_amdgcn_cvt_pkrtz(p0, p1);
           const unsigned int hi_u = __builtin_bit_cast(unsigned int, hi_h);
           ph_u[kk][r >> 1] = hi_u;
@@ -1110,9 +1149,19 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
           if constexpr (H3) vfl[s] = ql[s];
           continue;
         }
+        if constexpr (PF > 0) {
+          vfh[s] = pvh[kk][s];
+          if constexpr (H3) vfl[s] = pvl[kk][s];
+          continue;
+        }
         const int vpos = l31 * KT2 + 8 * ((4 * kk + 2 * s + lh) ^ ((l31 >> 1) & 7));
         vfh[s] = *reinterpret_cast<const h16x8*>(Vth[buf] + vpos);
         if constexpr (H3) vfl[s] = *reinterpret_cast<const h16x8*>(Vtl[buf] + vpos);
+        if constexpr (ABL & 8) {
+          const h16x8 d0 = *reinterpret_cast<const volatile h16x8*>(Vth[buf ^ 1] + vpos);
+          const h16x8 d1 = *reinterpret_cast<const volatile h16x8*>(Vtl[buf ^ 1] + vpos);
+          asm volatile("" ::"v"(d0), "v"(d1));
+        }
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -1154,6 +1203,7 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
     __builtin_amdgcn_sched_barrier(0);
     if (more) stash(buf ^ 1);
     if constexpr (!(ABL & 4)) __syncthreads();
+    if constexpr (ABL & 32) __syncthreads();
   }
   if (kt < klen) tile(kt, buf, std::true_type{});
 
@@ -1330,10 +1380,11 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
     if (abl != 0 && mode == 1) {
       switch (abl) {
         case 1: SPR_ATTN_SA(1); break;
-        case 2: SPR_ATTN_SA(2); break;
-        case 3: SPR_ATTN_SA(3); break;
         case 4: SPR_ATTN_SA(4); break;
-        case 6: SPR_ATTN_SA(6); break;
+        case 8: SPR_ATTN_SA(8); break;
+        case 16: SPR_ATTN_SA(16); break;
+        case 32: SPR_ATTN_SA(32); break;
+        case 64: SPR_ATTN_SA(64); break;
         default: SPR_ATTN_SA(7); break;
       }
       SPR_LAUNCH_CHECK();
@@ -1341,6 +1392,17 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
     }
 #undef SPR_ATTN_SA
 #endif
+    static const int pf = [] { const char* e = getenv("SPR_ATTN_PF"); return e != nullptr ? atoi(e) : 0; }();
+    if (pf > 0 && (mode == 1 || mode == 3)) {
+      if (mode == 1)
+        hipLaunchKernelGGL((k_attn_s<true, true, 3, 2, 0, false, 1>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl,
+                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
+      else
+        hipLaunchKernelGGL((k_attn_s<true, false, 3, 2, 0, false, 1>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl,
+                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
+      SPR_LAUNCH_CHECK();
+      return 0;
+    }
     if (mode == 4) {
       hipLaunchKernelGGL((k_attn_s<true, true, 4, 2, 0, true>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
                          pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
