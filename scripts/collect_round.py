@@ -26,6 +26,9 @@ shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 if glob.glob(f"{src}/stats_attn2/*/*kernel_stats.csv"):
     shutil.copy(newest(f"{src}/stats_attn2/*/*kernel_stats.csv"), f"profiles/{tag}_attn_mode2_kernel_stats.csv")
     shutil.copy(f"{src}/bench_attn2_under_rocprof.json", f"profiles/{tag}_attn_mode2_bench_under_rocprof.json")
+if glob.glob(f"{src}/stats_attn3/*/*kernel_stats.csv"):
+    shutil.copy(newest(f"{src}/stats_attn3/*/*kernel_stats.csv"), f"profiles/{tag}_attn_mode3_kernel_stats.csv")
+    shutil.copy(f"{src}/bench_attn3_under_rocprof.json", f"profiles/{tag}_attn_mode3_bench_under_rocprof.json")
 
 
 def per_kernel(path, counter):
