@@ -106,6 +106,13 @@ int spr_radius_table_build(const float* s_xyz, const int* s_cu, int ns, int nb, 
 int spr_radius_table_query(const float* q_xyz, const int* q_cu, int nq, int self, int ns, int nb,
                            float radius, int limit, int slot, const void* table, int* out_idx,
                            int* max_count, void* ws, size_t ws_bytes, void* stream);
+/* Round 5: the same with the K-nearest selection chosen by the caller -- algo 0: one thread per query (cell scan into
+ * a scratch row + rank sort in registers; cheaper for sparse rows), algo 1: one wave per query (one pass over the
+ * coalesced record runs, the row kept sorted in the wave's registers, no scratch, no sort kernel; faster when more
+ * supports lie in range than `limit`: LiDAR-shaped clouds).  Identical rows. */
+int spr_radius_table_query_a(const float* q_xyz, const int* q_cu, int nq, int self, int ns, int nb,
+                             float radius, int limit, int slot, const void* table, int* out_idx,
+                             int* max_count, int algo, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a4: KPConv forward ---------------------------------------------------
  * Replaces KPConv.forward(q_pts, s_pts, neighb_inds, x)

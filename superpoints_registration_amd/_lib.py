@@ -34,6 +34,7 @@ SIGNATURES = {
     "spr_radius_table_slots": (_i, []),
     "spr_radius_table_build": (_i, [_vp, _vp, _i, _i, _f, _vp, _sz, _vp, _sz, _vp]),
     "spr_radius_table_query": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "spr_radius_table_query_a": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "spr_kpconv_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "spr_kpconv_fwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _f, _vp,
                             _i, _vp, _sz, _vp]),

@@ -647,6 +647,152 @@ __global__ __launch_bounds__(BLOCK) void k_sort_rows(const unsigned long long* _
 // profile came from (150 us alone).  Every index into the key array is a compile-time constant (the loops are fully
 // unrolled; a wave leaves both loops at its longest row through wave-uniform branches), so the array lives in VGPRs.
 // Results are those of k_sort_rows, entry for entry.
+// ---------------------------------------------------------------------------------------------------
+// Round 5: one-pass K-nearest selection, one WAVE per query (neighbors.cpp:272-327 semantics).
+// k_scan_table + k_sort_rows(_reg) give every query a thread: the 64 lanes of a wave stream 64 different record
+// runs (one 128-byte line per lane and load for a 16-byte record unless neighbouring queries share cells), append
+// to a slot-major scratch in global memory, and a dense row (LiDAR ground: 100-150 supports in range against a
+// limit of ~40) pays a second scan.  Here the lanes of a wave take 64 CONSECUTIVE candidate records of one query
+// (the nine x-runs of its 3 x 3 x 3 cells as one sequence: coalesced 1-KiB loads), and the row lives in the wave's
+// registers, sorted by (d2, index), one entry per lane (two for limits > 64):
+//   per batch: in-range candidates are ranked against the row and each other by ballots -- for each accepted
+//   candidate j (wave-uniform loop over the ballot's set bits): rank_j = #{row entries < key_j} + #{accepted < key_j},
+//   and every row entry counts the accepted keys below it -- and the union is written through 1 KiB of LDS per wave
+//   into its new order, cut at `limit`.  Once the row is full only candidates below its last entry are accepted, so
+//   a dense row costs a few ranks per batch, never a second pass.  No scratch, no sort kernel.
+// Queries are handed out in chunks of consecutive indices (device counter): a wave's successive queries of a self
+// search are neighbours in cell order and re-read the same record lines.
+// Rows are bit for bit those of k_scan_table + k_sort_rows: same keys, same total order, same cut.
+constexpr int kKnnChunk = 16;
+
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l);
+  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(256) void k_knn_wave(
+    const float* __restrict__ q_xyz, const int* __restrict__ q_cu, int nq, int nb,
+    const GridCloud* __restrict__ info, const int* __restrict__ start, const float4* __restrict__ rec,
+    const int* __restrict__ err, float r2, float inv_cell, int limit, int self, int ns, int* __restrict__ out,
+    int* max_count, int* q_ctr) {
+  __shared__ unsigned long long s_key[4][128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (*err) return;
+  unsigned long long* sk = s_key[wave];
+  constexpr unsigned long long kNone = ~0ull;
+  int cl_lo = 0, cl_hi = 0;          // query range of the cached cloud
+  GridCloud g = info[0];
+  int wave_max = 0;
+  for (;;) {
+    int c0 = 0;
+    if (lane == 0) c0 = atomicAdd(q_ctr, kKnnChunk);
+    c0 = __builtin_amdgcn_readfirstlane(c0);
+    if (c0 >= nq) break;
+    const int c1 = min(c0 + kKnnChunk, nq);
+    for (int t = c0; t < c1; ++t) {
+      if (t < cl_lo || t >= cl_hi) {      // wave uniform
+        const int c = find_segment(q_cu, nb, t);
+        cl_lo = q_cu[c];
+        cl_hi = q_cu[c + 1];
+        g = info[c];
+      }
+      int qi = t;
+      float qx, qy, qz;
+      if (self) {                         // the query IS record t (cell order)
+        const float4 me = rec[t];
+        qi = __float_as_int(me.w);
+        qx = me.x, qy = me.y, qz = me.z;
+      } else {
+        qx = q_xyz[3 * (size_t)t + 0], qy = q_xyz[3 * (size_t)t + 1], qz = q_xyz[3 * (size_t)t + 2];
+      }
+      const int cx = cell_coord(qx, g.mn[0], inv_cell);
+      const int cy = cell_coord(qy, g.mn[1], inv_cell);
+      const int cz = cell_coord(qz, g.mn[2], inv_cell);
+      const int xlo = max(cx - 1, 0), xhi = min(cx + 1, g.dim[0] - 1);
+      // lane k < 9: record run k (the x-cells xlo..xhi of one (y, z) row of the neighbourhood)
+      int rb = 0, re = 0;
+      if (lane < 9) {
+        const int z = cz + lane / 3 - 1, y = cy + lane % 3 - 1;
+        const bool in = xlo <= xhi && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
+        if (in) {
+          rb = start[grid_cell(g, xlo, y, z)];
+          re = start[grid_cell(g, xhi, y, z) + 1];
+        }
+      }
+      // exclusive prefix of the run lengths over lanes 0..8
+      const int len = re - rb;
+      int pre = len;
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const int v = __shfl_up(pre, o, 64);
+        if (lane >= o) pre += v;
+      }
+      const int n_c = __builtin_amdgcn_readlane(pre, 8);
+      const int ex = pre - len;
+      int roff[9], rdel[9];               // SGPRs: first candidate index of run k, record index - candidate index
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        roff[k] = __builtin_amdgcn_readlane(ex, k);
+        rdel[k] = __builtin_amdgcn_readlane(rb, k) - roff[k];
+      }
+      unsigned long long lk0 = kNone, lk1 = kNone;   // the row: rank `lane` (and 64 + lane)
+      int cnt = 0, total = 0;
+      for (int base = 0; base < n_c; base += 64) {
+        const int ci = base + lane;
+        const bool valid = ci < n_c;
+        int d = rdel[0];
+#pragma unroll
+        for (int k = 1; k < 9; ++k) d = ci >= roff[k] ? rdel[k] : d;     // runs of length 0 are skipped over
+        const float4 sp = rec[valid ? ci + d : 0];
+        // nanoflann.hpp:432-440: diff = query - support; result += diff*diff
+        const float dx = __fsub_rn(qx, sp.x), dy = __fsub_rn(qy, sp.y), dz = __fsub_rn(qz, sp.z);
+        float d2 = __fmul_rn(dx, dx);
+        d2 = __fadd_rn(d2, __fmul_rn(dy, dy));
+        d2 = __fadd_rn(d2, __fmul_rn(dz, dz));
+        bool in = valid && d2 < r2;       // strict, nanoflann.hpp:249
+        const unsigned long long key = nbr_key(d2, __float_as_int(sp.w));
+        unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+        total += __popcll(m);
+        if (cnt == limit) {               // full: only what beats the current last entry can enter
+          const unsigned long long worst = (!BIG || limit <= 64) ? readlane_u64(lk0, limit - 1) : readlane_u64(lk1, limit - 65);
+          in = in && key < worst;
+          m = __builtin_amdgcn_ballot_w64(in);
+        }
+        if (m == 0) continue;
+        int sh0 = 0, sh1 = 0, myrank = 0;
+        for (unsigned long long mm = m; mm != 0; mm &= mm - 1) {
+          const int jl = __builtin_ctzll(mm);
+          const unsigned long long kj = readlane_u64(key, jl);
+          int nl = __popcll(__builtin_amdgcn_ballot_w64(lk0 < kj));     // empty slots hold ~0: never below
+          sh0 += kj < lk0 ? 1 : 0;
+          if (BIG) {
+            nl += __popcll(__builtin_amdgcn_ballot_w64(lk1 < kj));
+            sh1 += kj < lk1 ? 1 : 0;
+          }
+          nl += __popcll(__builtin_amdgcn_ballot_w64(in && key < kj));
+          if (lane == jl) myrank = nl;
+        }
+        // the union in its new order (ranks are distinct: keys carry the support index), cut at `limit`
+        if (lk0 != kNone && lane + sh0 < limit) sk[lane + sh0] = lk0;
+        if (BIG && lk1 != kNone && 64 + lane + sh1 < limit) sk[64 + lane + sh1] = lk1;
+        if (in && myrank < limit) sk[myrank] = key;
+        cnt = min(cnt + (int)__popcll(m), limit);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lk0 = lane < cnt ? sk[lane] : kNone;
+        if (BIG) lk1 = 64 + lane < cnt ? sk[64 + lane] : kNone;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      int* row = out + (size_t)qi * limit;
+      if (lane < limit) row[lane] = lane < cnt ? (int)(unsigned)lk0 : ns;
+      if (BIG && 64 + lane < limit) row[64 + lane] = 64 + lane < cnt ? (int)(unsigned)lk1 : ns;
+      wave_max = max(wave_max, total);
+    }
+  }
+  if (lane == 0 && wave_max > 0 && wave_max > *reinterpret_cast<volatile int*>(max_count)) atomicMax(max_count, wave_max);
+}
+
 // f(integral_constant<int, I>) for I = B .. E-1: every index is a compile-time constant in the callee (a plain
 // `#pragma unroll` nest of 64 x 64 iterations is not unrolled by the compiler: the key array then went to scratch)
 template <int B, int E, class F>
@@ -769,9 +915,11 @@ int table_build(const float* s_xyz, const int* s_cu, int ns, int nb, float radiu
   return 0;
 }
 
+// algo: 0 = thread per query (k_scan_table + rank sort), 1 = wave per query (k_knn_wave), -1 = the library's default
+// (0, or 1 under SPR_NBR_ALGO=wave).  Rows are identical either way.
 int table_query(const float* q_xyz, const int* q_cu, int nq, int self, int ns, int nb, float radius, int limit,
                 int slot, const void* blob, int* out_idx, int* max_count, void* ws, size_t ws_bytes,
-                hipStream_t stream) {
+                hipStream_t stream, int algo = -1) {
   const TableView t = table_view(const_cast<void*>(blob), ns, nb);
   Workspace w(ws, ws_bytes);
   // limits up to kRegRows: the scratch rows are capped there and sorted in registers (k_sort_rows_reg); a query with
@@ -786,6 +934,25 @@ int table_query(const float* q_xyz, const int* q_cu, int nq, int self, int ns, i
   SPR_REQUIRE(qid != nullptr, "radius query: workspace carve failed");
   const float r2 = radius * radius;  // neighbors.cpp:226 (float32)
   const float inv_cell = 1.0f / (radius * (1.0f + 1.0f / 256.0f));
+  // SPR_NBR_ALGO=wave: the one-pass wave-per-query selection (k_knn_wave) instead of scan + rank sort
+  static const int env_algo = [] {
+    const char* e = getenv("SPR_NBR_ALGO");
+    return e == nullptr ? -1 : (e[0] == 'w' ? 1 : 0);     // "wave" / "scan": force one of them (A/B)
+  }();
+  const bool knn_wave = env_algo >= 0 ? env_algo == 1 : algo == 1;
+  if (knn_wave) {
+    SPR_HIP_CHECK(hipMemsetAsync(qid, 0, sizeof(int), stream));
+    const int nblk = min(cdiv(nq, 4 * kKnnChunk), 8 * device_cu_count());
+    if (limit <= 64)
+      hipLaunchKernelGGL(k_knn_wave<false>, dim3(nblk), dim3(256), 0, stream, q_xyz, q_cu, nq, nb, t.ginfo, t.start, t.rec,
+                         t.hdr + kHdrErr, r2, inv_cell, limit, self, ns, out_idx, t.hdr + kHdrSlot0 + slot, qid);
+    else
+      hipLaunchKernelGGL(k_knn_wave<true>, dim3(nblk), dim3(256), 0, stream, q_xyz, q_cu, nq, nb, t.ginfo, t.start, t.rec,
+                         t.hdr + kHdrErr, r2, inv_cell, limit, self, ns, out_idx, t.hdr + kHdrSlot0 + slot, qid);
+    hipLaunchKernelGGL(k_nbr_err2, dim3(1), dim3(1), 0, stream, t.hdr, slot, max_count);
+    SPR_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_scan_table, dim3(cdiv(nq, 256)), dim3(256), 0, stream, q_xyz, q_cu, nq, nb, t.ginfo, t.start,
                      t.rec, t.hdr + kHdrErr, r2, inv_cell, rcap, limit, self, tmp_key, kept, qid, t.hdr + kHdrSlot0 + slot);
   if (use_reg) {
@@ -931,4 +1098,20 @@ extern "C" int spr_radius_table_query(const float* q_xyz, const int* q_cu, int n
   SPR_REQUIRE(ws != nullptr && ws_bytes >= table_query_ws_bytes(nq), "radius_table_query: workspace too small");
   return table_query(q_xyz, q_cu, nq, self ? 1 : 0, ns, nb, radius, limit, slot, table, out_idx, max_count, ws, ws_bytes,
                      (hipStream_t)stream_);
+}
+
+// The same with the selection algorithm chosen by the caller: 0 = one thread per query (scan of its 27 cells into a
+// scratch row + rank sort in registers: the cheaper one for sparse rows), 1 = one wave per query (one pass, the row in
+// registers, no scratch: the faster one when rows are dense -- more supports in range than `limit`).
+extern "C" int spr_radius_table_query_a(const float* q_xyz, const int* q_cu, int nq, int self, int ns, int nb,
+                                        float radius, int limit, int slot, const void* table, int* out_idx,
+                                        int* max_count, int algo, void* ws, size_t ws_bytes, void* stream_) {
+  SPR_REQUIRE(q_xyz && q_cu && table && out_idx && max_count && nq > 0 && ns > 0 && nb >= 1, "radius_table_query: bad arguments");
+  SPR_REQUIRE(limit >= 1 && limit <= 128, "radius_table_query: limit must be in [1,128], got %d", limit);
+  SPR_REQUIRE(slot >= 0 && slot < kTableSlots, "radius_table_query: slot out of range");
+  SPR_REQUIRE(!self || nq == ns, "radius_table_query: a self search has nq == ns");
+  SPR_REQUIRE(algo == 0 || algo == 1, "radius_table_query: algo must be 0 (thread per query) or 1 (wave per query)");
+  SPR_REQUIRE(ws != nullptr && ws_bytes >= table_query_ws_bytes(nq), "radius_table_query: workspace too small");
+  return table_query(q_xyz, q_cu, nq, self ? 1 : 0, ns, nb, radius, limit, slot, table, out_idx, max_count, ws, ws_bytes,
+                     (hipStream_t)stream_, algo);
 }

@@ -206,6 +206,10 @@ class Preprocessor(nn.Module):
         self.compute_upsamples = compute_upsamples
         self.order = order
         self.index_dtype = index_dtype
+        # untruncated max row count of every search of the previous forward, keyed (level, kind): a search whose
+        # rows were dense last time (more supports in range than 1.5 x the limit: LiDAR-shaped clouds) takes the
+        # wave-per-query selection, the others the thread-per-query one (ops.RadiusTable.query; identical rows)
+        self._row_counts = {}
 
     def forward(self, pts: List[torch.Tensor]):
         meta = None
@@ -254,10 +258,13 @@ class Preprocessor(nn.Module):
         # up-sampling search (radius 2 r = the next level's r) all look into the same one.
         table = [None]
 
-        def search(queries, q_cu, supports, s_cu, radius, limit):
+        def search(key, queries, q_cu, supports, s_cu, radius, limit):
             if table[0] is None or not table[0].matches(supports, s_cu, radius):
                 table[0] = ops.RadiusTable(supports, s_cu, radius)
-            return table[0].query(queries, q_cu, limit)[0]
+            prev = self._row_counts.get(key)
+            idx, m = table[0].query(queries, q_cu, limit, dense=None if prev is None else prev > 1.5 * limit)
+            self._row_counts[key] = m
+            return idx
 
         cu = ops.lengths_to_cu(lens_host, device)
         open_level(0, points, lens_host, cu)
@@ -265,7 +272,7 @@ class Preprocessor(nn.Module):
             conv = pool = up = None
             plan_ns[0] = points.shape[0]
             if lv.has_conv:
-                conv = search(points, cu, points, cu, lv.radius, lv.limit)
+                conv = search((l, 'conv'), points, cu, points, cu, lv.radius, lv.limit)
             publish('neighbors', l, conv)
             yield meta, 'conv', l
             if lv.down:
@@ -273,9 +280,9 @@ class Preprocessor(nn.Module):
                 sub_points, sub_lens = ops.grid_subsample(points, cu, dl, order=self.order)
                 sub_lens_host = sub_lens.tolist()
                 sub_cu = ops.lengths_to_cu(sub_lens_host, device)
-                pool = search(sub_points, sub_cu, points, cu, lv.radius, lv.limit)
+                pool = search((l, 'pool'), sub_points, sub_cu, points, cu, lv.radius, lv.limit)
                 if self.compute_upsamples:
-                    up = search(points, cu, sub_points, sub_cu, 2 * lv.radius, lv.limit)
+                    up = search((l, 'up'), points, cu, sub_points, sub_cu, 2 * lv.radius, lv.limit)
             publish('pools', l, pool)
             publish('upsamples', l, up)
             if lv.down:

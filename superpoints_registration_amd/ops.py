@@ -320,8 +320,11 @@ class RadiusTable:
                 and supports._version == self.supports._version and s_cu._version == self.s_cu._version
                 and self._slot < self._slots)
 
-    def query(self, queries: torch.Tensor, q_cu: torch.Tensor, limit: int) -> Tuple[torch.Tensor, int]:
-        """int32 [Nq, min(max_count, limit)] and the untruncated max count, like radius_neighbors."""
+    def query(self, queries: torch.Tensor, q_cu: torch.Tensor, limit: int,
+              dense: Optional[bool] = None) -> Tuple[torch.Tensor, int]:
+        """int32 [Nq, min(max_count, limit)] and the untruncated max count, like radius_neighbors.
+        dense: True -> one wave per query (one pass, no scratch: faster when more supports lie in range than
+        `limit`), False -> one thread per query (cheaper for sparse rows), None -> the library's default.  Same rows."""
         queries = _dev(queries, "queries", torch.float32)
         q_cu = _dev(q_cu, "q_cu", torch.int32)
         nq = queries.shape[0]
@@ -332,9 +335,15 @@ class RadiusTable:
         out = torch.empty((nq, limit), dtype=torch.int32, device=queries.device)
         mc = torch.empty((1,), dtype=torch.int32, device=queries.device)
         slot, self._slot = self._slot, self._slot + 1
-        _lib.check(L.spr_radius_table_query(_ptr(queries), _ptr(q_cu), nq, self_search, self.ns, self.nb, self.radius,
-                                            int(limit), slot, _ptr(self.blob), _ptr(out), _ptr(mc), _ptr(ws),
-                                            ws.numel(), _stream(queries)), "spr_radius_table_query")
+        if dense is None:
+            _lib.check(L.spr_radius_table_query(_ptr(queries), _ptr(q_cu), nq, self_search, self.ns, self.nb, self.radius,
+                                                int(limit), slot, _ptr(self.blob), _ptr(out), _ptr(mc), _ptr(ws),
+                                                ws.numel(), _stream(queries)), "spr_radius_table_query")
+        else:
+            _lib.check(L.spr_radius_table_query_a(_ptr(queries), _ptr(q_cu), nq, self_search, self.ns, self.nb,
+                                                  self.radius, int(limit), slot, _ptr(self.blob), _ptr(out), _ptr(mc),
+                                                  1 if dense else 0, _ptr(ws), ws.numel(), _stream(queries)),
+                       "spr_radius_table_query_a")
         m = int(mc.item())
         if m == -2:     # cell table too small for this geometry: exact same result, slower path
             return radius_neighbors(queries, self.supports, q_cu, self.s_cu, self.radius, limit, True, algo=1)

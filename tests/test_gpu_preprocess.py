@@ -318,3 +318,43 @@ def test_radius_search_with_more_than_65535_coincident_supports_in_range(device)
         inr = np.nonzero(d2[i] < np.float32(radius) ** 2)[0]
         order = inr[np.lexsort((inr, d2[i][inr]))][:limit]               # (d2, index) ascending, cut at limit
         assert np.array_equal(out[i], order), i
+
+
+@pytest.mark.parametrize("limit", [7, 40, 64, 74, 128])
+def test_wave_per_query_selection_is_the_thread_per_query_selection(device, limit):
+    """Round 5: `RadiusTable.query(dense=True)` (k_knn_wave: one wave per query, the K nearest kept sorted in the wave's
+    registers while it scans the coalesced record runs of the 27 cells -- no scratch rows, no sort kernel) must return
+    exactly the rows of the thread-per-query path (`dense=False`: k_scan_table + rank sort), which the golden tests
+    pin to the reference: self search and a search with other queries, several ragged clouds, sparse rows (a few
+    supports in range), dense rows (hundreds in range against limits from 7 to 128: every merge of a full row, both
+    row registers of limits > 64), equal distances (lattice points), a cloud of one point, and 3 000 coincident
+    supports (ties broken by the support index through hundreds of batches)."""
+    rng = np.random.default_rng(limit)
+    clouds = [rng.uniform(0, 1.0, (3000, 3)),                                  # dense: ~100-300 in range
+              rng.uniform(0, 6.0, (2500, 3)),                                  # sparse: 0-3 in range
+              np.stack(np.meshgrid(*[np.arange(12) * 0.07] * 3, indexing="ij"), -1).reshape(-1, 3),   # lattice: ties
+              np.array([[0.3, 0.3, 0.3]]),                                     # a cloud of one point
+              np.concatenate([np.tile([[0.5, 0.5, 0.5]], (3000, 1)), rng.normal(0.5, 0.05, (500, 3))])]
+    sup = np.concatenate(clouds).astype(np.float32)
+    lens = [len(c) for c in clouds]
+    qry_clouds = [c[rng.permutation(len(c))[:max(1, len(c) // 3)]] + rng.normal(0, 0.01, (max(1, len(c) // 3), 3))
+                  for c in clouds]
+    qry = np.concatenate(qry_clouds).astype(np.float32)
+    s_, q = torch.from_numpy(sup).to(device), torch.from_numpy(qry).to(device)
+    scu, qcu = ops.lengths_to_cu(lens, device), ops.lengths_to_cu([len(c) for c in qry_clouds], device)
+    radius = 0.2
+    for queries, cu in ((s_, scu), (q, qcu)):
+        t0 = ops.RadiusTable(s_, scu, radius)
+        a, ma = t0.query(queries, cu, limit, dense=False)
+        b, mb = t0.query(queries, cu, limit, dense=True)
+        assert ma == mb and a.shape == b.shape
+        assert torch.equal(a, b)
+    # ... and against a numpy brute force with the library's total order (d2, index) on the dense cloud
+    d = qry[:200, None, :] - sup[None, :lens[0], :]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    got = b[:200].cpu().numpy()
+    for i in range(200):
+        inr = np.nonzero(d2[i] < np.float32(radius) ** 2)[0]
+        order = inr[np.lexsort((inr, d2[i][inr]))][:limit]
+        assert np.array_equal(got[i, :len(order)], order), i
+        assert (got[i, len(order):] == len(sup)).all()
