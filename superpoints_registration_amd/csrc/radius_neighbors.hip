@@ -739,13 +739,25 @@ __global__ __launch_bounds__(256) void k_knn_wave(
       }
       unsigned long long lk0 = kNone, lk1 = kNone;   // the row: rank `lane` (and 64 + lane)
       int cnt = 0, total = 0;
-      for (int base = 0; base < n_c; base += 64) {
+      // record of candidate `base + lane`, loaded ONE BATCH AHEAD: the L2 latency of a batch's 1 KiB of records (1-2 us:
+      // a wave alone cannot hide it, and a dense row has seven batches) runs under the ranking of the batch before it.
+      // (A plain load: the compiler tracks it and waits at the first use in the next iteration.  An inline-asm load is
+      // wrong here -- the compiler believes the asm's output is written at once and copies the not-yet-loaded
+      // registers into the loop-carried ones.)
+      auto fetch = [&](int base) __attribute__((always_inline)) -> float4 {
         const int ci = base + lane;
-        const bool valid = ci < n_c;
         int d = rdel[0];
 #pragma unroll
         for (int k = 1; k < 9; ++k) d = ci >= roff[k] ? rdel[k] : d;     // runs of length 0 are skipped over
-        const float4 sp = rec[valid ? ci + d : 0];
+        return rec[ci < n_c ? ci + d : 0];
+      };
+      float4 sp_next = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n_c > 0) sp_next = fetch(0);
+      for (int base = 0; base < n_c; base += 64) {
+        const int ci = base + lane;
+        const bool valid = ci < n_c;
+        const float4 sp = sp_next;
+        if (base + 64 < n_c) sp_next = fetch(base + 64);
         // nanoflann.hpp:432-440: diff = query - support; result += diff*diff
         const float dx = __fsub_rn(qx, sp.x), dy = __fsub_rn(qy, sp.y), dz = __fsub_rn(qz, sp.z);
         float d2 = __fmul_rn(dx, dx);
