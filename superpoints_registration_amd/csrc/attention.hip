@@ -250,13 +250,13 @@ __device__ __forceinline__ int vstart(const int* __restrict__ cu, int s) {
 __global__ __launch_bounds__(256) void k_attn_zero_gaps(const int* __restrict__ cu, int nseg, int tp,
                                                          _Float16* __restrict__ vth,
                                                          _Float16* __restrict__ vtl) {
-  const size_t row = (size_t)blockIdx.x * tp;
+  const int f = blockIdx.x, d = gridDim.x;
   for (int s = 0; s < nseg; ++s) {
     const int beg = vstart(cu, s) + cu[s + 1] - cu[s];
     const int end = s + 1 < nseg ? vstart(cu, s + 1) : tp;
     for (int c = beg + threadIdx.x; c < end; c += 256) {
-      vth[row + attn_vperm(c)] = (_Float16)0.f;     // (a bijection inside every aligned 16-column group)
-      vtl[row + attn_vperm(c)] = (_Float16)0.f;
+      vth[attn_v_off(f, attn_vperm(c), d)] = (_Float16)0.f;     // (a bijection inside every aligned 16-column group)
+      vtl[attn_v_off(f, attn_vperm(c), d)] = (_Float16)0.f;
     }
   }
 }
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(256) void k_attn_pack(
       if (half + d < d_model) {
         const u32x2 a0 = *reinterpret_cast<const u32x2*>(Lh + d * PS + c0), a1 = *reinterpret_cast<const u32x2*>(Lh + d * PS + c0 + 8);
         const u32x2 b0 = *reinterpret_cast<const u32x2*>(Ll + d * PS + c0), b1 = *reinterpret_cast<const u32x2*>(Ll + d * PS + c0 + 8);
-        *reinterpret_cast<u32x4*>(vth + (size_t)(half + d) * tp + col0 + ch) = (u32x4){a0[0], a0[1], a1[0], a1[1]};
-        *reinterpret_cast<u32x4*>(vtl + (size_t)(half + d) * tp + col0 + ch) = (u32x4){b0[0], b0[1], b1[0], b1[1]};
+        *reinterpret_cast<u32x4*>(vth + attn_v_off(half + d, col0 + ch, d_model)) = (u32x4){a0[0], a0[1], a1[0], a1[1]};
+        *reinterpret_cast<u32x4*>(vtl + attn_v_off(half + d, col0 + ch, d_model)) = (u32x4){b0[0], b0[1], b1[0], b1[1]};
       }
     }
   }
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, WPS) void k_attn_h3(
   u32x4 rkh, rkl, rvh, rvl;
   auto fetch = [&](int kt) {
     const size_t krow = ((size_t)head * t_total + kbeg + min(kt + skr, klen - 1)) * HD + skc;
-    const size_t vrow = (size_t)(hoff + svr) * tp + vbeg + kt + svc;
+    const size_t vrow = attn_v_off(hoff + svr, (size_t)(vbeg + kt + svc), nhead * HD);
     const _Float16 *a = kh_g + krow, *b = kl_g + krow, *c = vth_g + vrow, *d = vtl_g + vrow;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rkh) : "v"(a));
     if constexpr (H3) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rkl) : "v"(b));
@@ -870,7 +870,8 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
     const _Float16* __restrict__ kh_g, const _Float16* __restrict__ kl_g,
     const _Float16* __restrict__ vth_g, const _Float16* __restrict__ vtl_g, int t_total, int tp,
     const int* __restrict__ cu, const int* __restrict__ kv_seg, int nseg, int nhead,
-    const float* __restrict__ scales, float* __restrict__ out, int o_stride, float* __restrict__ lse_out) {
+    const float* __restrict__ scales, float* __restrict__ out, int o_stride, float* __restrict__ lse_out,
+    const int* __restrict__ o_tiles) {
   static_assert(H3 || !PLO, "a lo plane of P only with split operands");
   static_assert(!ADAPT || (H3 && PLO), "the adaptive form is a refinement of the split form");
   // K tiles arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write): the image is lane-linear,
@@ -945,7 +946,7 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
   auto fetch = [&](int kt, int nbuf) {     // nbuf: the buffer tile kt will be read from
     if constexpr (ABL & 2) return;
     const unsigned koff = (unsigned)((((size_t)head * t_total + kbeg + min(kt + skr, klen - 1)) * HD + skc) * 2);
-    const unsigned voff = (unsigned)(((size_t)(hoff + svr) * tp + vbeg + kt + svc) * 2);
+    const unsigned voff = (unsigned)(attn_v_off(hoff + svr, (size_t)(vbeg + kt + svc), nhead * HD) * 2);
     dma16(kh_g, koff, kdst_h + (unsigned)nbuf * 4096u);
     if constexpr (H3) dma16(kl_g, koff, kdst_l + (unsigned)nbuf * 4096u);
     dma16(vth_g, voff, vdst_h + (unsigned)nbuf * 4096u);
@@ -1213,7 +1214,24 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
   // log2 sum_j 2^(s_ij): handed to the backward (training), as k_attn_h3's lazy form does
   if (lse_out != nullptr && qi < qlen && lh == 0)
     lse_out[(size_t)(qbeg + qi) * nhead + head] = __builtin_amdgcn_logf(l_run) - negm[0];
-  if (qi < qlen) {
+  if (o_tiles != nullptr) {
+    // Tiled output for the fused row chains (xenc.hip, "tiled token tensors"): this workgroup's 128 queries are chain tile
+    // o_tiles[seg] + qt, the wave's 32 queries one 32 KiB wave block of it, and the lane's four features 8 g + 4 lh .. + 3
+    // of head `head` are the 16-byte piece (4 head + g, lane) of that block -- what the chain's lane (token l31, half lh)
+    // loads with ONE coalesced instruction per piece.  Every lane stores (rows past the cloud's end hold the clamped last
+    // query's finite values: the chain computes on them and drops them).
+    const float inv = (l_run > 0.f ? 1.0f / l_run : 0.f) * scales[3];
+    float4* op = reinterpret_cast<float4*>(out) + ((size_t)(o_tiles[seg] + qt) * 4 + wave) * 2048 + lane;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 w4;
+      w4.x = o[4 * g + 0] * inv;
+      w4.y = o[4 * g + 1] * inv;
+      w4.z = o[4 * g + 2] * inv;
+      w4.w = o[4 * g + 3] * inv;
+      op[(4 * head + g) * 64] = w4;
+    }
+  } else if (qi < qlen) {
     const float inv = (l_run > 0.f ? 1.0f / l_run : 0.f) * scales[3];   // 2^-ev undoes the V multiplier
     float* op = out + (size_t)(qbeg + qi) * o_stride + hoff;
 #pragma unroll
@@ -1355,7 +1373,7 @@ bool attn_core_writes_lse(int mode) { return mode != 0 && (env_attn_nq() == 1 ||
 
 int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int* kv_seg, int nseg,
                 int max_len_host, int nhead, float* out, int o_stride, int mode, hipStream_t stream,
-                float* lse_out = nullptr) {
+                float* lse_out = nullptr, const int* o_tiles = nullptr) {
   ProfScope prof(stream, -1, t);
   // Default since round 4: 32 queries per wave with a 168-register budget, three waves per SIMD (147 VGPRs in split
   // mode): 927 vs 956 us per call at the bench shape, 452 vs 458 us in mode 2.  SPR_ATTN_NQ=2 selects the 64-query /
@@ -1371,12 +1389,12 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
     dim3 grid1(cdiv(max_len_host, QB2 / 2) * nhead * nseg);
 #define SPR_ATTN_S(H3_, PLO_, PR_)                                                                                   \
     hipLaunchKernelGGL((k_attn_s<H3_, PLO_, 3, PR_>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth, \
-                       pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out)
+                       pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles)
 #ifdef SPR_ATTN_ABLATE
     static const int abl = [] { const char* e = getenv("SPR_ATTN_ABL"); return e != nullptr ? atoi(e) : 0; }();
 #define SPR_ATTN_SA(A_)                                                                                               \
     hipLaunchKernelGGL((k_attn_s<true, true, 3, 2, A_>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth, \
-                       pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out)
+                       pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles)
     if (abl != 0 && mode == 1) {
       switch (abl) {
         case 1: SPR_ATTN_SA(1); break;
@@ -1396,16 +1414,16 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
     if (pf > 0 && (mode == 1 || mode == 3)) {
       if (mode == 1)
         hipLaunchKernelGGL((k_attn_s<true, true, 3, 2, 0, false, 1>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl,
-                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
+                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles);
       else
         hipLaunchKernelGGL((k_attn_s<true, false, 3, 2, 0, false, 1>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl,
-                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
+                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles);
       SPR_LAUNCH_CHECK();
       return 0;
     }
     if (mode == 4) {
       hipLaunchKernelGGL((k_attn_s<true, true, 4, 2, 0, true>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
-                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out);
+                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles);
     } else if (prio > 0) {
       if (mode == 2) SPR_ATTN_S(false, false, 2);
       else if (mode == 3) SPR_ATTN_S(true, false, 2);
@@ -1419,6 +1437,7 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
     SPR_LAUNCH_CHECK();
     return 0;
   }
+  SPR_REQUIRE(o_tiles == nullptr, "attention core: tiled output needs the k_attn_s core (attn_core_tiled_ok)");
   if (nq == 1) {
     dim3 grid1(cdiv(max_len_host, QB2 / 2) * nhead * nseg);
     // experiment switch (profiles/r04_attn_counters.txt): the same kernel compiled for FOUR waves per SIMD
@@ -1697,12 +1716,18 @@ int spr::attn_zero_gaps(const AttnPlanes& pl, int d, hipStream_t stream) {
   SPR_LAUNCH_CHECK();
   return 0;
 }
+// does launch_core() pick k_attn_s (the only core that can write the chains' tiled output) for `mode`?
+bool spr::attn_core_tiled_ok(int mode) {
+  static const bool core_h3 = [] { const char* e = getenv("SPR_ATTN_CORE"); return e != nullptr && e[0] == 'h'; }();
+  return mode >= 3 || ((mode == 1 || mode == 2) && env_attn_nq() == 1 && !core_h3);
+}
 int spr::attn_core_on_planes(const AttnPlanes& pl, const int* kv_seg, int max_len_host, int nhead, float* out,
-                             int o_stride, int mode, hipStream_t stream) {
+                             int o_stride, int mode, hipStream_t stream, const int* o_tiles) {
   SPR_REQUIRE(mode >= 1 && mode <= 4, "attention core on planes: mode must be 1 .. 4 (got %d)", mode);
   SPR_REQUIRE((long)cdiv(max_len_host, QB2 / 2) * nhead * pl.nseg < (1l << 31), "attention: grid too large");
+  SPR_REQUIRE(o_tiles == nullptr || (nhead == 8 && attn_core_tiled_ok(mode)), "attention core: tiled output unavailable");
   return launch_core(pl, pl.t_total, (size_t)pl.tp, pl.cu, kv_seg, pl.nseg, max_len_host, nhead, out, o_stride, mode,
-                     stream);
+                     stream, nullptr, o_tiles);
 }
 
 extern "C" int spr_set_attn_mode(int mode) {

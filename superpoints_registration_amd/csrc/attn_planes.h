@@ -14,10 +14,16 @@ __host__ __device__ inline int attn_vstart_of(int cu_s, int s) { return (cu_s + 
 // core stages V^T tiles by LDS-DMA (16-byte pieces cannot be permuted on the way) and reads a fragment with one
 // ds_read_b128.  attn_vperm(column) = where a token column lives.
 __host__ __device__ inline int attn_vperm(int col) { return (col & ~15) | (col & 3) | ((col & 4) << 1) | ((col & 8) >> 1); }
+// Round 5: the "transposed" V planes are stored BLOCKED, [16-column group][feature][16 columns]: element (feature f,
+// plane column c) of a plane with d features lives at ((c >> 4) d + f) 16 + (c & 15).  One head's 32 features of one
+// 16-column group are 1 KiB contiguous -- the unit a wave of the fused chains writes with ONE coalesced store
+// instruction (lane = (feature, 8 of the 16 columns), 16 bytes each; with row-major [feature][column] planes the same
+// instruction touched 32 cache lines) -- and a 64-key tile of one head is four such blocks for the attention core's DMA.
+__host__ __device__ inline size_t attn_v_off(int f, size_t col, int d) { return ((col >> 4) * (size_t)d + f) * 16 + (col & 15); }
 
 struct AttnPlanes {
   _Float16 *qh, *ql, *kh, *kl;   // [nhead][T][32] head-major, Q pre-scaled by log2(e)/sqrt(d)
-  _Float16 *vth, *vtl;           // [nhead*32][tp] transposed
+  _Float16 *vth, *vtl;           // [tp/16][nhead*32][16] blocked transposed (attn_v_off)
   const int* cu;                 // [nseg + 1]
   int nseg, t_total, tp;
   // device [4]: multipliers applied when the planes are written -- [0] Q: log2(e)/sqrt(d) * 2^-ek,
@@ -33,8 +39,11 @@ struct AttnPlanes {
 size_t attn_tp(int t, int nseg);
 int attn_carve_planes(void* ws, size_t ws_bytes, int t, int nseg, int d, AttnPlanes& pl);
 int attn_zero_gaps(const AttnPlanes& pl, int d, hipStream_t stream);
+// o_tiles != nullptr: `out` is a TILED token tensor of the fused chains (xenc.hip; o_tiles[s] = chain tiles in front
+// of segment s); only where attn_core_tiled_ok(mode).
 int attn_core_on_planes(const AttnPlanes& pl, const int* kv_seg, int max_len_host, int nhead, float* out,
-                        int o_stride, int mode, hipStream_t stream);
+                        int o_stride, int mode, hipStream_t stream, const int* o_tiles = nullptr);
+bool attn_core_tiled_ok(int mode);
 int attn_mode();   // 1 split-fp16, 0 exact f32, 2 single-pass fp16
 
 // Split-fp16 GEMM  planes <- x [m, k] . w [n, k]^T + bias  for the n output

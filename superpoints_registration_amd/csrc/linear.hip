@@ -383,11 +383,11 @@ __global__ __launch_bounds__(WM* WN * 64) void k_gemm_nt_h3(
             unsigned int hu, lu;
             split_pk_s(a, b, pmul, hu, lu);
             const f16x2 hh = __builtin_bit_cast(f16x2, hu), ll = __builtin_bit_cast(f16x2, lu);
-            const size_t o = (size_t)(fg + d) * pl.tp + vcol;
+            const size_t o = attn_v_off(fg + d, (size_t)vcol, 256);     // blocked planes: the next feature is 16 halves on
             pl.vth[o] = hh[0];
-            pl.vth[o + pl.tp] = hh[1];
+            pl.vth[o + 16] = hh[1];
             pl.vtl[o] = ll[0];
-            pl.vtl[o + pl.tp] = ll[1];
+            pl.vtl[o + 16] = ll[1];
           }
         } else {
           _Float16* ph = which == 0 ? pl.qh : pl.kh;

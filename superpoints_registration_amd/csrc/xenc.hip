@@ -31,6 +31,17 @@
 // s_barrier per chunk.  A fragment is one conflict-free ds_read_b128 per lane and feeds three MFMAs
 // (al.bh + ah.bl + ah.bh, the split-fp16 product of spr_common.h).
 //
+// Token tensors between the kernels of one forward are TILED (round 5).  With token = lane, a row-major [T, 256] f32
+// tensor is read 16 bytes per lane at a 1-KiB lane stride: 32 cache lines per instruction, which one CU's vector-memory
+// path serves at ~14 bytes per cycle -- 9 400 cycles per 128-KiB tile tensor, six to eight of them per tile, all exposed
+// (one wave per SIMD), a quarter of the chain's time.  So every tensor that only the chains and the attention core touch
+// -- the residual stream x, the attention output o, a copy of the positional embedding -- is kept as
+//   [chain tile][wave][piece k = 0..31][lane] x 16 bytes,   piece k of lane (token r, half h) = features 8 k + 4 h .. + 3
+// i.e. exactly the registers of load_c() in the order the lanes hold them: every load and store is one fully coalesced
+// 1-KiB wave instruction.  The prologue converts x and pos once; the attention core writes o in this form itself
+// (k_attn_s, o_tiles); only the stack's input and its final output are row-major.  Rows past a cloud's end are computed
+// and stored like any other (they start as copies of the cloud's last row and are never read back as tokens).
+//
 // Operand scales are STATIC: every tensor inside a chain has a data-independent bound
 //   |LayerNorm(x)| <= sqrt(d - 1) max|gamma| + max|beta|,   |x W^T + b| <= bound(x) max_row ||W||_1 + max|b|,
 //   |attention output| <= bound(V),   |pos| <= pos_bound
@@ -132,6 +143,31 @@ __device__ __forceinline__ void store_c(float* __restrict__ dst, int tok, int h,
     for (int g = 0; g < 4; ++g) {
       const f32x4 t = {v[b][4 * g + 0], v[b][4 * g + 1], v[b][4 * g + 2], v[b][4 * g + 3]};
       *reinterpret_cast<f32x4*>(p + 32 * b + 8 * g) = t;
+    }
+}
+// the same registers from / to a TILED tensor: wb4 = float4 index of the wave's 32-KiB block
+constexpr size_t XWAVE4 = 2048;    // float4s per wave block (32 tokens x 256 features)
+__device__ __forceinline__ void load_t(const float* src, size_t wb4, int lane, f32x16 (&v)[8]) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(src) + wb4 + lane;
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 t = p[(4 * b + g) * 64];
+      v[b][4 * g + 0] = t[0];
+      v[b][4 * g + 1] = t[1];
+      v[b][4 * g + 2] = t[2];
+      v[b][4 * g + 3] = t[3];
+    }
+}
+__device__ __forceinline__ void store_t(float* dst, size_t wb4, int lane, const f32x16 (&v)[8]) {
+  f32x4* p = reinterpret_cast<f32x4*>(dst) + wb4 + lane;
+#pragma unroll
+  for (int b = 0; b < 8; ++b)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 t = {v[b][4 * g + 0], v[b][4 * g + 1], v[b][4 * g + 2], v[b][4 * g + 3]};
+      p[(4 * b + g) * 64] = t;
     }
 }
 // per-feature table (in LDS) in the same shape: t[g] = table[32 b + 8 g + 4 h .. + 3]
@@ -240,10 +276,15 @@ __device__ unsigned long long g_xenc_stamps[64 * 64];
 #endif
 
 // TAIL: 0 = x_out only, 1 = LayerNorm -> ln_out (final norm), 2 = LayerNorm + pos -> in-projection -> planes
+// Layouts: HEAD chains read x_g TILED and o_g tiled (o_tiled) or row-major; the prologue (!HEAD) reads x_g and pos_g
+// row-major and writes their tiled copies to xo_g and pos_t; xo_g is tiled unless TAIL == 0 (then it is the stack's
+// row-major output); pos_t is read by every HEAD chain with an in-projection tail; ln_g is row-major.
 template <bool HEAD, bool FFN, int TAIL>
 __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const float* o_g, const float* x_g, float* xo_g,
-                                                       const float* pos_g, float* ln_g, AttnPlanes pl, int T,
-                                                       int ntiles, int* tile_ctr, const int* __restrict__ tfirst_g, int stamp_on) {
+                                                       const float* pos_g, float* pos_t, float* ln_g, AttnPlanes pl, int T,
+                                                       int ntiles, int* tile_ctr, const int* __restrict__ tfirst_g,
+                                                       int o_tiled, int stamp_on) {
+  constexpr bool XO_TILED = TAIL != 0;
   extern __shared__ __align__(16) unsigned char ring[];
   float* tab = reinterpret_cast<float*>(ring + XSLOTS * XCHUNK);
   const int d_ff = 32 * c.nf;
@@ -418,6 +459,7 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
     const bool valid = tok < seg_end;
     const bool wave_valid = tok_w < seg_end;               // lane 0 of the wave is valid: its stores do issue
     const int tokc = valid ? tok : seg_end - 1;
+    const size_t wb4 = ((size_t)tile * 4 + wave) * XWAVE4;       // the wave's block of the tiled tensors
     (void)T;
     f32x16 v[8];
     f16x8 ph[16], pw[16];
@@ -426,7 +468,8 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
 
     if constexpr (HEAD) {
       // ---- x' = o Wo^T + bo + x ------------------------------------------------------------------
-      load_c(o_g, tokc, h, v);
+      if (o_tiled) load_t(o_g, wb4, lane, v);
+      else load_c(o_g, tokc, h, v);
 #pragma unroll
       for (int b = 0; b < 8; ++b) split_block(v[b], c.o_scale, ph[2 * b], pw[2 * b], ph[2 * b + 1], pw[2 * b + 1]);
 #pragma unroll
@@ -442,16 +485,22 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
       XSTAMP(3);
       {
         f32x16 t_x[8];
-        load_c(x_g, tokc, h, t_x);
+        load_t(x_g, wb4, lane, t_x);
 #pragma unroll
         for (int b = 0; b < 8; ++b)
 #pragma unroll
           for (int e = 0; e < 16; ++e) v[b][e] = v[b][e] * c.un_o + t_x[b][e];
       }
-      store_c(xo_g, tok, h, valid, v);      // the new residual stream (FFN: parked there, re-read behind the loop)
+      // the new residual stream (FFN: parked there, re-read behind the loop)
+      if constexpr (XO_TILED) store_t(xo_g, wb4, lane, v);
+      else store_c(xo_g, tok, h, valid, v);
+      // The 32 stores are younger than every DMA piece in flight (the wait for x just drained the ring): the first
+      // acquire of the feed-forward loop would otherwise wait for them as well.
+      if constexpr (FFN) s_cnt += 32;
       XSTAMP(4);
     } else {
       load_c(x_g, tokc, h, v);
+      store_t(xo_g, wb4, lane, v);          // prologue: the tiled copy of x the chains read
     }
 
     if constexpr (FFN) {
@@ -524,13 +573,15 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
       XSTAMP(8);
       {
         f32x16 t_x[8];
-        load_c(xo_g, tokc, h, t_x);                                       // x' again (this lane stored it)
+        if constexpr (XO_TILED) load_t(xo_g, wb4, lane, t_x);             // x' again (this lane stored it)
+        else load_c(xo_g, tokc, h, t_x);
 #pragma unroll
         for (int b = 0; b < 8; ++b)
 #pragma unroll
           for (int e = 0; e < 16; ++e) v[b][e] = y[b][e] * c.un_f + t_x[b][e];
       }
-      if constexpr (TAIL != 1) store_c(xo_g, tok, h, valid, v);
+      if constexpr (TAIL == 2) store_t(xo_g, wb4, lane, v);
+      if constexpr (TAIL == 0) store_c(xo_g, tok, h, valid, v);
       XSTAMP(9);
     }
 
@@ -547,7 +598,12 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
         float mean, rstd;
         ln_stats(v, c.eps_tail, mean, rstd);
         f32x16 t_p[8];
-        load_c(pos_g, tokc, h, t_p);
+        if constexpr (HEAD) {
+          load_t(pos_t, wb4, lane, t_p);
+        } else {
+          load_c(pos_g, tokc, h, t_p);
+          store_t(pos_t, wb4, lane, t_p);   // prologue: the tiled copy of the positional embedding
+        }
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
           f32x16 t = ln_block(v[b], b, h, mean, rstd, tab + T_GT, tab + T_BT);
@@ -592,6 +648,9 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
           // the wave's first 16 and {16..19, 24..27} + 4 h of its second 16 as packed pairs.  The four
           // v_permlane32_swaps per plane that used to gather 8 consecutive tokens are gone.)
         } else if (s >= 18 && s < 22) {            // stores behind the acquire of step 8 (slice 16): counted there
+#ifdef SPR_XENC_STAMP
+          if (stamp_on & 8) return;                // ablation: no plane stores (garbage results)
+#endif
           const unsigned int* src = s < 20 ? hu : lu;
           const int o4 = 4 * (s & 1);
           if constexpr (WHICH < 2) {
@@ -611,7 +670,8 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
             const int t0 = tok_w + 16 * (s & 1) + 4 * h;
             if (t0 < seg_end) {
               _Float16* pb = s < 20 ? pl.vth : pl.vtl;
-              const size_t o0 = (size_t)(head * 32 + r) * pl.tp + vcol_w + 16 * (s & 1) + 8 * h;
+              // (blocked planes, attn_v_off: the wave's instruction writes the head's 1-KiB block of this 16-column group)
+              const size_t o0 = attn_v_off(head * 32 + r, (size_t)(vcol_w + 16 * (s & 1) + 8 * h), XD);
               store16(pb + o0, (u32x4){src[o4], src[o4 + 1], src[o4 + 2], src[o4 + 3]});
             }
           }
@@ -769,8 +829,9 @@ __global__ void k_xenc_tiles(const int* __restrict__ cu, int nseg, int* __restri
 }
 
 template <bool HEAD, bool FFN, int TAIL>
-int launch_chain(const ChainConsts& c, const float* o, const float* x, float* xo, const float* pos, float* ln,
-                 const AttnPlanes& pl, int T, int* tile_ctr, const int* tfirst, hipStream_t stream) {
+int launch_chain(const ChainConsts& c, const float* o, const float* x, float* xo, const float* pos, float* pos_t,
+                 float* ln, const AttnPlanes& pl, int T, int* tile_ctr, const int* tfirst, int o_tiled,
+                 hipStream_t stream) {
   auto kern = k_xenc_chain<HEAD, FFN, TAIL>;
   const size_t lds = xenc_lds_bytes(32 * c.nf, pl.nseg);
   SPR_REQUIRE(lds + 64 <= 160 * 1024, "xenc: d_ff %d with %d segments does not fit the LDS tables", 32 * c.nf, pl.nseg);
@@ -785,11 +846,12 @@ int launch_chain(const ChainConsts& c, const float* o, const float* x, float* xo
     const char kind = !HEAD ? 'P' : (FFN ? 'B' : 'A');
     const char* et = getenv("SPR_XENC_STAMP_TAIL");      // "0", "1" or "2": additionally only that tail
     stamp_on = (e == nullptr || e[0] == kind) && (et == nullptr || et[0] - '0' == TAIL) ? 1 : 0;
-    const char* ea = getenv("SPR_XENC_ABL");             // ablation bits: 2 = no weight DMA, 4 = no barrier
-    if (ea != nullptr) stamp_on |= atoi(ea) & 6;
+    const char* ea = getenv("SPR_XENC_ABL");             // ablation bits: 2 = no weight DMA, 4 = no barrier, 8 = no plane stores
+    if (ea != nullptr) stamp_on |= atoi(ea) & 14;
   }
 #endif
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, c, o, x, xo, pos, ln, pl, T, ntiles, tile_ctr, tfirst, stamp_on);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, c, o, x, xo, pos, pos_t, ln, pl, T, ntiles, tile_ctr, tfirst,
+                     o_tiled, stamp_on);
   SPR_LAUNCH_CHECK();
   return 0;
 }
@@ -1041,9 +1103,13 @@ extern "C" int spr_xenc_debug_stamps(unsigned long long* out_host, int clear) {
 }
 #endif
 
+// bytes of one tiled token tensor: an upper bound of the tile count (tiles do not straddle clouds) x 128 KiB; a
+// row-major [t, 256] tensor (the attention output when the core cannot write tiles) fits as well
+static size_t xenc_tiled_bytes(int t, int nseg) { return (size_t)(cdiv(t, XTOK) + nseg) * XTOK * XD * sizeof(float); }
+
 extern "C" size_t spr_xenc_workspace_bytes(int t, int nseg) {
   if (t < 1 || nseg < 1) return 0;
-  return spr_attn_workspace_bytes(t, nseg, 8, 32) + 3 * align_up((size_t)t * XD * sizeof(float), 256) + 1024 +
+  return spr_attn_workspace_bytes(t, nseg, 8, 32) + 4 * xenc_tiled_bytes(t, nseg) + 1024 +
          align_up((size_t)(nseg + 1) * sizeof(int), 256);
 }
 
@@ -1069,35 +1135,40 @@ extern "C" int spr_xenc_forward(const void* plan_host, const float* x, const flo
   pl.nseg = nseg;
   pl.t_total = t;
   pl.tp = (int)attn_tp(t, nseg);
-  const size_t act = align_up((size_t)t * XD * sizeof(float), 256);
-  float* obuf = (float*)((char*)ws + planes_bytes);
-  float* xa = (float*)((char*)ws + planes_bytes + act);
-  float* xb = (float*)((char*)ws + planes_bytes + 2 * act);
-  int* ctr = (int*)((char*)ws + planes_bytes + 3 * act);      // one tile counter per chain launch
+  const size_t act = xenc_tiled_bytes(t, nseg);
+  SPR_REQUIRE(act < (1ull << 32), "xenc_forward: too many tokens");
+  float* obuf = (float*)((char*)ws + planes_bytes);            // attention output (tiled when the core can write tiles)
+  float* xa = (float*)((char*)ws + planes_bytes + act);        // residual stream, tiled, ping
+  float* xb = (float*)((char*)ws + planes_bytes + 2 * act);    //                          pong
+  float* pos_t = (float*)((char*)ws + planes_bytes + 3 * act); // positional embedding, tiled
+  int* ctr = (int*)((char*)ws + planes_bytes + 4 * act);       // one tile counter per chain launch
   SPR_HIP_CHECK(hipMemsetAsync(ctr, 0, 1024, stream));
-  int* tfirst = (int*)((char*)ws + planes_bytes + 3 * act + 1024);
+  int* tfirst = (int*)((char*)ws + planes_bytes + 4 * act + 1024);
   hipLaunchKernelGGL(k_xenc_tiles, dim3(1), dim3(64), 0, stream, cu, nseg, tfirst);
   if (int rc = attn_zero_gaps(pl, XD, stream)) return rc;
   const int L = plan->n_layers;
-  if (int rc = launch_chain<false, false, 2>(plan->prologue, nullptr, x, nullptr, pos, nullptr, pl, t, ctr++, tfirst, stream)) return rc;
-  const float* cur = x;
+  const int o_tiled = attn_core_tiled_ok(mode) ? 1 : 0;
+  const int* o_tiles = o_tiled ? tfirst : nullptr;
+  // prologue: planes of layer 0's self attention + the tiled copies of x (into xb) and pos
+  if (int rc = launch_chain<false, false, 2>(plan->prologue, nullptr, x, xb, pos, pos_t, nullptr, pl, t, ctr++, tfirst, 0, stream)) return rc;
+  const float* cur = xb;
   float* nxt = xa;
   for (int l = 0; l < L; ++l) {
     pl.scales = plan->scales_self[l];
-    if (int rc = attn_core_on_planes(pl, kv_self, max_len_host, 8, obuf, XD, mode, stream)) return rc;
-    if (int rc = launch_chain<true, false, 2>(plan->a[l], obuf, cur, nxt, pos, nullptr, pl, t, ctr++, tfirst, stream)) return rc;
+    if (int rc = attn_core_on_planes(pl, kv_self, max_len_host, 8, obuf, XD, mode, stream, o_tiles)) return rc;
+    if (int rc = launch_chain<true, false, 2>(plan->a[l], obuf, cur, nxt, nullptr, pos_t, nullptr, pl, t, ctr++, tfirst, o_tiled, stream)) return rc;
     cur = nxt;
     nxt = (nxt == xa) ? xb : xa;
     pl.scales = plan->scales_cross[l];
-    if (int rc = attn_core_on_planes(pl, kv_cross, max_len_host, 8, obuf, XD, mode, stream)) return rc;
+    if (int rc = attn_core_on_planes(pl, kv_cross, max_len_host, 8, obuf, XD, mode, stream, o_tiles)) return rc;
     if (l + 1 < L) {
-      if (int rc = launch_chain<true, true, 2>(plan->b[l], obuf, cur, nxt, pos, nullptr, pl, t, ctr++, tfirst, stream)) return rc;
+      if (int rc = launch_chain<true, true, 2>(plan->b[l], obuf, cur, nxt, nullptr, pos_t, nullptr, pl, t, ctr++, tfirst, o_tiled, stream)) return rc;
       cur = nxt;
       nxt = (nxt == xa) ? xb : xa;
     } else if (plan->has_final) {
-      if (int rc = launch_chain<true, true, 1>(plan->b[l], obuf, cur, nxt, pos, out, pl, t, ctr++, tfirst, stream)) return rc;
+      if (int rc = launch_chain<true, true, 1>(plan->b[l], obuf, cur, nxt, nullptr, pos_t, out, pl, t, ctr++, tfirst, o_tiled, stream)) return rc;
     } else {
-      if (int rc = launch_chain<true, true, 0>(plan->b[l], obuf, cur, out, pos, nullptr, pl, t, ctr++, tfirst, stream)) return rc;
+      if (int rc = launch_chain<true, true, 0>(plan->b[l], obuf, cur, out, nullptr, pos_t, nullptr, pl, t, ctr++, tfirst, o_tiled, stream)) return rc;
     }
   }
   return 0;
