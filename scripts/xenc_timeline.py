@@ -51,6 +51,11 @@ for it in range(8):
             continue
         print(f"   {names[k]:28s} +{row[k] - prev:8d} cyc   (t = {row[k] - row[0]:8d})")
         prev = row[k]
+    if row[32] and it == 1:      # per-step stamps of the last F chunk (15..30) and of G(nf - 2) (32..47, end 48)
+        f = [int(row[k + 1] - row[k]) for k in range(15, 30)] + [int(row[32] - row[30])]
+        g = [int(row[k + 1] - row[k]) for k in range(32, 48)]
+        print("   steps of F(nf-1) (relu + split beside it):", f, "sum", sum(f))
+        print("   steps of G(nf-2) (no side work)         :", g, "sum", sum(g))
     if it + 1 < 64 and st[it + 1][0]:
         dt, dr = st[it + 1][0] - row[0], st[it + 1][31] - row[31]
         print(f"   tile total {dt} cyc = {dr / 100.0:.1f} us  ({dt / max(dr, 1) / 10.0:.2f} GHz)")

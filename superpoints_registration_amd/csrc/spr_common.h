@@ -168,6 +168,21 @@ __device__ __forceinline__ void split_pk_s(float a, float b, float s, unsigned i
       : "v"(hi_u), "v"(a), "v"(b), "v"(s));
 }
 
+// The two halves of split_pk_s as separate calls (same instructions, same bits): for callers that place the work in
+// the issue shadow of matrix instructions a few cycles at a time (xenc.hip).
+__device__ __forceinline__ void split_pk_s_hi(float a, float b, float s, unsigned int& hi_u) {
+  asm("v_fma_mixlo_f16 %0, %1, %3, 0 op_sel_hi:[0,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %2, %3, 0 op_sel_hi:[0,0,0]"
+      : "=&v"(hi_u)
+      : "v"(a), "v"(b), "v"(s));
+}
+__device__ __forceinline__ void split_pk_s_lo(float a, float b, float s, unsigned int hi_u, unsigned int& lo_u) {
+  asm("v_fma_mixlo_f16 %0, %2, %4, -%1 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %3, %4, -%1 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(lo_u)
+      : "v"(hi_u), "v"(a), "v"(b), "v"(s));
+}
+
 // Exponent k of the power-of-two scale 2^k that brings `amax` into [2^14, 2^15);
 // clamped to [-60, 60] (so that 2^-(ka+kb) stays a normal float); 0 for a zero,
 // negative or non-finite bound.

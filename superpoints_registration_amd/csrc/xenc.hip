@@ -104,6 +104,17 @@ __device__ __forceinline__ void dma16(const void* base, unsigned off, unsigned d
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                : : "v"(off), "s"(base), "s"(dst_s) : "memory", "m0");
 }
+// Four 1-KiB pieces behind ONE M0 / address setup: the instruction's immediate offset moves the global AND the LDS
+// address (LDS address = M0 + offset + 16 lane), so piece q of a 4-KiB group is the same instruction with offset q KiB.
+// dma_set() loads M0; dma_q<Q>() relies on nothing having written M0 since (the chunk loops hold no instruction that
+// uses M0: LDS instructions of this architecture do not).
+__device__ __forceinline__ void dma_set(unsigned dst_s) {
+  asm volatile("s_mov_b32 m0, %0" : : "s"(dst_s) : "memory", "m0");
+}
+template <int Q>
+__device__ __forceinline__ void dma_q(const void* base, unsigned off) {
+  asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(off), "s"(base), "n"(Q * 1024) : "memory", "m0");
+}
 // (the trailing s_nop keeps the compiler's next instruction from overwriting the data registers of a
 // wide store before it has read them)
 __device__ __forceinline__ void store16(void* p, const u32x4& v) {
@@ -270,6 +281,11 @@ __device__ unsigned long long g_xenc_stamps[64 * 64];
     if (blockIdx.x == 0 && tid == 0 && it < 64 && (stamp_on & 1))                                   \
       g_xenc_stamps[it * 64 + (k)] = __builtin_amdgcn_s_memrealtime();                              \
   } while (0)
+#define XSTAMP_IT(k)                                                                                \
+  do {                                                                                              \
+    if (blockIdx.x == 0 && tid == 0 && stamp_it < 64 && (stamp_on & 1))                             \
+      g_xenc_stamps[stamp_it * 64 + (k)] = __builtin_amdgcn_s_memtime();                            \
+  } while (0)
 #else
 #define XSTAMP(k) do { } while (0)
 #define XSTAMP_REAL(k) do { } while (0)
@@ -327,20 +343,30 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
   int i_pos = 0, i_slot = 0;              // issue side: stream position, slot
   int a_slot = 0;
   int s_cnt = 0;                          // counted (asm) stores since the last acquire
-  unsigned dma_dst = 0, dma_off = 0;      // armed pieces
-  bool dma_on = false;
+  unsigned dma_dst = 0, dma_off = 0, dma_off4 = 0;      // armed pieces: LDS address, per-lane source offsets (+ 4 KiB)
   auto arm = [&]() {
-    dma_on = true;
-#ifdef SPR_XENC_STAMP
-    if (stamp_on & 2) dma_on = false;     // ablation: no weight DMA (garbage results)
-#endif
     dma_dst = __builtin_amdgcn_readfirstlane(ring_s + (unsigned)i_slot * XCHUNK + (unsigned)wave * (XDMA * 1024));
     dma_off = (unsigned)i_pos * XCHUNK + (unsigned)wave * (XDMA * 1024) + (unsigned)lane * 16;
+    dma_off4 = dma_off + 4096;
     if (++i_pos == nch) i_pos = 0;
     if (++i_slot == XSLOTS) i_slot = 0;
   };
+  // piece j of the armed chunk (j is a constant after unrolling): pieces 0 and 4 set M0 for their group of four (the
+  // wait state M0 needs in front of an LDS-DMA is the s_nop), the others are ONE instruction
   auto piece = [&](int j) __attribute__((always_inline)) {
-    if (dma_on) dma16(c.w, dma_off + j * 1024, dma_dst + j * 1024);
+#ifdef SPR_XENC_STAMP
+    if (stamp_on & 2) return;             // ablation: no weight DMA (garbage results)
+#endif
+    switch (j) {
+      case 0: dma_set(dma_dst); asm volatile("s_nop 0"); dma_q<0>(c.w, dma_off); break;
+      case 1: dma_q<1>(c.w, dma_off); break;
+      case 2: dma_q<2>(c.w, dma_off); break;
+      case 3: dma_q<3>(c.w, dma_off); break;
+      case 4: dma_set(dma_dst + 4096); asm volatile("s_nop 0"); dma_q<0>(c.w, dma_off4); break;
+      case 5: dma_q<1>(c.w, dma_off4); break;
+      case 6: dma_q<2>(c.w, dma_off4); break;
+      default: dma_q<3>(c.w, dma_off4); break;
+    }
   };
   auto acquire = [&]() __attribute__((always_inline)) -> const unsigned char* {
     // younger than the last piece of chunk g_acq: the eight pieces of chunk g_acq + 1 and the counted stores
@@ -370,7 +396,6 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
 #pragma unroll
     for (int j = 0; j < XDMA; ++j) piece(j);
   }
-  dma_on = false;
   Carry cy;
   const unsigned char* slot = ring;
   wait_vm<16>();
@@ -381,12 +406,17 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
   // chunk with accumulator `acc`, activation planes xh / xl (one fragment per step), side slices side(0..31).
   // SWAP = false: acc[feature][token] (weights are the A operand); true: acc[token][feature] (activations are the A
   // operand: the lane is a FEATURE and holds 16 tokens -- the V blocks, whose planes are stored transposed)
+  int stamp_it = 0;
+  int step_stamp = -1;       // diagnostic build: >= 0 = stamp every step of the next chunk at step_stamp + i
   auto chunk_f = [&](auto swap_tag, f32x16& acc, const f16x8 (&xh)[16], const f16x8 (&xl)[16], auto&& side)
       __attribute__((always_inline)) {
     constexpr bool SW = decltype(swap_tag)::value;
     const unsigned char* nxt = slot;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
+#ifdef SPR_XENC_STAMP
+      if (step_stamp >= 0) XSTAMP_IT(step_stamp + i);
+#endif
       if (i == 8) nxt = acquire();
       acc = SW ? mfma1(xh[i], cy.l[i & (XRING - 1)], acc) : mfma1(cy.l[i & (XRING - 1)], xh[i], acc);
       XSB();
@@ -411,6 +441,9 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
     const unsigned char* nxt = slot;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
+#ifdef SPR_XENC_STAMP
+      if (step_stamp >= 0) XSTAMP_IT(step_stamp + i);
+#endif
       if (i == 8) nxt = acquire();
       y[i >> 1] = mfma1(cy.l[i & (XRING - 1)], hh[i & 1], y[i >> 1]);
       XSB();
@@ -441,6 +474,7 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
 
 #pragma unroll 1
   for (int it = 0; tile < ntiles; ++it) {
+    stamp_it = it;
     if (tid == 0) s_tile[(it + 1) & 1] = atomicAdd(tile_ctr, 1);       // the next tile (read at the end of this one)
     // Tiles never straddle a segment (cloud): tile = (segment, 128-token slice of it).  A wave's 32 tokens then sit in
     // 32 consecutive, 32-byte aligned columns of the transposed V planes (one segment, vstart is a multiple of 16).
@@ -530,11 +564,21 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
       XSTAMP(5);
       // side of F(c): slices 0..7 ReLU + split of the previous accumulator P (hidden chunk c - 1), slices
       // 8..11 re-initialise P with the bias of hidden chunk c + 1 (the table is padded past d_ff)
+      // (a slice must fit the ~24 issue cycles an MFMA leaves free: the split of one register pair is four half-rate
+      // v_fma_mix*_f16 + the two maxima = 40 cycles, so it is cut in two -- hi plane in slice 2 q, lo plane in 2 q + 1)
+      float ra = 0.f, rb = 0.f;
       auto relu_split = [&](f32x16& P, int cnext, int s) __attribute__((always_inline)) {
-        if (s < 8) {
-          split_pk_s(fmaxf(P[2 * s], 0.f), fmaxf(P[2 * s + 1], 0.f), c.h_mul, hu[s], lu[s]);
-        } else if (s < 12) {
-          bias_group(P, b1t + 32 * cnext, c.bs1, s - 8);
+        if (s < 16) {
+          const int q = s >> 1;
+          if (!(s & 1)) {
+            ra = fmaxf(P[2 * q], 0.f);
+            rb = fmaxf(P[2 * q + 1], 0.f);
+            split_pk_s_hi(ra, rb, c.h_mul, hu[q]);
+          } else {
+            split_pk_s_lo(ra, rb, c.h_mul, hu[q], lu[q]);
+          }
+        } else if (s < 20) {
+          bias_group(P, b1t + 32 * cnext, c.bs1, s - 16);
         }
       };
       auto pack_h = [&]() __attribute__((always_inline)) {
@@ -562,9 +606,19 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
       }
       {
         const int c1 = c.nf - 1;                                                                        // last pair
+#ifdef SPR_XENC_STAMP
+        step_stamp = 15;
+#endif
         chunk_f(std::false_type{}, B, ph, pw, [&](int s) __attribute__((always_inline)) { relu_split(A, c1 + 1, s); });
         pack_h();
+#ifdef SPR_XENC_STAMP
+        step_stamp = 32;
+#endif
         chunk_g(y, hh, hl, no_side);                                                                    // G(nf - 2)
+#ifdef SPR_XENC_STAMP
+        XSTAMP(48);
+        step_stamp = -1;
+#endif
 #pragma unroll
         for (int s = 0; s < 8; ++s) split_pk_s(fmaxf(B[2 * s], 0.f), fmaxf(B[2 * s + 1], 0.f), c.h_mul, hu[s], lu[s]);
         pack_h();
@@ -638,15 +692,19 @@ __global__ __launch_bounds__(256, 1) void k_xenc_chain(ChainConsts c, const floa
       auto epi = [&](auto which_tag, f32x16& P, int fbp, int fbn, int s) __attribute__((always_inline)) {
         constexpr int WHICH = decltype(which_tag)::value;
         const int head = fbp & 7;
-        if (s < 8) {
-          split_pk_s(P[2 * s] * c.un_in, P[2 * s + 1] * c.un_in, c.pmul[WHICH], hu[s], lu[s]);
-        } else if (s < 12) {
-          bias_next(P, fbn, s - 8);
-        } else if (s < 16) {
+        if (s < 16) {
+          // split of register pair q: hi plane in slice 2 q, lo plane in 2 q + 1 (a slice must fit the issue cycles an
+          // MFMA leaves free).  un_in is a power of two: folded into the plane multiplier, same bits.
+          const float pm = c.un_in * c.pmul[WHICH];
+          const int q = s >> 1;
+          if (!(s & 1)) split_pk_s_hi(P[2 * q], P[2 * q + 1], pm, hu[q]);
+          else split_pk_s_lo(P[2 * q], P[2 * q + 1], pm, hu[q], lu[q]);
           // (round 5: the V planes keep every 16-token group in the order [0-3, 8-11, 4-7, 12-15] -- attn_planes.h,
           // attn_vperm -- which is exactly what a lane holds: (feature l & 31, half h) has tokens {0..3, 8..11} + 4 h of
           // the wave's first 16 and {16..19, 24..27} + 4 h of its second 16 as packed pairs.  The four
           // v_permlane32_swaps per plane that used to gather 8 consecutive tokens are gone.)
+        } else if (s >= 22 && s < 26) {
+          bias_next(P, fbn, s - 22);
         } else if (s >= 18 && s < 22) {            // stores behind the acquire of step 8 (slice 16): counted there
 #ifdef SPR_XENC_STAMP
           if (stamp_on & 8) return;                // ablation: no plane stores (garbage results)
