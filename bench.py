@@ -62,8 +62,9 @@ def parse():
                          "(BASELINE configs[3]; use with --config kitti)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-mode", type=int, default=1, help="1 = range-scaled split-fp16 MFMA (default), 0 = exact f32")
-    ap.add_argument("--attn-mode", type=int, default=1,
-                    help="1 = split-fp16 (default), 0 = exact f32, 2 = single-pass fp16 operands")
+    ap.add_argument("--attn-mode", type=int, default=4,
+                    help="4 = split-fp16, second probability plane only where a key block carries weight (default), "
+                         "1 = split-fp16 everywhere, 3 = one probability plane, 0 = exact f32, 2 = single-pass fp16 operands")
     ap.add_argument("--no-train-leg", action="store_true", help="skip the training-step leg (N = 1 only)")
     ap.add_argument("--train-pairs", type=int, default=16,
                     help="pairs per training step of the train_step leg (16 fill the chip: 4 pairs run at 0.7x the rate)")
@@ -291,7 +292,7 @@ def main():
                                          0: "k_attn (exact f32 MFMA)"}[args.attn_mode],
                                  avg_launch_ms=round(avg_ms_attn, 5), launches=len(attn_ms),
                                  alg_flops_per_launch=int(avg_flops),
-                                 mfma_flops_executed_per_launch=int({1: 3, 2: 1, 0: 1, 3: 2.5, 4: 2.5}[args.attn_mode] * avg_flops))
+                                 mfma_flops_executed_per_launch=int({1: 3, 2: 1, 0: 1, 3: 2.5, 4: 2.75}[args.attn_mode] * avg_flops))
         best = None
         for code, a in agg.items():
             if code not in fwd_bytes or a['count'] % fwd_launches[code] != 0:
@@ -372,6 +373,9 @@ def main():
         # from the exact-f32 forward on this workload, up to ~2e-4 when the softmax rows are carried by a few keys
         # (scripts/attn_mode_err.py) -- an opt-in mode, never the headline
         extra["single_plane_attention"] = leg(args.gemm_mode, 3, n_leg)
+        # rounds 1-4 default (both probability planes on every tile); the round-5 default (mode 4) keeps the second
+        # plane only for key blocks that hold a weight >= 2^-5 of the row's running sum
+        extra["two_plane_attention"] = leg(args.gemm_mode, 1, n_leg)
         ops.set_gemm_mode(args.gemm_mode)
         ops.set_attn_mode(args.attn_mode)
         if roofline is not None:
@@ -444,7 +448,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": {(1, 1): "f32 (matrix products: range-scaled split-f16x2 MFMA, f32 accumulate)",
+        "dtype": {(1, 4): "f32 (matrix products: range-scaled split-f16x2 MFMA, f32 accumulate; attention weights below "
+                          "2^-5 of their row sum carried in one f16 plane)",
+                  (1, 1): "f32 (matrix products: range-scaled split-f16x2 MFMA, f32 accumulate)",
                   (0, 0): "f32 (exact f32 MFMA)"}.get((args.gemm_mode, args.attn_mode),
                                                       f"f32 storage/accumulate, gemm_mode={args.gemm_mode}, "
                                                       f"attn_mode={args.attn_mode}"),
@@ -467,6 +473,7 @@ def main():
         "exact_f32": extra.get("exact_f32"),
         "fp16_attention": extra.get("fp16_attention"),
         "single_plane_attention": extra.get("single_plane_attention"),
+        "two_plane_attention": extra.get("two_plane_attention"),
         "two_streams": extra.get("two_streams"),
         "train_step": extra.get("train_step"),
         "ranks": {"world_size_seen": (dist.get_world_size() if dist is not None else 1),

@@ -416,7 +416,7 @@ int spr_attn_varlen_bwd_lse(const float* q, int q_stride, const float* k, int k_
                             float* dv, void* ws, size_t ws_bytes, void* stream);
 
 /* Arithmetic of the attention core:
- *   1 (default) = split-fp16 MFMA (Q, K, V and the probabilities carried as fp16
+ *   1 = split-fp16 MFMA (Q, K, V and the probabilities carried as fp16
  *     hi + lo; Q/K balanced and V scaled by powers of two derived from measured
  *     or derived bounds, so no magnitude overflows fp16; fp32 accumulation and
  *     softmax; fp32-level accuracy);
@@ -429,9 +429,16 @@ int spr_attn_varlen_bwd_lse(const float* q, int q_stride, const float* k, int k_
  *     of the value rows with weights perturbed by < 2^-10 each (5e-6 of the
  *     output scale on flat rows of ~2 000 keys, up to ~3e-4 on rows carried by a
  *     few keys); 20 instead of 24 MFMAs per 64-key tile;
- *   4 = as 1, the lo plane of the probabilities only on the key tiles that hold
- *     a weight of at least 2^-7 of the running row sum (dominant keys exact, the
- *     rest as mode 3: <= 3e-5 of the output scale on every tested distribution). */
+ *   4 (default since round 5) = as 1, the lo plane of the probabilities only on
+ *     the 32-key blocks that hold a weight of at least 2^-5 of the running row
+ *     sum: every key that carries a row is exact as in mode 1, the many small
+ *     weights travel in one fp16 plane rounded to nearest (their rounded values
+ *     also form the row sum).  Error of the small weights: 2^-12 / sqrt(3 n) of
+ *     the value spread for n comparable keys -- <= 3e-5 of the output scale on
+ *     every tested distribution, 3e-6 on the bench's rows of ~2 000 keys (mode
+ *     1: 1e-6), and equal to mode 1 on peaked rows (DESIGN.md section 4,
+ *     profiles/r05_attn_mode_accuracy.txt).  22-23 instead of 24 MFMAs per
+ *     64-key tile and a third fewer conversion instructions. */
 int spr_set_attn_mode(int mode);
 
 /* ---- a11: dual-softmax matching ---------------------------------------------

@@ -871,7 +871,7 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
     const _Float16* __restrict__ vth_g, const _Float16* __restrict__ vtl_g, int t_total, int tp,
     const int* __restrict__ cu, const int* __restrict__ kv_seg, int nseg, int nhead,
     const float* __restrict__ scales, float* __restrict__ out, int o_stride, float* __restrict__ lse_out,
-    const int* __restrict__ o_tiles) {
+    const int* __restrict__ o_tiles, float sig_thr) {
   static_assert(H3 || !PLO, "a lo plane of P only with split operands");
   static_assert(!ADAPT || (H3 && PLO), "the adaptive form is a refinement of the split form");
   // K tiles arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write): the image is lane-linear,
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
 
   constexpr float kOff = 4.0f;        // a fresh reference puts the row maximum at 2^kOff
   constexpr float kSumMax = 32768.f;  // a lane's tile sum below this: every probability inside fp16's range
-  constexpr float kSig = 1.0f / 128;  // ADAPT: a probability below kSig x the lane's running sum needs no lo plane
+  const float kSig = sig_thr;         // ADAPT: a probability below kSig x the lane's running sum needs no lo plane
 
   auto tile = [&](int kt, int buf, auto tail_tag) {
     constexpr bool TAIL = decltype(tail_tag)::value;
@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(256, WPS) void k_attn_s(
   }
 }
 
-static std::atomic<int> g_attn_mode{1};   // 1 = split-fp16 (default), 0 = exact f32 MFMA, 2 = single-pass fp16,
+static std::atomic<int> g_attn_mode{4};   // 4 = adaptive lo plane (default), 1 = split-fp16, 0 = exact f32 MFMA, 2 = single-pass fp16,
                                           // 3 = split-fp16 scores, ONE probability plane (k_attn_s<true, false>), 4 = adaptive lo plane
 
 // L1 norm of every row of w [rows, cols]: one wave per row.
@@ -1386,15 +1386,17 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
   static const bool core_h3 = [] { const char* e = getenv("SPR_ATTN_CORE"); return e != nullptr && e[0] == 'h'; }();
   static const int prio = [] { const char* e = getenv("SPR_ATTN_PRIO"); return e != nullptr ? atoi(e) : 2; }();
   if (mode >= 3 || (nq == 1 && !core_h3)) {
+    // mode 4: significance threshold 2^-SPR_ATTN_SIG of the lane's running sum (default 2^-5)
+    static const float sig = [] { const char* e = getenv("SPR_ATTN_SIG"); return ldexpf(1.0f, -(e != nullptr ? atoi(e) : 5)); }();
     dim3 grid1(cdiv(max_len_host, QB2 / 2) * nhead * nseg);
 #define SPR_ATTN_S(H3_, PLO_, PR_)                                                                                   \
     hipLaunchKernelGGL((k_attn_s<H3_, PLO_, 3, PR_>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth, \
-                       pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles)
+                       pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles, sig)
 #ifdef SPR_ATTN_ABLATE
     static const int abl = [] { const char* e = getenv("SPR_ATTN_ABL"); return e != nullptr ? atoi(e) : 0; }();
 #define SPR_ATTN_SA(A_)                                                                                               \
     hipLaunchKernelGGL((k_attn_s<true, true, 3, 2, A_>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth, \
-                       pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles)
+                       pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles, sig)
     if (abl != 0 && mode == 1) {
       switch (abl) {
         case 1: SPR_ATTN_SA(1); break;
@@ -1414,16 +1416,21 @@ int launch_core(const AttnPlanes& pl, int t, size_t tp, const int* cu, const int
     if (pf > 0 && (mode == 1 || mode == 3)) {
       if (mode == 1)
         hipLaunchKernelGGL((k_attn_s<true, true, 3, 2, 0, false, 1>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl,
-                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles);
+                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles, sig);
       else
         hipLaunchKernelGGL((k_attn_s<true, false, 3, 2, 0, false, 1>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl,
-                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles);
+                           pl.vth, pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles, sig);
       SPR_LAUNCH_CHECK();
       return 0;
     }
     if (mode == 4) {
+      static const int awps = [] { const char* e = getenv("SPR_ATTN_ADAPT_WPS"); return e != nullptr ? atoi(e) : 4; }();
+      if (awps == 3)
+        hipLaunchKernelGGL((k_attn_s<true, true, 3, 2, 0, true>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
+                           pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles, sig);
+      else
       hipLaunchKernelGGL((k_attn_s<true, true, 4, 2, 0, true>), grid1, dim3(256), 0, stream, pl.qh, pl.ql, pl.kh, pl.kl, pl.vth,
-                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles);
+                         pl.vtl, t, (int)tp, cu, kv_seg, nseg, nhead, pl.scales, out, o_stride, lse_out, o_tiles, sig);
     } else if (prio > 0) {
       if (mode == 2) SPR_ATTN_S(false, false, 2);
       else if (mode == 3) SPR_ATTN_S(true, false, 2);

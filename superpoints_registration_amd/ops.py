@@ -957,6 +957,11 @@ def xenc_forward(plan: XencPlan, x, pos, cu, seg_self, seg_cross, max_len: int) 
     return out
 
 
+# the attention arithmetic a fresh process runs (csrc/attention.hip, g_attn_mode): split-fp16 scores, split-fp16
+# probabilities where a 32-key block holds a weight of at least 2^-5 of the running row sum, one rounded plane elsewhere
+DEFAULT_ATTN_MODE = 4
+
+
 def set_attn_mode(mode: int) -> None:
     """1 = split-fp16 MFMA (default), 0 = exact f32 MFMA, 2 = single-pass fp16 MFMA, 3 = split-fp16 scores with ONE
     probability plane (weights rounded to 11 bits, row sum from the rounded plane), 4 = as 1 with the lo plane of the

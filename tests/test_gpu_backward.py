@@ -121,12 +121,12 @@ def test_kpconv_backward(device, tag):
     assert _rel(dw.grad, cw.grad) <= 2e-5, f"kpconv {tag} dW {_rel(dw.grad, cw.grad):.2e}"
 
 
-@pytest.fixture(params=[1, 0], ids=["split-fp16", "exact-f32"])
+@pytest.fixture(params=[4, 1, 0], ids=["default", "split-fp16", "exact-f32"])
 def attn_mode(request):
     """Both arithmetic forms of the attention kernels (forward AND backward follow spr_set_attn_mode)."""
     ops.set_attn_mode(request.param)
     yield request.param
-    ops.set_attn_mode(1)
+    ops.set_attn_mode(ops.DEFAULT_ATTN_MODE)
 
 
 def test_attention_backward(device, attn_mode):

@@ -227,12 +227,12 @@ def test_fp16_attention_mode_end_to_end_on_modelnet_batch256(device):
             "tgt_xyz": [torch.from_numpy(p[1]).to(device) for p in pairs]}
     try:
         with torch.no_grad():
-            ops.set_attn_mode(1)
+            ops.set_attn_mode(ops.DEFAULT_ATTN_MODE)
             o8_split, o256_split = model(dict(b8)), model(dict(b256))
             ops.set_attn_mode(2)
             o8, o256 = model(dict(b8)), model(dict(b256))
     finally:
-        ops.set_attn_mode(1)
+        ops.set_attn_mode(ops.DEFAULT_ATTN_MODE)
     worst_pose = worst_feat = worst_split = 0.0
     for b in range(8):
         worst_pose = max(worst_pose, float(np.linalg.norm(o8["pose"][b].cpu().numpy() - g["pose"][b])))

@@ -182,7 +182,7 @@ def test_layernorm(device):
     _close(npos.cpu().numpy(), (ref + p.double()).numpy(), 2e-6, "layernorm+pos")
 
 
-@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("mode", [4, 1, 0])
 def test_attention_core_vs_fp64(device, mode):
     ops.set_attn_mode(mode)
     lens = [70, 33, 129, 1]
@@ -202,18 +202,20 @@ def test_attention_core_vs_fp64(device, mode):
             v = qkv[offs[ks]:offs[ks + 1], 512:].double().view(-1, 8, 32).transpose(0, 1)
             a = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(32), -1)
             ref[offs[s]:offs[s + 1]] = (a @ v).transpose(0, 1).reshape(-1, 256)
-        _close(o.cpu().numpy(), ref.numpy(), 3e-6, f"attention mode={mode} kv_seg={kv_seg}")
-    ops.set_attn_mode(1)
+        # mode 4 (the default): weights below 2^-5 of their row sum are carried in ONE fp16 plane -- rows of 30 .. 130
+        # comparable keys, as here, are its least accurate case (2^-12 / sqrt(3 n_eff) of the value spread)
+        _close(o.cpu().numpy(), ref.numpy(), 3e-5 if mode == 4 else 3e-6, f"attention mode={mode} kv_seg={kv_seg}")
+    ops.set_attn_mode(ops.DEFAULT_ATTN_MODE)
 
 
-@pytest.mark.parametrize("mode", [1, 0])
+@pytest.mark.parametrize("mode", [4, 1, 0])
 @pytest.mark.parametrize("shared", [True, False])
 def test_attention_with_fused_in_projection_vs_fp64(device, mode, shared):
     """spr_attn_inproj_varlen_fwd = packed in-projection (F.multi_head_attention_forward) + core.
     Ragged segments incl. lengths that are not multiples of 4/8 (plane alignment), a
     segment shorter than a tile, > 256 tokens in total so that the fused GEMM path runs."""
     ops.set_attn_mode(mode)
-    ops.set_gemm_mode(mode)
+    ops.set_gemm_mode(min(mode, 1))
     lens = [301, 70, 257, 33, 129, 1]
     tot = sum(lens)
     x_qk = synthetic.rand((tot, 256), 31, -1.5, 1.5)
@@ -237,8 +239,8 @@ def test_attention_with_fused_in_projection_vs_fp64(device, mode, shared):
         v = vv[offs[ks]:offs[ks + 1]].view(-1, 8, 32).transpose(0, 1)
         a = torch.softmax(q @ k.transpose(1, 2) / math.sqrt(32), -1)
         ref[offs[s]:offs[s + 1]] = (a @ v).transpose(0, 1).reshape(-1, 256)
-    _close(o.cpu().numpy(), ref.numpy(), 5e-6, f"fused in-projection attention mode={mode} shared={shared}")
-    ops.set_attn_mode(1)
+    _close(o.cpu().numpy(), ref.numpy(), 3e-5 if mode == 4 else 5e-6, f"fused in-projection attention mode={mode} shared={shared}")
+    ops.set_attn_mode(ops.DEFAULT_ATTN_MODE)
     ops.set_gemm_mode(1)
 
 

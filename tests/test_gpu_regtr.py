@@ -98,7 +98,7 @@ def test_full_size_pairs_order_and_arithmetic_invariance(device):
         model = model.to(device).eval()
         outs[tag] = model(batch())
     ops.set_gemm_mode(1)
-    ops.set_attn_mode(1)
+    ops.set_attn_mode(ops.DEFAULT_ATTN_MODE)
     for b in range(2):
         ref = outs["ref"]["pose"][b].cpu().numpy()
         assert np.linalg.norm(ref - outs["canon"]["pose"][b].cpu().numpy()) < 1e-4
