@@ -274,6 +274,16 @@ int spr_instnorm_r(const float* x, const int* cu, int n, int nb, int max_len_hos
                    float* out_range, int out_range_n, void* ws, size_t ws_bytes, void* stream);
 int spr_maxpool_gather_r(const float* x, int ns, int c, const int* idx, int nq, int idx_stride,
                          int k, float* out, float* out_range, int out_range_n, void* stream);
+/* The same rows with the queries WALKED in `order` (int32 [nq], a permutation: spr_cell_order of the query points;
+ * NULL = spr_maxpool_gather_r).  Results are identical; queries in flight together then share support rows, which L2
+ * serves instead of HBM (reference: kpconv_blocks.py:127-140 max_pool, no counterpart of the order there). */
+int spr_maxpool_gather_o(const float* x, int ns, int c, const int* idx, int nq, int idx_stride, int k,
+                         const int* order, float* out, float* out_range, int out_range_n, void* stream);
+/* order [n] = the points of every cloud (cu [nb + 1]) sorted by the Morton code of their cell of size `cell`
+ * (clouds in batch order): a spatial walk order for gather operators, not part of any result. */
+size_t spr_cell_order_workspace_bytes(int n);
+int spr_cell_order(const float* xyz, const int* cu, int n, int nb, float cell, int* order, void* ws, size_t ws_bytes,
+                   void* stream);
 int spr_layernorm_range_count(int m);
 int spr_layernorm_r(const float* x, int m, int c, const float* gamma, const float* beta,
                     float eps, const float* pos, float* out_norm, float* out_pos,

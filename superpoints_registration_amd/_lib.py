@@ -66,6 +66,9 @@ SIGNATURES = {
                               _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _sz, _vp]),
     "spr_instnorm_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "spr_maxpool_gather_r": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "spr_maxpool_gather_o": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "spr_cell_order_workspace_bytes": (_sz, [_i]),
+    "spr_cell_order": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _sz, _vp]),
     "spr_layernorm_range_count": (_i, [_i]),
     "spr_layernorm_r": (_i, [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "spr_attn_inproj_varlen_fwd_r": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp,

@@ -517,6 +517,71 @@ extern "C" int spr_grid_subsample(const float* xyz, const int* cu, int n, int nb
   return 0;
 }
 
+// ---- spatial walk order -----------------------------------------------------------------------------
+// order[] = the points of every cloud sorted by the Morton code of their `cell`-sized grid cell (clouds in batch
+// order).  Not part of any result: operators that gather rows of the PREVIOUS level for every point (max-pool, the
+// first convolution) walk their queries in this order so that queries in flight together share neighbours and the
+// rows they gather are served by L2 instead of being re-fetched from HBM (the points themselves stay in the
+// reference's hash-map order).  The grid origin of a cloud is its first point: any fixed origin does.
+namespace spr {
+namespace {
+__device__ __forceinline__ unsigned int spread10(unsigned int v) {     // 10 bits -> every third bit
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__global__ void k_order_keys(const float* __restrict__ xyz, const int* __restrict__ cu, int n, int nb, float inv_cell,
+                             unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int lo = 0, hi = nb;                               // cloud of point i
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (cu[mid] <= i) lo = mid; else hi = mid;
+  }
+  const int o = cu[lo];
+  unsigned int c[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float d = (xyz[3 * (size_t)i + a] - xyz[3 * (size_t)o + a]) * inv_cell;
+    const int q = (int)floorf(fminf(fmaxf(d, -512.f), 511.f)) + 512;
+    c[a] = (unsigned int)q;
+  }
+  const unsigned int m = spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
+  keys[i] = ((unsigned long long)lo << 30) | m;
+  vals[i] = i;
+}
+}  // namespace
+}  // namespace spr
+
+extern "C" size_t spr_cell_order_workspace_bytes(int n) {
+  const size_t N = (size_t)(n > 0 ? n : 1);
+  return 2 * align_up(8 * N, 256) + align_up(4 * N, 256) + sort_temp_bytes(n) + 256;
+}
+
+extern "C" int spr_cell_order(const float* xyz, const int* cu, int n, int nb, float cell, int* order, void* ws,
+                              size_t ws_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(n >= 1 && nb >= 1 && nb < (1 << 30) && cell > 0.f, "cell_order: bad arguments");
+  SPR_REQUIRE(ws_bytes >= spr_cell_order_workspace_bytes(n), "cell_order: workspace too small");
+  Workspace w(ws, ws_bytes);
+  unsigned long long* keys = w.take<unsigned long long>(n);
+  unsigned long long* keys2 = w.take<unsigned long long>(n);
+  int* vals = w.take<int>(n);
+  size_t tb = sort_temp_bytes(n);
+  void* temp = w.take<char>(tb);
+  SPR_REQUIRE(temp != nullptr, "cell_order: workspace carve failed");
+  hipLaunchKernelGGL(k_order_keys, dim3(cdiv(n, 256)), dim3(256), 0, stream, xyz, cu, n, nb, 1.0f / cell, keys, vals);
+  SPR_LAUNCH_CHECK();
+  int bits = 31;
+  while (bits < 60 && (1ull << (bits - 30)) < (unsigned long long)nb) ++bits;
+  SPR_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, keys, keys2, vals, order, (unsigned int)n, 0, bits, stream));
+  return 0;
+}
+
 // ---- voxel pre-downsampling, one point per voxel -----------------------------------
 // Replaces the CPU voxel_down_sample of the KITTI loader (data_loaders/kitti_pred.py:12-14, :203-204,
 // kiss_icp: voxel = (p / voxel_size) truncated toward zero per axis; the FIRST point that falls

@@ -317,14 +317,20 @@ __global__ void k_in_bwd_apply4(const float* __restrict__ x, const float* __rest
   reinterpret_cast<float4*>(dx)[gid] = make_float4(r[0], r[1], r[2], r[3]);
 }
 
+// order != nullptr (spr_cell_order of the query points): the queries are walked in that order, every XCD a contiguous
+// share of it (workgroups b and b + 8 share an L2) -- queries in flight together are neighbours in space, so the
+// ~4.5 reads of every support row happen close together and hit L2 (the grid is then a multiple of 8).
 __global__ void k_maxpool(const float* __restrict__ x, int ns, int c, const int* __restrict__ idx,
                           int nq, int idx_stride, int k, float* __restrict__ out, float* __restrict__ out_range,
-                          int nslots) {
+                          int nslots, const int* __restrict__ order) {
   const int c4 = c >> 2;
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (order != nullptr) gid = ((long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * blockDim.x + threadIdx.x;
   float mx = 0.f;
   if (gid < (long)nq * c4) {
-  const int row = (int)(gid / c4), q = (int)(gid % c4);
+  const int q = (int)(gid % c4);
+  const int row = order != nullptr ? order[gid / c4] : (int)(gid / c4);
+  gid = (long)row * c4 + q;
   float4 m = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
   const int* ir = idx + (size_t)row * idx_stride;
   int j = 0;
@@ -499,7 +505,21 @@ extern "C" int spr_maxpool_gather_r(const float* x, int ns, int c, const int* id
   SPR_REQUIRE(nq > 0 && ns > 0 && c % 4 == 0 && k >= 1 && k <= idx_stride, "maxpool: bad arguments");
   const long total = (long)nq * (c / 4);
   hipLaunchKernelGGL(k_maxpool, dim3(cdiv(total, 256)), dim3(256), 0, stream, x, ns, c, idx, nq,
-                     idx_stride, k, out, out_range, out_range_n);
+                     idx_stride, k, out, out_range, out_range_n, (const int*)nullptr);
+  SPR_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int spr_maxpool_gather_o(const float* x, int ns, int c, const int* idx, int nq, int idx_stride, int k,
+                                    const int* order, float* out, float* out_range, int out_range_n, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SPR_REQUIRE(out_range == nullptr || (out_range_n >= 1 && (out_range_n & (out_range_n - 1)) == 0),
+              "maxpool: out_range_n must be a power of two");
+  SPR_REQUIRE(nq > 0 && ns > 0 && c % 4 == 0 && k >= 1 && k <= idx_stride, "maxpool: bad arguments");
+  const long total = (long)nq * (c / 4);
+  const long nblk = order != nullptr ? align_up((size_t)cdiv(total, 256), 8) : cdiv(total, 256);
+  hipLaunchKernelGGL(k_maxpool, dim3((unsigned)nblk), dim3(256), 0, stream, x, ns, c, idx, nq, idx_stride, k, out,
+                     out_range, out_range_n, order);
   SPR_LAUNCH_CHECK();
   return 0;
 }

@@ -18,6 +18,7 @@ preprocessor consume, instead of two hand-rolled loops with running state.
 from dataclasses import dataclass
 from typing import List
 
+import os
 import torch
 import torch.nn as nn
 
@@ -182,6 +183,9 @@ class _IndexList(list):
         return (self._conv(i) for i in range(len(self)))
 
 
+_POOL_ORDER = os.environ.get("SPR_NO_POOL_ORDER", "") == ""   # A/B switch: max-pool in storage order
+
+
 class Preprocessor(nn.Module):
     """Builds the KPConv pyramid metadata for a list of clouds.
 
@@ -234,7 +238,7 @@ class Preprocessor(nn.Module):
 
         meta = {k: [] for k in ('points', 'stack_lengths')}
         meta.update({k: _IndexList(self.index_dtype) for k in ('neighbors', 'pools', 'upsamples')})
-        meta.update(_cu={}, _i32={}, _lens_host=[], _rows_sorted=True)
+        meta.update(_cu={}, _i32={}, _lens_host=[], _rows_sorted=True, pool_order=[])
         placeholder = torch.zeros((0, 1), dtype=self.index_dtype, device=device)
 
         def publish(key, level, idx):
@@ -281,8 +285,13 @@ class Preprocessor(nn.Module):
                 sub_lens_host = sub_lens.tolist()
                 sub_cu = ops.lengths_to_cu(sub_lens_host, device)
                 pool = search((l, 'pool'), sub_points, sub_cu, points, cu, lv.radius, lv.limit)
+                # spatial walk order of the level's pooled queries (kpconv_blocks.max_pool): one key + sort pass here,
+                # off the main stream, saves the max-pool most of its re-reads of the finer level's features
+                meta['pool_order'].append(ops.cell_order(sub_points, sub_cu, dl) if _POOL_ORDER else None)
                 if self.compute_upsamples:
                     up = search((l, 'up'), points, cu, sub_points, sub_cu, 2 * lv.radius, lv.limit)
+            if not lv.down:
+                meta['pool_order'].append(None)
             publish('pools', l, pool)
             publish('upsamples', l, up)
             if lv.down:

@@ -60,9 +60,15 @@ def gather(x, idx, method=2):
     return flat.view(*idx.shape, x.shape[1])
 
 
-def max_pool(x, inds):
-    """kpconv_blocks.py:127-143 (shadow index reads a zero row)."""
-    return ops.maxpool(x, inds)
+def _pool_order_of(batch, level):
+    po = batch.get('pool_order') if isinstance(batch, dict) else None
+    return po[level] if po is not None and level < len(po) else None
+
+
+def max_pool(x, inds, order=None):
+    """kpconv_blocks.py:127-143 (shadow index reads a zero row).  order: optional spatial walk order of the query
+    rows (ops.cell_order; the pyramid builder supplies it as batch['pool_order']) -- same result, fewer HBM reads."""
+    return ops.maxpool(x, inds, order)
 
 
 def closest_pool(x, inds):
@@ -277,7 +283,7 @@ class ResnetBottleneckBlock(nn.Module):
                  and ops.block_tail_tile_rows(mid, self.in_dim if projected else 0, self.out_dim) > 0)
 
         def shortcut_branch():
-            sc = max_pool(features, neighb_inds) if strided else features
+            sc = max_pool(features, neighb_inds, _pool_order_of(batch, li)) if strided else features
             if projected and not fused:
                 sc = self.unary_shortcut(sc, stack_lengths_post, cu=cu_post, max_len=ml_post)
             return sc

@@ -625,14 +625,28 @@ def block_tail(xa, wa, cu, xb=None, wb=None, add=None, eps: float = 1e-5, slope:
     return out
 
 
-def maxpool(x, idx) -> torch.Tensor:
+def cell_order(points: torch.Tensor, cu: torch.Tensor, cell: float) -> torch.Tensor:
+    """int32 [N]: the points of every cloud sorted by the Morton code of their `cell`-sized grid cell -- a spatial WALK
+    order for gather operators (maxpool(order=...)); results never depend on it."""
+    points = _dev(points, "points", torch.float32)
+    cu = _dev(cu, "cu", torch.int32)
+    n, nb = points.shape[0], cu.numel() - 1
+    L = _lib.lib()
+    out = torch.empty((n,), dtype=torch.int32, device=points.device)
+    ws = _workspace(L.spr_cell_order_workspace_bytes(n), points.device)
+    _lib.check(L.spr_cell_order(_ptr(points), _ptr(cu), n, nb, float(cell), _ptr(out), _ptr(ws), ws.numel(),
+                                _stream(points)), "spr_cell_order")
+    return out
+
+
+def maxpool(x, idx, order=None) -> torch.Tensor:
     if _wants_grad(x):
         from .autograd import MaxPoolFn
         return MaxPoolFn.apply(_dev(x, "x", torch.float32), idx)
-    return maxpool_raw(x, idx)
+    return maxpool_raw(x, idx, order)
 
 
-def maxpool_raw(x, idx) -> torch.Tensor:
+def maxpool_raw(x, idx, order=None) -> torch.Tensor:
     x = _dev(x, "x", torch.float32)
     if idx.dtype != torch.int32:
         idx = idx.to(torch.int32)
@@ -646,8 +660,14 @@ def maxpool_raw(x, idx) -> torch.Tensor:
     L = _lib.lib()
     cnt = _STREAM_SLOTS
     rng = _zero_slots(cnt, x.device) if _HANDOVER else None
-    _lib.check(L.spr_maxpool_gather_r(_ptr(x), ns, c, _ptr(idx), nq, int(stride), k, _ptr(out), _ptr(rng), cnt,
-                                      _stream(x)), "spr_maxpool_gather_r")
+    if order is not None:
+        if order.dtype != torch.int32 or order.numel() != nq or not order.is_contiguous():
+            raise ValueError("maxpool: order must be a contiguous int32 permutation of the query rows")
+        _lib.check(L.spr_maxpool_gather_o(_ptr(x), ns, c, _ptr(idx), nq, int(stride), k, _ptr(order), _ptr(out),
+                                          _ptr(rng), cnt, _stream(x)), "spr_maxpool_gather_o")
+    else:
+        _lib.check(L.spr_maxpool_gather_r(_ptr(x), ns, c, _ptr(idx), nq, int(stride), k, _ptr(out), _ptr(rng), cnt,
+                                          _stream(x)), "spr_maxpool_gather_r")
     if rng is not None:
         _set_range(out, rng, cnt)
     return out

@@ -358,3 +358,31 @@ def test_wave_per_query_selection_is_the_thread_per_query_selection(device, limi
         order = inr[np.lexsort((inr, d2[i][inr]))][:limit]
         assert np.array_equal(got[i, :len(order)], order), i
         assert (got[i, len(order):] == len(sup)).all()
+
+
+@pytest.mark.gpu
+def test_cell_order_is_a_spatial_permutation_and_the_ordered_maxpool_is_the_maxpool(device):
+    """ops.cell_order: a permutation of the rows, clouds kept in batch order, consecutive rows close in space;
+    ops.maxpool(order=...) walks its queries in that order and must return the same bits (round 5: the walk
+    order only decides which rows share L2)."""
+    lens = [3000, 1, 777, 5000]
+    g = torch.Generator().manual_seed(3)
+    pts = torch.cat([torch.rand((n, 3), generator=g) * 2.0 + 5.0 * i for i, n in enumerate(lens)]).to(device)
+    cu = ops.lengths_to_cu(lens, device)
+    order = ops.cell_order(pts, cu, 0.1)
+    o = order.cpu().numpy()
+    assert o.dtype == np.int32 and sorted(o.tolist()) == list(range(sum(lens)))
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    for i in range(len(lens)):
+        seg = o[offs[i]:offs[i + 1]]
+        assert seg.min() >= offs[i] and seg.max() < offs[i + 1]          # clouds stay in batch order
+    p = pts.cpu().numpy()
+    walk = np.linalg.norm(np.diff(p[o[:3000]], axis=0), axis=1).mean()
+    stored = np.linalg.norm(np.diff(p[:3000], axis=0), axis=1).mean()
+    assert walk < 0.3 * stored, (walk, stored)                            # neighbours in the walk are neighbours in space
+    nq, ns, c, k = sum(lens), 20000, 64, 11
+    x = torch.randn((ns, c), generator=g).to(device)
+    idx = torch.randint(0, ns + 1, (nq, k), generator=g, dtype=torch.int32).to(device)   # ns = the shadow row
+    a = ops.maxpool(x, idx)
+    b = ops.maxpool(x, idx, order)
+    assert torch.equal(a, b)
