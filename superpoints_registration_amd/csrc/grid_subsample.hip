@@ -477,8 +477,12 @@ extern "C" int spr_grid_subsample(const float* xyz, const int* cu, int n, int nb
                      info, keys, vals, err);
   SPR_LAUNCH_CHECK();
   size_t tb = temp_bytes;
+  // keys = cloud << kKeyBits | voxel: only the bits a batch of nb clouds can set are sorted (6 radix passes instead
+  // of 8 for 128 clouds)
+  int key_bits = kKeyBits + 1;
+  while (key_bits < 64 && (1ull << (key_bits - kKeyBits)) < (unsigned long long)nb) ++key_bits;
   SPR_HIP_CHECK(rocprim::radix_sort_pairs(temp, tb, keys, keys2, vals, vals2,
-                                          (unsigned int)n, 0, 64, stream));
+                                          (unsigned int)n, 0, key_bits, stream));
   hipLaunchKernelGGL(k_flags, dim3(cdiv(n, TB)), dim3(TB), 0, stream, keys2, n, flags);
   tb = temp_bytes;
   SPR_HIP_CHECK(rocprim::exclusive_scan(temp, tb, flags, vid, 0, (size_t)n,
