@@ -262,6 +262,153 @@ __global__ __launch_bounds__(512) void k_col_lse_v(const float* __restrict__ mat
   }
 }
 
+// ---- two reductions per sweep (round 5) ---------------------------------------------------------------
+// The head of spr_match_sinkhorn reads every correlation matrix for four independent reductions: row / column
+// log-sum-exp of the dual softmax (raw x) and the first Sinkhorn row / column pass (affinity view, slack).  The two
+// row passes share one read of the row, the two column passes one read of the column block: per quantity the SAME
+// operations in the same order as k_row_lse_v / k_col_lse_v, so the results are bit for bit those of the separate
+// launches -- two sweeps of each matrix instead of four.
+template <int RV>
+__global__ __launch_bounds__(256) void k_row_lse_v2(const float* __restrict__ mat, const PairDesc* __restrict__ pd,
+                                                    float* __restrict__ row_out1, float* __restrict__ row_out2,
+                                                    const float* __restrict__ col_sub2, const float* __restrict__ aff2) {
+  const PairDesc p = pd[blockIdx.y];
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= p.n) return;
+  const Aff af(aff2);
+  const float* r = mat + p.off + (size_t)row * p.m;
+  const float* cs = col_sub2 + p.tgt_beg;
+  float v1[RV][4], v2[RV][4];
+  float mx1 = -INFINITY, mx2 = 0.f;      // (the Sinkhorn pass carries the slack entry: exp(0))
+#pragma unroll
+  for (int i = 0; i < RV; ++i) {
+    const int j = 4 * (lane + 64 * i);
+    if (j + 3 < p.m) {
+      const f4u a = *reinterpret_cast<const f4u*>(r + j);
+      const f4u b = *reinterpret_cast<const f4u*>(cs + j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v1[i][e] = a[e] - 0.f;
+        v2[i][e] = af(a[e]) - b[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v1[i][e] = j + e < p.m ? r[j + e] - 0.f : -INFINITY;
+        v2[i][e] = j + e < p.m ? af(r[j + e]) - cs[j + e] : -INFINITY;
+      }
+    }
+    mx1 = fmaxf(mx1, fmaxf(fmaxf(v1[i][0], v1[i][1]), fmaxf(v1[i][2], v1[i][3])));
+    mx2 = fmaxf(mx2, fmaxf(fmaxf(v2[i][0], v2[i][1]), fmaxf(v2[i][2], v2[i][3])));
+  }
+  mx1 = wave_max(mx1);
+  mx2 = wave_max(mx2);
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < RV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s1 += exp_neg(v1[i][e] - mx1);
+#pragma unroll
+  for (int i = 0; i < RV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s2 += exp_neg(v2[i][e] - mx2);
+  s1 = wave_sum_t(s1);
+  s2 = wave_sum_t(s2);
+  s2 += expf(0.f - mx2);
+  if (lane == 0) {
+    row_out1[p.src_beg + row] = mx1 + lse_log(s1);
+    row_out2[p.src_beg + row] = mx2 + lse_log(s2);
+  }
+}
+
+__global__ __launch_bounds__(512) void k_col_lse_v2(const float* __restrict__ mat, const PairDesc* __restrict__ pd,
+                                                   float* __restrict__ col_out1, float* __restrict__ col_out2,
+                                                   const float* __restrict__ row_sub2, const float* __restrict__ aff2) {
+  const PairDesc p = pd[blockIdx.y];
+  const Aff af(aff2);
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + 4 * cl;
+  __shared__ float smx[2][kColLanesV][64];
+  __shared__ float ssum[2][kColLanesV][64];
+  float mx[2][4], s[2][4];
+#pragma unroll
+  for (int w = 0; w < 2; ++w)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mx[w][e] = -INFINITY;
+      s[w][e] = 0.f;
+    }
+  if (col < p.m) {
+    const int shift = col + 3 < p.m ? 0 : col - (p.m - 4);
+    const float* base = mat + p.off + (col - shift);
+    const float* rs = row_sub2 + p.src_beg;
+    for (int i0 = rl; i0 < p.n; i0 += 4 * kColLanesV) {
+      f4u a[4];
+      float sub[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = min(i0 + q * kColLanesV, p.n - 1);
+        a[q] = *reinterpret_cast<const f4u*>(base + (size_t)i * p.m);
+        sub[q] = rs[i];
+      }
+      float v[2][4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool rok = i0 + q * kColLanesV < p.n;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const float a0 = w ? af(a[q][0]) : a[q][0], a1 = w ? af(a[q][1]) : a[q][1], a2 = w ? af(a[q][2]) : a[q][2],
+                      a3 = w ? af(a[q][3]) : a[q][3];
+          const float sb = w ? sub[q] : 0.f;
+          const float t0 = shift == 0 ? a0 : shift == 1 ? a1 : shift == 2 ? a2 : a3;
+          const float t1 = shift == 0 ? a1 : shift == 1 ? a2 : shift == 2 ? a3 : INFINITY;
+          const float t2 = shift == 0 ? a2 : shift == 1 ? a3 : INFINITY;
+          const float t3 = shift == 0 ? a3 : INFINITY;
+          v[w][q][0] = rok ? t0 - sb : -INFINITY;
+          v[w][q][1] = rok && t1 < INFINITY ? t1 - sb : -INFINITY;
+          v[w][q][2] = rok && t2 < INFINITY ? t2 - sb : -INFINITY;
+          v[w][q][3] = rok && t3 < INFINITY ? t3 - sb : -INFINITY;
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < 2; ++w)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float m4 = fmaxf(fmaxf(v[w][0][e], v[w][1][e]), fmaxf(v[w][2][e], v[w][3][e]));
+          if (m4 > mx[w][e]) {
+            s[w][e] *= exp_neg(mx[w][e] - m4);
+            mx[w][e] = m4;
+          }
+          if (mx[w][e] > -INFINITY) {
+            const float m = mx[w][e];
+            s[w][e] += (exp_neg(v[w][0][e] - m) + exp_neg(v[w][1][e] - m)) + (exp_neg(v[w][2][e] - m) + exp_neg(v[w][3][e] - m));
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < 2; ++w)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      smx[w][rl][4 * cl + e] = mx[w][e];
+      ssum[w][rl][4 * cl + e] = s[w][e];
+    }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int w = threadIdx.x >> 6, t = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + t;
+    if (c < p.m) {
+      float M = w ? 0.f : -INFINITY;
+      for (int k = 0; k < kColLanesV; ++k) M = fmaxf(M, smx[w][k][t]);
+      float S = w ? expf(0.f - M) : 0.f;
+      for (int k = 0; k < kColLanesV; ++k)
+        if (smx[w][k][t] > -INFINITY) S += ssum[w][k][t] * expf(smx[w][k][t] - M);
+      (w ? col_out2 : col_out1)[p.tgt_beg + c] = M + lse_log(S);
+    }
+  }
+}
+
 // launches of the two passes for `np` pairs starting at descriptor pg
 template <typename PT>
 void launch_row_lse(const float* mat, const PairDesc* pg, int np, int max_n, int max_m, PT* out, const PT* col_sub,
@@ -1278,13 +1425,26 @@ extern "C" int spr_match_sinkhorn(const float* feat, int d, const float* xyz, co
       hipLaunchKernelGGL(k_scale, dim3(cdiv(cnt, 256)), dim3(256), 0, stream, c.mat + c.beg(g), cnt, scale);
     }
     const dim3 grow(cdiv((long)c.max_n * 64, 256), np), gcol(cdiv(c.max_m, 64), np);
-    launch_row_lse<float>(c.mat, pg, np, c.max_n, c.max_m, row_lse, nullptr, 0, stream);
-    launch_col_lse<float>(c.mat, pg, np, c.max_m, col_lse, nullptr, 0, stream, c.min_m);
+    // the dual softmax's row / column pass and the first Sinkhorn iteration's in two sweeps instead of four
+    // (k_row_lse_v2 / k_col_lse_v2: same bits); SPR_MATCH_NO_FUSE=1 = the separate launches
+    static const bool no_fuse = [] { const char* e = getenv("SPR_MATCH_NO_FUSE"); return e != nullptr && e[0] == '1'; }();
+    const bool fuse = !no_fuse && n_iters >= 1 && c.max_m <= 2048 && c.min_m >= 4;
+    if (fuse) {
+      if (c.max_m <= 1024)
+        hipLaunchKernelGGL(k_row_lse_v2<4>, grow, dim3(256), 0, stream, c.mat, pg, row_lse, u, (const float*)v, (const float*)aff);
+      else
+        hipLaunchKernelGGL(k_row_lse_v2<8>, grow, dim3(256), 0, stream, c.mat, pg, row_lse, u, (const float*)v, (const float*)aff);
+      hipLaunchKernelGGL(k_col_lse_v2, gcol, dim3(16 * kColLanesV), 0, stream, c.mat, pg, col_lse, v, (const float*)u,
+                         (const float*)aff);
+    } else {
+      launch_row_lse<float>(c.mat, pg, np, c.max_n, c.max_m, row_lse, nullptr, 0, stream);
+      launch_col_lse<float>(c.mat, pg, np, c.max_m, col_lse, nullptr, 0, stream, c.min_m);
+    }
     hipLaunchKernelGGL(k_match_cols, gcol, dim3(1024), 0, stream, c.mat, pg, row_lse, col_lse, match_val, match_ind,
                        match_val2);
     hipLaunchKernelGGL(k_match_rows, grow, dim3(256), 0, stream, c.mat, pg, row_lse, col_lse, match_val, match_ind,
                        match_val2);
-    for (int it = 0; it < n_iters; ++it) {
+    for (int it = fuse ? 1 : 0; it < n_iters; ++it) {
       launch_row_lse<float>(c.mat, pg, np, c.max_n, c.max_m, u, (const float*)v, 1, stream, aff);
       launch_col_lse<float>(c.mat, pg, np, c.max_m, v, (const float*)u, 1, stream, c.min_m, aff);
     }
