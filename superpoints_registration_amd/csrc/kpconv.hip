@@ -761,6 +761,34 @@ __device__ __forceinline__ void ring_dma16_rec8(const void* base, unsigned off, 
       "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, %0"
       : "=&s"(keep) : "v"(off), "s"(base), "s"(dst_s) : "memory", "m0");
 }
+// All DMA instructions of one ring item behind ONE M0 setup (round 5): the instruction's immediate offset moves the
+// global AND the LDS address, so the second row piece (LDS slot + 1 KiB) and the record piece (slot + 8 RB) are issued
+// against bases moved DOWN by their LDS displacement.  PPI = row pieces per item (1: 32 channels, 2: 64 channels).
+template <int PPI, int RB>
+__device__ __forceinline__ void ring_item_dma(const void* x, const void* x_m1k, const void* sx_m, unsigned off0,
+                                              unsigned off1, unsigned off_rec, unsigned dst_s) {
+  unsigned long long keep;
+  if constexpr (PPI == 2) {
+    asm volatile(
+        "s_mov_b32 m0, %7\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %4\n\t"
+        "global_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+        "s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xff\n\t"
+        "global_load_lds_dwordx4 %3, %6 offset:%8\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(keep) : "v"(off0), "v"(off1), "v"(off_rec), "s"(x), "s"(x_m1k), "s"(sx_m), "s"(dst_s), "n"(8 * RB)
+        : "memory", "m0");
+  } else {
+    asm volatile(
+        "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xff\n\t"
+        "global_load_lds_dwordx4 %2, %4 offset:%6\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(keep) : "v"(off0), "v"(off_rec), "s"(x), "s"(sx_m), "s"(dst_s), "n"(8 * RB)
+        : "memory", "m0");
+  }
+}
 __device__ __forceinline__ void ring_dma4(const void* base, unsigned off, unsigned dst_s) {
   unsigned keep;
   asm volatile(
@@ -960,12 +988,21 @@ __global__ __launch_bounds__(512, (RingShape<CC, COUT, NS>::MINW)) void k_kpconv
     // a DMA can land -- which no ISA rule guarantees).  A/B against -DSPR_KP_RING_NO_LGKM: scripts/kp_lgkm_ab.sh.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
+#ifdef SPR_KP_ITEM_DMA_OLD
 #pragma unroll
     for (int pc = 0; pc < PPI; ++pc) {
       const unsigned rid = min(ids.row[pc], (unsigned)(ns - 1));   // shadow slots fetch a real (finite) row
       ring_dma16_m0(x, rid * RB + a_dma, slot + pc * 1024);
     }
     ring_dma16_rec8(sxf, min(ids.rec, (unsigned)ns) * 16, slot + 8 * RB);   // record ns = the shadow record
+#else
+    static_assert(PPI == 1 || PPI == 2, "ring item: one or two row pieces");
+    const unsigned o0 = min(ids.row[0], (unsigned)(ns - 1)) * RB + a_dma;      // shadow slots fetch a real (finite) row
+    const unsigned o1 = min(ids.row[PPI - 1], (unsigned)(ns - 1)) * RB + a_dma;
+    const unsigned orec = min(ids.rec, (unsigned)ns) * 16;                       // record ns = the shadow record
+    ring_item_dma<PPI, RB>(x, reinterpret_cast<const char*>(x) - 1024, reinterpret_cast<const char*>(sxf) - 8 * RB, o0, o1,
+                           orec, slot);
+#endif
   };
   // first min(NS, n) items of a tile: all ids first, then all gathers
   auto prime = [&](const int4 d, int par) {
