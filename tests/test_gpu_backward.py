@@ -348,6 +348,32 @@ def _train_step(tag, device, which):
     return g, model, losses
 
 
+_F64_SCALARS = {}
+
+
+def _f64_sinkhorn_scalar_grads(tag, which):
+    """d loss / d alpha, d beta of the same training step by the float64 CPU oracle's autograd."""
+    key = (tag, which)
+    if key not in _F64_SCALARS:
+        from oracle import torch_oracle as O
+        g = load_golden(f"grad_{tag}_b2.npz")
+        B = int(g["B"])
+        cfg = get_config(tag)
+        pairs, sizes = pairs_for(tag, B)
+        pose, src_ov, tgt_ov = loss_inputs(tag, B)
+        model = RegTR(cfg)
+        synthetic.fill_parameters(model, seed=int(g["seed"]))
+        sd = {k: (v.detach().clone().double() if v.is_floating_point() else v.clone()) for k, v in model.state_dict().items()}
+        for k in ("alpha", "beta"):
+            sd[k].requires_grad_(True)
+        fwd = O.regtr_forward(cfg, sd, [p[0][:n] for p, (n, m) in zip(pairs, sizes)],
+                              [p[1][:m] for p, (n, m) in zip(pairs, sizes)])
+        L = O.compute_loss(cfg, sd, fwd, pose, src_ov, tgt_ov)
+        (L["total"] if which == "total" else 0.1 * L["feature"] + L["overlap"]).backward()
+        _F64_SCALARS[key] = {k: float(sd[k].grad) for k in ("alpha", "beta")}
+    return _F64_SCALARS[key]
+
+
 def test_backward_is_bitwise_reproducible(device):
     """Every sum of the backward has a fixed order -- deterministic split-K partials, the flash-style attention
     backward, and 64-bit fixed-point integer atomics for the three scatter-adds (max-pool, row gather, KPConv
@@ -409,8 +435,17 @@ def test_parameter_gradients_match_the_reference(device, tag, which):
         rms = np.sqrt(np.mean((got_e - ref_e) ** 2)) / max(np.sqrt(np.mean(ref_e ** 2)), 1e-30)
         nerr = abs(np.linalg.norm(gr) - ref_norm) / max(ref_norm, 1e-30)
         n_checked += 1
-        if name in ("alpha", "beta"):        # (round 4: Sinkhorn potentials of the backward in float64; observed <= 6e-4)
+        if name in ("alpha", "beta"):
+            # Sums over all N x M affinities with heavy cancellation: at fp32 the reference's OWN value sits 3e-4 (alpha) /
+            # 5e-5 (beta) from the float64 oracle's autograd on the same step (scripts/dalpha_probe.py), so 1e-4
+            # against the reference is not a meaningful bar.  Anchor = the float64 oracle: ours must be within 1e-4 of
+            # it, or at most twice as far from it as the reference's fp32 backward is (observed: 3.9e-4 vs 2.7e-4 for
+            # alpha, 2.9e-5 vs 4.7e-5 for beta); the window against the reference itself stays at 1e-3.
             assert nerr <= 1e-3, f"{tag}/{which} {name}: deviates by {nerr:.2e}"
+            f64 = _f64_sinkhorn_scalar_grads(tag, which)[name]
+            ours, ref_v = float(gr[0]), float(ref_e.reshape(-1)[0])
+            e_ours, e_ref = abs(ours - f64) / abs(f64), abs(ref_v - f64) / abs(f64)
+            assert e_ours <= max(1e-4, 2.0 * e_ref), f"{tag}/{which} d{name}: {e_ours:.2e} from float64 (reference: {e_ref:.2e})"
         elif name.startswith("kpf_encoder."):
             n_enc += 1
             enc_loose += err > 1e-4
