@@ -1,6 +1,8 @@
 """GPU: the fused cross-encoder stack (csrc/xenc.hip, spr_xenc_forward) against the reference's
 golden layer output, the float64 oracle of the same layers (oracle/torch_oracle.py: layer_pre /
 transformer, which restate transformers.py:184-245 and :27-59) and the per-operator HIP route."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -155,3 +157,23 @@ def test_many_small_segments(device):
             assert (enc._spr_xenc is not None) == fused_expected
             plain = enc.forward_packed(x, cu, s_self, s_cross, mx, pos=pos)
         _close(y.cpu().numpy(), plain.cpu().numpy(), 5e-6, f"{2 * npairs} segments")
+
+
+def test_row_major_attention_output_route(device, tmp_path):
+    """The chains read the attention output TILED when the core that runs is k_attn_s (it writes the tiles itself)
+    and row-major otherwise (SPR_ATTN_CORE=h3: the round-4 core).  Both routes, each in its own process (the switch is
+    read once), must agree to rounding: ragged clouds incl. a one-token and a 33-token one."""
+    import subprocess, sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_xenc_route_child.py")
+    outs = {}
+    for core in ("s", "h3"):
+        env = dict(os.environ)
+        env.pop("SPR_ATTN_CORE", None)
+        if core == "h3":
+            env["SPR_ATTN_CORE"] = "h3"
+        f = str(tmp_path / f"route_{core}.pt")
+        subprocess.run([sys.executable, child, f], check=True, env=env, timeout=300)
+        outs[core] = torch.load(f)
+    scale = float(outs["s"].abs().max())
+    assert torch.isfinite(outs["s"]).all() and torch.isfinite(outs["h3"]).all()
+    assert float((outs["s"] - outs["h3"]).abs().max()) <= 5e-6 * scale
