@@ -1072,11 +1072,6 @@ __global__ __launch_bounds__(512, (RingShape<CC, COUT, NS>::MINW)) void k_kpconv
   for (; tile < ntiles; par ^= 1) {
     const int4 d = d_cur;
     KP_STAMP(1);
-#ifdef SPR_KP_STAGGER
-    // experiment (MI355X_MICROARCH.md, two waves per SIMD, item 9): the partner waves of a SIMD (w and w + 4) run the
-    // same program and fall into lockstep; delay the younger half by a fraction of an item at the start of phase 1
-    if (wave >= 4) __builtin_amdgcn_s_sleep(SPR_KP_STAGGER);
-#endif
     const int n_items = d.z + d.w;
     // descriptor two tiles ahead (scalar load; its index rows are staged at the end of this phase 1)
     int4 d_nn = make_int4(-1, -1, 0, 0);
